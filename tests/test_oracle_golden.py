@@ -1,0 +1,84 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors produced by the reference itself
+(tools/make_goldens.py imports /root/reference; only the .npz outputs are committed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adapose_ref, postproc_ref, ppo_ref
+from rgbmanip_amd import synth
+
+RTOL = 1e-4  # north_star: 1e-4 relative fp32
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+
+
+def test_layers_against_reference_modules(golden_dir, sd):
+    g = np.load(os.path.join(golden_dir, "adapose_layers.npz"))
+    with torch.no_grad():
+        y = adapose_ref.pspnet(torch.from_numpy(g["psp_in"]), sd)
+        assert _rel(y.numpy(), g["psp_out"]) < 1e-5
+        pv = adapose_ref.cost_reg_net(torch.from_numpy(g["cr_in"]), sd)
+        assert _rel(pv.numpy(), g["cr_out"]) < 1e-5
+        wv = adapose_ref.homo_warping(torch.from_numpy(g["warp_fea"]), torch.from_numpy(g["warp_Psrc"]),
+                                      torch.from_numpy(g["warp_Pref"]), torch.from_numpy(g["warp_depths"]))
+        assert _rel(wv.numpy(), g["warp_out"]) < 1e-5
+
+
+def test_full_forward_b2(golden_dir, sd):
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    inp = {k: torch.from_numpy(v) for k, v in synth.adapose_inputs(2, seed=0).items()}
+    taps = {}
+    out = adapose_ref.adapose_forward(sd, inp["img1"], inp["choose1"], inp["img2"], inp["choose2"],
+                                      inp["P1"], inp["P2"], inp["depths"], taps=taps)
+    for k, v in out.items():
+        assert _rel(v.numpy(), g[k]) < RTOL, k
+    assert abs(float(taps["feat1"].abs().mean()) - float(g["absmean_feat1"])) < 1e-4
+
+
+def test_postproc_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    for i in range(int(g["n_cases"])):
+        bb = postproc_ref.bbox_world(g[f"c{i}_in_nocs"], g[f"c{i}_in_depth"], g[f"c{i}_in_R"],
+                                     g[f"c{i}_in_choose"], g[f"c{i}_in_K"], g[f"c{i}_in_E"])
+        np.testing.assert_allclose(bb, g[f"c{i}_bbox"], rtol=1e-9, atol=1e-9, err_msg=f"case {i}")
+    for box, exp in zip(g["get_bbox_in"], g["get_bbox_out"]):
+        assert list(postproc_ref.get_bbox([int(x) for x in box])) == [int(x) for x in exp]
+
+
+def test_ppo_act_evaluate_gae_update(golden_dir):
+    import yaml  # noqa: F401
+    g = np.load(os.path.join(golden_dir, "ppo.npz"))
+    cfg = dict(num_mini_batches=4, num_learning_epochs=8, clip_range=0.2, desired_kl=0.016, min_lr=2e-4,
+               max_lr=5e-3, value_loss_coef=1.0, entropy_coef=0.0, max_grad_norm=1.0)
+    N, T = 32, 16
+    sd = {k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()}
+    roll = {k: torch.from_numpy(v) for k, v in synth.ppo_rollout(T, N, seed=0).items()}
+    a, logp, v, mu, _ = ppo_ref.act(sd, roll["observations"][0], torch.from_numpy(g["n32_act_eps"]))
+    assert _rel(a, g["n32_act_a"]) < 1e-5 and _rel(logp, g["n32_act_logp"]) < 1e-5
+    assert _rel(v, g["n32_act_v"]) < 1e-5 and _rel(mu, g["n32_act_mu"]) < 1e-5
+    lp, ent, vv, _, _ = ppo_ref.evaluate(sd, roll["observations"][0], roll["actions"][0])
+    assert _rel(lp, g["n32_eval_logp"]) < 1e-5 and _rel(ent, g["n32_eval_ent"]) < 1e-5
+    ret, adv = ppo_ref.compute_returns(roll["rewards"], roll["dones"], roll["values"], roll["last_values"], 0.98, 0.98)
+    assert _rel(ret, g["n32_returns"]) < 1e-6 and _rel(adv, g["n32_advantages"]) < 1e-5
+    r2 = dict(roll)
+    r2["actions_log_prob"] = torch.from_numpy(g["n32_actions_log_prob"])
+    r2["mu"] = torch.from_numpy(g["n32_mu"])
+    r2["sigma"] = torch.from_numpy(g["n32_sigma"])
+    mvl, msl, lr, _ = ppo_ref.ppo_update(sd, r2, torch.from_numpy(g["n32_returns"]), torch.from_numpy(g["n32_advantages"]),
+                                         cfg, 1e-5)
+    flat = torch.cat([sd[k].reshape(-1) for k in synth.policy_state_dict(seed=0).keys()])
+    assert abs(lr - float(g["n32_lr_after"])) < 1e-12
+    assert abs(mvl - float(g["n32_mvl"])) < 1e-3 * abs(float(g["n32_mvl"]))
+    assert abs(msl - float(g["n32_msl"])) < 1e-3 * abs(float(g["n32_msl"])) + 1e-6
+    assert _rel(flat, g["n32_params_after"]) < 1e-3

@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE modules from /root/reference.
+
+Runs only in the build container (the reference never travels to the GPU box; only the
+small .npz outputs written here are committed).  Recipe = SURVEY.md Appendix C:
+stub torchvision/cv2/ipdb/gym/sapien/tensorboard, make Tensor.cuda the identity
+(rotation_utils.py:6 hard-codes .cuda()), put the net in .eval().
+
+Inputs and weights come from rgbmanip_amd.synth (seeded; regenerated identically by tests).
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+sys.path.insert(1, REF)
+
+import numpy as np
+import torch
+import yaml
+
+
+def stub(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+    return m
+
+
+class _Space:
+    pass
+
+
+class _Box(_Space):
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.shape = tuple(shape) if shape is not None else np.asarray(low).shape
+        self.low = np.full(self.shape, low, dtype=np.float32) if np.isscalar(low) else np.asarray(low)
+        self.high = np.full(self.shape, high, dtype=np.float32) if np.isscalar(high) else np.asarray(high)
+        self.dtype = dtype
+
+
+class _Dict(_Space):
+    def __init__(self, spaces=None):
+        self.spaces = spaces or {}
+
+
+class _SW:
+    def __init__(self, *a, **k):
+        pass
+
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def install_stubs():
+    stub("torchvision", models=stub("torchvision.models"))
+    stub("cv2")
+    stub("ipdb")
+    spaces = stub("gym.spaces", Space=_Space, Box=_Box, Dict=_Dict)
+    gv = stub("gym.vector")
+    gvu = stub("gym.vector.utils", shared_memory=stub("gym.vector.utils.shared_memory"))
+    gv.utils = gvu
+    stub("gym", spaces=spaces, vector=gv, Env=object)
+    sc = stub("sapien.core", Pose=object)
+    stub("sapien", core=sc)
+    stub("torch.utils.tensorboard", SummaryWriter=_SW)
+    stub("env.my_vec_env", MultiVecEnv=object)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def strided(t, n=64):
+    f = t.reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone().numpy()
+
+
+def gen_adapose(out_dir):
+    from models.pose_estimator.AdaPose.lib.network_v5 import StereoPoseNet_with_depth
+    from rgbmanip_amd import synth
+
+    net = StereoPoseNet_with_depth(n_cat=1, nv_pts=1024, regress_pose=True).eval()
+    sd = synth.adapose_state_dict(seed=0)
+    missing = net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    print("load_state_dict:", missing)
+    B = 2
+    inp = synth.adapose_inputs(B, seed=0)
+    tin = {k: torch.from_numpy(v) for k, v in inp.items()}
+    inter = {}
+
+    def hook(name):
+        def f(mod, i, o):
+            inter.setdefault(name, o.detach())
+        return f
+    ie = net.img_extractor
+    hs = [ie.feats.conv1.register_forward_hook(hook("v1_conv1_raw")),
+          ie.feats.maxpool.register_forward_hook(hook("v1_pool")),
+          ie.feats.layer1.register_forward_hook(hook("v1_layer1")),
+          ie.feats.layer2.register_forward_hook(hook("v1_layer2")),
+          ie.feats.layer3.register_forward_hook(hook("v1_layer3")),
+          ie.feats.layer4.register_forward_hook(hook("v1_layer4")),
+          ie.psp.register_forward_hook(hook("v1_psp")),
+          ie.up_1.register_forward_hook(hook("v1_up_1")),
+          ie.up_2.register_forward_hook(hook("v1_up_2")),
+          ie.up_3.register_forward_hook(hook("v1_up_3")),
+          ie.register_forward_hook(hook("feat1")),
+          net.cost_regularization.conv0.register_forward_hook(hook("v1_c0")),
+          net.cost_regularization.conv2.register_forward_hook(hook("v1_c2")),
+          net.cost_regularization.conv4.register_forward_hook(hook("v1_c4")),
+          net.cost_regularization.conv6.register_forward_hook(hook("v1_c6")),
+          net.cost_regularization.conv7.register_forward_hook(hook("v1_d7")),
+          net.cost_regularization.conv9.register_forward_hook(hook("v1_d9")),
+          net.cost_regularization.conv11.register_forward_hook(hook("v1_d11")),
+          net.cost_regularization.prob.register_forward_hook(hook("v1_probvol"))]
+    with torch.no_grad():
+        out = net(tin["img1"], tin["choose1"], tin["img2"], tin["choose2"], tin["P1"], tin["P2"], tin["depths"])
+        # run twice: eval mode must be deterministic
+        out2 = net(tin["img1"], tin["choose1"], tin["img2"], tin["choose2"], tin["P1"], tin["P2"], tin["depths"])
+    for h in hs:
+        h.remove()
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k
+    save = {k: v.numpy() for k, v in out.items()}
+    for k, v in inter.items():
+        save["slice_" + k] = strided(v)
+        save["absmean_" + k] = np.array(v.abs().mean().item(), dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, "adapose_b2.npz"), **save)
+    for k, v in out.items():
+        print(k, tuple(v.shape), float(v.abs().mean()), bool(torch.isfinite(v).all()))
+    print("depth range", out["view1_depth"].min().item(), out["view1_depth"].max().item())
+
+    # reduced-shape layer fixtures straight from reference sub-modules
+    g = np.random.default_rng(5)
+    with torch.no_grad():
+        x = torch.from_numpy(g.normal(size=(2, 3, 64, 64)).astype(np.float32))
+        y = ie(x)
+        vol = torch.from_numpy(g.normal(size=(1, 32, 8, 16, 16)).astype(np.float32))
+        pv = net.cost_regularization(vol)
+        fea = torch.from_numpy(g.normal(size=(2, 32, 16, 16)).astype(np.float32))
+        K = np.array([[20.0, 0, 8, 0], [0, 20.0, 8, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        E1 = np.eye(4)
+        E2 = np.eye(4)
+        E2[0, 3] = -0.1
+        E2[2, 3] = 0.02
+        Pa = torch.from_numpy(np.stack([K @ E1, K @ E1]).astype(np.float32))
+        Pb = torch.from_numpy(np.stack([K @ E2, K @ E2]).astype(np.float32))
+        dv = torch.from_numpy(np.tile(np.arange(0.1, 0.85, 0.1, dtype=np.float32)[None], (2, 1)))
+        wv = net.homo_warping(fea, Pb, Pa, dv)
+    np.savez_compressed(os.path.join(out_dir, "adapose_layers.npz"),
+                        psp_in=x.numpy(), psp_out=y.numpy(), cr_in=vol.numpy(), cr_out=pv.numpy(),
+                        warp_fea=fea.numpy(), warp_Psrc=Pb.numpy(), warp_Pref=Pa.numpy(), warp_depths=dv.numpy(),
+                        warp_out=wv.numpy())
+    return out, inp
+
+
+def gen_postproc(out_dir, net_out, inp):
+    from models.pose_estimator.AdaPose.lib import utils as U
+
+    cases = {}
+    g = np.random.default_rng(11)
+
+    def run_case(nocs, depth, R, choose, K, E1):
+        # glue = interface_v5.py:318-321,354-374 around the reference's own lib/utils.py functions
+        default_bbox = np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1],
+                                   [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]]) + 10.0
+        with np.errstate(all="ignore"):
+            tt, ts = U.compute_scale_and_translation(depth, nocs, choose, K, 224, R)
+            half = np.max(abs(nocs), axis=0)
+            size = 2 * half * ts
+            bbox = U.get_3d_bbox(size)
+            sRT = np.eye(4).astype(np.float32)
+            sRT[:3, :3] = R
+            sRT[:3, 3] = tt.flatten()
+            bbox = U.transform_coordinates_3d(bbox, sRT)
+            ex_inv = np.linalg.inv(E1)
+            if np.isfinite(ex_inv).all() and np.isfinite(bbox).all():
+                return (ex_inv[:3, :3] @ bbox + ex_inv[:3, 3:4]).T, tt, ts
+            return default_bbox, tt, ts
+
+    idx = 0
+    # cases 0,1: the network outputs of the golden forward
+    for b in range(2):
+        nocs = net_out["view1_nocs"][b].numpy()
+        depth = net_out["view1_depth"][b].numpy()
+        R = net_out["view1_r"][b].numpy()
+        bb, tt, ts = run_case(nocs, depth, R, inp["choose1"][b], inp["K1"][b], inp["E1"][b])
+        cases[f"c{idx}_in_nocs"], cases[f"c{idx}_in_depth"], cases[f"c{idx}_in_R"] = nocs, depth, R
+        cases[f"c{idx}_in_choose"], cases[f"c{idx}_in_K"], cases[f"c{idx}_in_E"] = inp["choose1"][b], inp["K1"][b], inp["E1"][b]
+        cases[f"c{idx}_bbox"], cases[f"c{idx}_t"], cases[f"c{idx}_s"] = bb, np.asarray(tt), np.asarray(ts)
+        idx += 1
+    # random well-posed cases + degenerate ones
+    for kind in ("rand", "rand", "rand", "even", "empty_valid", "nan_depth"):
+        nocs = g.uniform(-0.45, 0.45, size=(1024, 3)).astype(np.float32)
+        depth = g.uniform(0.5, 0.8, size=(1024,)).astype(np.float32)
+        q, _ = np.linalg.qr(g.normal(size=(3, 3)))
+        R = q.astype(np.float32)
+        choose = np.sort(g.choice(224 * 224, size=1024, replace=False)).astype(np.int64)
+        K = np.array([[300.0, 0, 112.0], [0, 300.0, 112.0], [0, 0, 1]])
+        E = np.eye(4)
+        E[:3, :3] = np.linalg.qr(g.normal(size=(3, 3)))[0]
+        E[:3, 3] = g.normal(size=3)
+        if kind == "even":
+            choose[512:] = choose[:512]           # duplicates (wrap padding, Appendix B-15)
+            nocs[512:] = nocs[:512]
+            depth[512:] = depth[:512]
+        if kind == "empty_valid":
+            nocs[:] = nocs[0]                     # all nocs distances 0 -> empty set -> nan -> default bbox
+        if kind == "nan_depth":
+            depth[3] = np.nan
+        bb, tt, ts = run_case(nocs, depth, R, choose, K, E)
+        cases[f"c{idx}_in_nocs"], cases[f"c{idx}_in_depth"], cases[f"c{idx}_in_R"] = nocs, depth, R
+        cases[f"c{idx}_in_choose"], cases[f"c{idx}_in_K"], cases[f"c{idx}_in_E"] = choose, K, E
+        cases[f"c{idx}_bbox"], cases[f"c{idx}_t"], cases[f"c{idx}_s"] = bb, np.asarray(tt), np.asarray(ts)
+        print("postproc case", idx, kind, "scale", ts, "bbox0", bb[0])
+        idx += 1
+    cases["n_cases"] = np.array(idx)
+    # get_bbox table
+    gb_in, gb_out = [], []
+    for _ in range(64):
+        y1, x1 = int(g.integers(0, 470)), int(g.integers(0, 630))
+        y2, x2 = int(g.integers(y1, 480)), int(g.integers(x1, 640))
+        gb_in.append([y1, x1, y2, x2])
+        gb_out.append(list(U.get_bbox([y1, x1, y2, x2])))
+    cases["get_bbox_in"] = np.array(gb_in)
+    cases["get_bbox_out"] = np.array(gb_out)
+    np.savez_compressed(os.path.join(out_dir, "postproc.npz"), **cases)
+
+
+def gen_ppo(out_dir):
+    from algo.ppo.ppo import PPO, ActorCritic, RolloutStorage
+    from rgbmanip_amd import synth
+
+    cfg = yaml.safe_load(open(os.path.join(REF, "cfg/controller/rl.yaml")))
+    cfg["learn"]["device"] = "cpu"
+    cfg["learn"]["log_dir"] = "/tmp/rgbm_gold_logs"
+    cfg["learn"]["save_dir"] = "/tmp/rgbm_gold_saves"
+    save = {}
+    for N in (32, 512):
+        T = cfg["learn"]["num_transitions_per_env"]
+
+        class FakeEnv:
+            num_envs = N
+            observation_space = _Box(-1.5, 1.5, (60,))
+            state_space = _Box(-1.5, 1.5, (75,))
+            action_space = _Box(-1.5, 1.5, (12,))
+        ppo = PPO(FakeEnv(), cfg)
+        sd = synth.policy_state_dict(seed=0)
+        ppo.actor_critic.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        roll = synth.ppo_rollout(T, N, seed=0)
+        tr = {k: torch.from_numpy(v) for k, v in roll.items()}
+        # act with a recorded noise draw
+        torch.manual_seed(123)
+        a, logp, v, mu, sig = ppo.actor_critic.act(tr["observations"][0], tr["states"][0])
+        torch.manual_seed(123)
+        eps = torch.randn(N, 12)
+        recon = mu + torch.exp(2 * ppo.actor_critic.log_std.detach()) * eps
+        print(f"N={N} act sample reconstruction max err", (recon - a).abs().max().item())
+        tag = f"n{N}_"
+        if N == 32:
+            save.update({tag + "act_eps": eps.numpy(), tag + "act_a": a.numpy(), tag + "act_logp": logp.numpy(),
+                         tag + "act_v": v.numpy(), tag + "act_mu": mu.numpy()})
+        # fill the storage: actions from the rollout, logp/mu/sigma from evaluate of the *initial* policy with an offset
+        with torch.no_grad():
+            for t in range(T):
+                lp, ent, vv, mm, ss, _ = ppo.actor_critic.evaluate(tr["observations"][t], None, tr["actions"][t])
+                mm = mm + 0.02 * torch.sin(torch.arange(12.0))[None]      # pretend the behaviour policy differed a bit
+                ppo.storage.add_transitions(tr["observations"][t], tr["states"][t], tr["actions"][t],
+                                            tr["rewards"][t].view(-1), tr["dones"][t].view(-1), tr["values"][t],
+                                            lp - 0.01, mm, ss - 0.005)
+                if N == 32 and t == 0:
+                    save.update({tag + "eval_logp": lp.numpy(), tag + "eval_ent": ent.numpy(), tag + "eval_v": vv.numpy()})
+        ppo.storage.compute_returns(tr["last_values"], cfg["learn"]["gamma"], cfg["learn"]["lam"])
+        st = ppo.storage
+        rec = {"returns": st.returns, "advantages": st.advantages, "actions_log_prob": st.actions_log_prob,
+               "mu": st.mu, "sigma": st.sigma}
+        mvl, msl = ppo.update(0)
+        flat = torch.cat([p.detach().reshape(-1) for p in ppo.actor_critic.state_dict().values()])
+        print(f"N={N} update: value_loss {mvl:.6f} surrogate {msl:.6f} lr {ppo.step_size}")
+        if N == 32:
+            for k, val in rec.items():
+                save[tag + k] = val.numpy()
+            save[tag + "params_after"] = flat.numpy()
+        else:
+            save[tag + "returns_sum"] = np.array(rec["returns"].double().sum().item())
+            save[tag + "adv_abs_sum"] = np.array(rec["advantages"].double().abs().sum().item())
+            save[tag + "returns_slice"] = strided(rec["returns"])
+            save[tag + "adv_slice"] = strided(rec["advantages"])
+            save[tag + "params_after_slice"] = strided(flat, 256)
+        save[tag + "mvl"] = np.array(mvl)
+        save[tag + "msl"] = np.array(msl)
+        save[tag + "lr_after"] = np.array(ppo.step_size)
+    np.savez_compressed(os.path.join(out_dir, "ppo.npz"), **save)
+
+
+if __name__ == "__main__":
+    install_stubs()
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["adapose", "postproc", "ppo"]
+    net_out = inp = None
+    if "adapose" in which or "postproc" in which:
+        net_out, inp = gen_adapose(out_dir)
+    if "postproc" in which:
+        gen_postproc(out_dir, net_out, inp)
+    if "ppo" in which:
+        gen_ppo(out_dir)
+    print("done")
