@@ -1,0 +1,118 @@
+/* rgbm.h — C ABI of librgbm_hip.so (MI355X / gfx950).
+ *
+ * The reference (hyperplane-lab/RGBManip) is pure Python and has no FFI: its "plugin ABI" for this path is the
+ * set of Python classes selected by Hydra name strings.  Each entry point below states which reference
+ * interface it stands in for (paths relative to /root/reference).  The Python classes in rgbmanip_amd/ mirror
+ * those interfaces and bind these functions through ctypes.
+ *
+ * Conventions: every function returns 0 on success, a negative code on error (rgbm_last_error() has the text);
+ * all `*_dev` / device pointers are HIP device memory owned by the caller (e.g. the PyTorch caching allocator);
+ * all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) with no hidden
+ * synchronisation; handles own only their packed weights; a handle is not thread-safe, distinct handles are.
+ * dtype: 0 = fp32 (exact-fp32 MFMA, the parity gate), 1 = bf16 storage + fp32 accumulate (throughput mode).
+ */
+#ifndef RGBM_H_
+#define RGBM_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBM_VERSION 100
+#define RGBM_F32 0
+#define RGBM_BF16 1
+
+int rgbm_version(void);
+const char* rgbm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * AdaPose estimator network.
+ * Replaces: StereoPoseNet_with_depth.__init__/load_state_dict and .forward
+ *   models/pose_estimator/AdaPose/lib/network_v5.py:301-376, 418-519   (called from interface_v5.py:43-56, 279-280)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct rgbm_weight_desc {
+  const char* name;        /* state_dict key, with or without the DataParallel "module." prefix */
+  const float* data;       /* host fp32, contiguous, PyTorch layout */
+  int ndim;
+  const int64_t* shape;
+} rgbm_weight_desc;
+
+typedef struct rgbm_adapose rgbm_adapose_t;
+
+typedef struct rgbm_adapose_out {   /* device fp32, shapes of the reference's output dict (network_v5.py:510-515) */
+  float *view1_nocs, *view2_nocs;   /* [B,1024,3] */
+  float *view1_depth, *view2_depth; /* [B,1024]   */
+  float *view1_r, *view2_r;         /* [B,3,3]    */
+  float *view1_t, *view2_t;         /* [B,3]      */
+  float *view1_s, *view2_s;         /* [B,3]      */
+} rgbm_adapose_out;
+
+/* norm_mode: 0 = eval-mode BatchNorm3d folded into the convs (the parity oracle). */
+int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode);
+int rgbm_adapose_destroy(rgbm_adapose_t* h);
+/* views per cost-volume chunk (default 32); bounds the workspace */
+int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
+int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
+/* img1/img2 [B,3,224,224] fp32 NCHW normalised; choose1/2 [B,1024] int32; P1/P2 [B,4,4] fp32; depths [B,24] fp32.
+ * Same argument meaning as network_v5.py:418 (view1_img, view1_choose, view2_img, view2_choose, view1_proj,
+ * view2_proj, depth_values).  workspace must be 256-byte aligned. */
+int rgbm_adapose_forward(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                         const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                         size_t workspace_bytes, const rgbm_adapose_out* out, void* stream);
+
+/* Post-processing of one batch of network outputs into world-frame handle boxes.
+ * Replaces: compute_scale_and_translation / get_3d_bbox / transform_coordinates_3d and the tail of predict()
+ *   models/pose_estimator/AdaPose/lib/utils.py:40-119, models/pose_estimator/AdaPose/interface_v5.py:318-321,354-374
+ * nocs1 [B,P,3] f32, depth1 [B,P] f32, r1 [B,3,3] f32, choose1 [B,P] i32, Kcrop [B,3,3] f64 (cropped intrinsics),
+ * E1 [B,4,4] f64 (world->camera of view 1)  ->  bbox_world [B,8,3] f64, ts [B,4] f64 (t xyz, scale), valid [B] i32
+ * (0 where the reference would return default_bbox (+10 cube), which is what bbox_world then holds). */
+int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, const float* depth1, const float* r1,
+                             const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
+                             int32_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * PPO rollout storage.
+ * Replaces: RolloutStorage.compute_returns   algo/ppo/ppo/storage.py:50-64
+ * rewards/values/returns/adv [T,N] f32, dones [T,N] u8, last_values [N] f32.
+ * sums: device f64 buffer with room for 2 + 2*ceil(N/256) doubles; on return sums[0..1] = {sum(adv), sum(adv^2)}
+ * of the un-normalised advantages (all-reduce these two over ranks for the global normalisation), then
+ * rgbm_adv_normalise applies (adv - mean) / (unbiased_std + 1e-8) with count_total = T*N summed over ranks.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rgbm_gae(int T, int N, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+             float gamma, float lam, float* returns, float* adv, double* sums, void* stream);
+int rgbm_adv_normalise(int64_t n_local, float* adv, const double* sums, double count_total, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layer-level entry points (used by the parity tests and by the Python host for pieces it drives itself).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Generic N-D convolution on channels-last tensors, weights given in PyTorch layout on the host
+ * (nn.Conv2d/Conv3d: [Cout][Cin][KD][KH][KW]; nn.ConvTranspose3d(k3,s2,p1,op1) when transposed=1: [Cin][Cout][3][3][3]).
+ * in_dev [N][D][H][W][Cin_pad], out_dev [N][Do][Ho][Wo][Cout_pad] in `dtype`; act 0 none 1 relu 2 prelu 3 tanh;
+ * res_mode 0 none 1 add before activation 2 add after activation. */
+int rgbm_conv_nd(int dtype, const void* in_dev, int N, int D, int H, int W, int Cin, int Cin_pad, const float* w_host,
+                 int Cout, int Cout_pad, int KD, int KH, int KW, int stride_d, int stride_hw, int pad_d, int pad_hw,
+                 int dil_hw, int transposed, const float* bias_host, const float* bn_scale_host, const float* bn_shift_host,
+                 const void* res_dev, int res_mode, int act, float slope, void* out_dev, void* stream);
+int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream);
+int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
+                            void* stream);
+int rgbm_adaptive_avgpool(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, int S, void* stream);
+/* fused plane-sweep volume for views [0,V): feat [V][H][W][32] (dtype), P [V][4][4] f32 (views ordered side*B+b),
+ * depths [B][D] f32 -> vol [V][D][H][W][32]; homog_scratch: V*12 floats */
+int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                      void* vol_dev, int V, int B, int D, int H, int W, void* stream);
+/* debugging access to a named intermediate of the last rgbm_adapose_forward on (h, B, workspace):
+ * converts it to fp32 into out_dev (elems = capacity in floats); *n_elems returns its size.  Intermediates of the
+ * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first. */
+int rgbm_adapose_forward_ex(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                            const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                            size_t workspace_bytes, const rgbm_adapose_out* out, int stop_after, void* stream);
+int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* name, float* out_dev, size_t capacity,
+                       size_t* n_elems, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBM_H_ */

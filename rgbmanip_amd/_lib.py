@@ -1,0 +1,90 @@
+"""ctypes binding of librgbm_hip.so (the C ABI declared in include/rgbm.h).
+
+The library is built in-tree by `rgbmanip_amd/csrc/build.sh` (hipcc, gfx950).  There is no CPU
+fallback: if the shared object is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgbm_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3
+RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
+
+
+class RgbmError(RuntimeError):
+    pass
+
+
+class WeightDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.POINTER(C.c_int64))]
+
+
+class AdaposeOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("view1_nocs", "view2_nocs", "view1_depth", "view2_depth", "view1_r", "view2_r",
+                                           "view1_t", "view2_t", "view1_s", "view2_s")]
+
+
+_vp, _i, _f, _d, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_int64
+
+# symbol -> (restype, argtypes); must list every function declared in include/rgbm.h
+SIGNATURES = {
+    "rgbm_version": (_i, []),
+    "rgbm_last_error": (C.c_char_p, []),
+    "rgbm_adapose_create": (_i, [C.POINTER(_vp), _i, C.POINTER(WeightDesc), _i, _i, _i]),
+    "rgbm_adapose_destroy": (_i, [_vp]),
+    "rgbm_adapose_set_chunk": (_i, [_vp, _i]),
+    "rgbm_adapose_workspace_bytes": (_i, [_vp, _i, C.POINTER(_sz)]),
+    "rgbm_adapose_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _vp]),
+    "rgbm_adapose_forward_ex": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _i, _vp]),
+    "rgbm_adapose_fetch": (_i, [_vp, _i, _vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
+    "rgbm_adapose_postprocess": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_gae": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "rgbm_adv_normalise": (_i, [_i64, _vp, _vp, _d, _vp]),
+    "rgbm_conv_nd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
+                          _vp, _i, _i, _f, _vp, _vp]),
+    "rgbm_maxpool3x3s2": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbm_build_volume": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RgbmError(f"{LIB_PATH} not found: build it with rgbmanip_amd/csrc/build.sh "
+                        f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().rgbm_last_error()
+        raise RgbmError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(stream=None):
+    """Raw hipStream_t of a torch.cuda.Stream (default: current stream)."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,140 @@
+"""Host-side wrapper of the HIP AdaPose network (the C ABI in include/rgbm.h).
+
+`AdaPoseNet` mirrors the call surface of the reference module `StereoPoseNet_with_depth`
+(`/root/reference/models/pose_estimator/AdaPose/lib/network_v5.py:301-519`): it is built from a
+state_dict with the reference's key names (optionally `module.`-prefixed, as saved by the
+reference's DataParallel wrapper, `interface_v5.py:48,55-56`) and called with
+`(view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values)`,
+returning the same 10-entry dict of tensors.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
+
+
+class AdaPoseNet:
+    def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.dtype_name = dtype
+        self.dtype = _DTYPES[dtype]
+        keep, descs = [], []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if a.dtype != np.float32:
+                if a.dtype.kind != "f":
+                    continue                      # num_batches_tracked (int64)
+                a = a.astype(np.float32)
+            a = np.ascontiguousarray(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape) if a.ndim else (C.c_int64 * 1)(1)
+            name = k.encode()
+            keep.append((a, shape, name))
+            descs.append(_lib.WeightDesc(name, a.ctypes.data, a.ndim, shape))
+        arr = (_lib.WeightDesc * len(descs))(*descs)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.rgbm_adapose_create(C.byref(self._h), device, arr, len(descs), self.dtype, 0), "rgbm_adapose_create")
+        if max_chunk_views:
+            _lib.check(self.lib.rgbm_adapose_set_chunk(self._h, int(max_chunk_views)), "rgbm_adapose_set_chunk")
+        self._ws = None
+        self._ws_B = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.rgbm_adapose_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def workspace_bytes(self, B: int) -> int:
+        n = C.c_size_t()
+        _lib.check(self.lib.rgbm_adapose_workspace_bytes(self._h, B, C.byref(n)), "rgbm_adapose_workspace_bytes")
+        return n.value
+
+    def _workspace(self, B: int):
+        if self._ws is None or self._ws_B != B:
+            self._ws = None
+            self._ws = torch.empty(self.workspace_bytes(B) + 256, dtype=torch.uint8, device=self.device)
+            self._ws_B = B
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    def _prep(self, t, dtype):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def forward(self, view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values,
+                stop_after: int = 0, stream=None):
+        img1 = self._prep(view1_img, torch.float32)
+        img2 = self._prep(view2_img, torch.float32)
+        ch1 = self._prep(view1_choose, torch.int32)
+        ch2 = self._prep(view2_choose, torch.int32)
+        P1 = self._prep(view1_proj, torch.float32)
+        P2 = self._prep(view2_proj, torch.float32)
+        dep = self._prep(depth_values, torch.float32)
+        B = img1.shape[0]
+        assert img1.shape == (B, 3, 224, 224) and img2.shape == img1.shape, img1.shape
+        assert ch1.shape == (B, 1024) and ch2.shape == ch1.shape
+        assert P1.shape == (B, 4, 4) and P2.shape == (B, 4, 4) and dep.shape == (B, 24)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = {
+            "view1_nocs": torch.empty(B, 1024, 3, **f32), "view2_nocs": torch.empty(B, 1024, 3, **f32),
+            "view1_depth": torch.empty(B, 1024, **f32), "view2_depth": torch.empty(B, 1024, **f32),
+            "view1_r": torch.empty(B, 3, 3, **f32), "view2_r": torch.empty(B, 3, 3, **f32),
+            "view1_t": torch.empty(B, 3, **f32), "view2_t": torch.empty(B, 3, **f32),
+            "view1_s": torch.empty(B, 3, **f32), "view2_s": torch.empty(B, 3, **f32),
+        }
+        o = _lib.AdaposeOut(*[out[n].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
+        ws_ptr, ws_bytes = self._workspace(B)
+        _lib.check(self.lib.rgbm_adapose_forward_ex(self._h, B, _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(ch1), _lib.ptr(ch2),
+                                                    _lib.ptr(P1), _lib.ptr(P2), _lib.ptr(dep), C.c_void_p(ws_ptr), ws_bytes,
+                                                    C.byref(o), stop_after, _lib.stream_ptr(stream)), "rgbm_adapose_forward")
+        self._last = (img1, img2, ch1, ch2, P1, P2, dep)     # keep inputs alive until the stream has consumed them
+        return out
+
+    __call__ = forward
+
+    def fetch(self, B: int, name: str, max_elems: int) -> torch.Tensor:
+        """Debug/test access to a named intermediate of the last forward (fp32, flat)."""
+        buf = torch.empty(max_elems, dtype=torch.float32, device=self.device)
+        n = C.c_size_t()
+        ws_ptr, _ = self._workspace(B)
+        _lib.check(self.lib.rgbm_adapose_fetch(self._h, B, C.c_void_p(ws_ptr), name.encode(), _lib.ptr(buf), max_elems,
+                                               C.byref(n), _lib.stream_ptr()), "rgbm_adapose_fetch")
+        return buf[: n.value]
+
+
+def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_size: int = 224, stream=None):
+    """Device post-processing: returns (bbox_world [B,8,3] f64, ts [B,4] f64, valid [B] i32) CUDA tensors.
+
+    Mirrors the tail of `AdaPoseEstimator_v5.predict` (`interface_v5.py:318-321,354-374`)."""
+    lib = _lib.load()
+    dev = view1_nocs.device
+    B, P = view1_depth.shape
+    nocs = view1_nocs.to(torch.float32).contiguous()
+    depth = view1_depth.to(torch.float32).contiguous()
+    r = view1_r.to(torch.float32).contiguous()
+    ch = torch.as_tensor(view1_choose).to(device=dev, dtype=torch.int32).contiguous()
+    K = torch.as_tensor(K_crop).to(device=dev, dtype=torch.float64).contiguous()
+    E = torch.as_tensor(E1).to(device=dev, dtype=torch.float64).contiguous()
+    bbox = torch.empty(B, 8, 3, dtype=torch.float64, device=dev)
+    ts = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    valid = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.rgbm_adapose_postprocess(B, P, img_size, _lib.ptr(nocs), _lib.ptr(depth), _lib.ptr(r), _lib.ptr(ch),
+                                            _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(ts), _lib.ptr(valid),
+                                            _lib.stream_ptr(stream)), "rgbm_adapose_postprocess")
+    return bbox, ts, valid

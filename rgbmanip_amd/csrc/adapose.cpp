@@ -1,0 +1,395 @@
+// AdaPose stereo pose network forward, orchestrated on one HIP stream.
+// Follows /root/reference/models/pose_estimator/AdaPose/lib/network_v5.py:418-519 (eval mode) with an
+// MI355X-first dataflow: channels-last tensors, BN folded into the 3-D convs, the probability conv and the
+// depth-guided fusion evaluated only at the 1024 sampled pixels, the cost volume processed in view chunks
+// so its footprint is bounded, the second half of pose_mlp2's first layer (global feature) turned into a
+// per-view bias.  Views are ordered v = side*B + b (all view-1 images, then all view-2 images).
+#include "adapose.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace rgbm {
+
+static const int kLayerPlanes[4] = {64, 128, 256, 512};
+static const int kLayerBlocks[4] = {3, 4, 6, 3};
+static const int kLayerStride[4] = {1, 2, 1, 1};
+static const int kLayerDil[4] = {1, 1, 2, 4};
+static const int kPspBins[4] = {1, 2, 3, 6};
+
+
+static const HostTensor* find(const StateDict& sd, const std::string& name) {
+  auto it = sd.find(name);
+  return it == sd.end() ? nullptr : &it->second;
+}
+
+#define GET(var, name)                                               \
+  const HostTensor* var = find(sd, name);                            \
+  RGBM_REQUIRE(var != nullptr, std::string("missing weight ") + (name))
+
+static int init_conv2d(ConvLayer& L, int dtype, const StateDict& sd, const std::string& wname, const char* bname, int Cin,
+                       int Cout, int k, int stride, int pad, int dil, int act, float slope, int Cin_pad) {
+  GET(w, wname);
+  RGBM_REQUIRE(w->numel() == (long long)Cout * Cin * k * k, "weight shape " + wname);
+  const float* b = nullptr;
+  if (bname) { GET(bt, std::string(bname)); b = bt->data; }
+  ConvGeom g;
+  g.Cin = Cin; g.Cout = Cout; g.KH = g.KW = k; g.sh = g.sw = stride; g.ph = g.pw = pad; g.dilh = g.dilw = dil;
+  g.act = act; g.slope = slope;
+  return L.init(dtype, g, w->data, b, nullptr, nullptr, Cin_pad, Cout);
+}
+
+static int bn_fold(const StateDict& sd, const std::string& p, int C, std::vector<float>& scale, std::vector<float>& shift) {
+  GET(gm, p + "weight"); GET(bt, p + "bias"); GET(mu, p + "running_mean"); GET(var, p + "running_var");
+  RGBM_REQUIRE(gm->numel() == C && bt->numel() == C && mu->numel() == C && var->numel() == C, "bn shape " + p);
+  scale.resize(C); shift.resize(C);
+  for (int i = 0; i < C; ++i) {
+    const float inv = 1.0f / sqrtf(var->data[i] + 1e-5f);
+    scale[i] = gm->data[i] * inv;
+    shift[i] = bt->data[i] - mu->data[i] * scale[i];
+  }
+  return 0;
+}
+
+static int init_conv3d_bn(ConvLayer& L, int dtype, const StateDict& sd, const std::string& p, int Cin, int Cout, int stride,
+                          bool transposed) {
+  GET(w, p + "conv.weight");
+  RGBM_REQUIRE(w->numel() == (long long)Cout * Cin * 27, "weight shape " + p);
+  std::vector<float> scale, shift;
+  if (int rc = bn_fold(sd, p + "bn.", Cout, scale, shift)) return rc;
+  ConvGeom g;
+  g.Cin = Cin; g.Cout = Cout; g.KD = g.KH = g.KW = 3; g.sd = g.sh = g.sw = stride; g.pd = g.ph = g.pw = 1;
+  g.transposed = transposed; g.act = ACT_RELU;
+  return L.init(dtype, g, w->data, nullptr, scale.data(), shift.data(), Cin, Cout);
+}
+
+static int init_linear(ConvLayer& L, const StateDict& sd, const std::string& p, int Cin, int Cout, int act, int Cin_pad,
+                       int Cout_pad, const float* w_override = nullptr) {
+  GET(w, p + ".weight"); GET(b, p + ".bias");
+  ConvGeom g;
+  g.Cin = Cin; g.Cout = Cout; g.act = act;
+  return L.init(F32, g, w_override ? w_override : w->data, b->data, nullptr, nullptr, Cin_pad, Cout_pad);
+}
+
+int AdaPose::create(const StateDict& sd, int dtype_) {
+  dtype = dtype_;
+  const int E = dtype == BF16 ? 8 : 4;
+  img_cpad = E;                              // RGB padded to one 16-byte chunk
+  const std::string fe = "img_extractor.feats.";
+  if (int rc = init_conv2d(conv1, dtype, sd, fe + "conv1.weight", nullptr, 3, 64, 7, 2, 3, 1, ACT_RELU, 0.f, img_cpad)) return rc;
+  int inpl = 64, nb = 0;
+  for (int li = 0; li < 4; ++li) {
+    for (int b = 0; b < kLayerBlocks[li]; ++b) {
+      Block& blk = blocks[nb++];
+      const int planes = kLayerPlanes[li];
+      const int cin = b == 0 ? inpl : planes;
+      const int stride = b == 0 ? kLayerStride[li] : 1;
+      const int dil = b == 0 ? 1 : kLayerDil[li];      // block 0 never dilated (pspnet.py:59-62)
+      const std::string p = fe + "layer" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
+      if (int rc = init_conv2d(blk.c1, dtype, sd, p + "conv1.weight", nullptr, cin, planes, 3, stride, dil, dil, ACT_RELU, 0.f, cin)) return rc;
+      if (int rc = init_conv2d(blk.c2, dtype, sd, p + "conv2.weight", nullptr, planes, planes, 3, 1, dil, dil, ACT_RELU, 0.f, planes)) return rc;
+      blk.has_ds = find(sd, p + "downsample.0.weight") != nullptr;
+      if (blk.has_ds)
+        if (int rc = init_conv2d(blk.ds, dtype, sd, p + "downsample.0.weight", nullptr, cin, planes, 1, stride, 0, 1, ACT_NONE, 0.f, cin)) return rc;
+      blk.stride = stride; blk.planes = planes;
+    }
+    inpl = kLayerPlanes[li];
+  }
+  n_blocks = nb;
+  for (int i = 0; i < 4; ++i)
+    if (int rc = init_conv2d(psp[i], dtype, sd, "img_extractor.psp.stages." + std::to_string(i) + ".1.weight", nullptr, 512, 128, 1, 1, 0, 1, ACT_RELU, 0.f, 512)) return rc;
+  struct { ConvLayer* L; const char* nm; int cin, cout; } ups[3] = {{&up1, "up_1", 1024, 256}, {&up2, "up_2", 256, 64}, {&up3, "up_3", 64, 64}};
+  for (auto& u : ups) {
+    const std::string p = std::string("img_extractor.") + u.nm + ".conv.";
+    GET(sl, p + "1.weight");
+    const std::string bn = p + "0.bias";
+    if (int rc = init_conv2d(*u.L, dtype, sd, p + "0.weight", bn.c_str(), u.cin, u.cout, 3, 1, 1, 1, ACT_PRELU, sl->data[0], u.cin)) return rc;
+  }
+  if (int rc = init_conv2d(fin, dtype, sd, "img_extractor.final.weight", "img_extractor.final.bias", 64, 32, 1, 1, 0, 1, ACT_NONE, 0.f, 64)) return rc;
+
+  const std::string cr = "cost_regularization.";
+  const int crc[8] = {32, 8, 16, 16, 32, 32, 64, 64};
+  const int crs[7] = {1, 2, 1, 2, 1, 2, 1};
+  for (int i = 0; i < 7; ++i)
+    if (int rc = init_conv3d_bn(c3d[i], dtype, sd, cr + "conv" + std::to_string(i) + ".", crc[i], crc[i + 1], crs[i], false)) return rc;
+  if (int rc = init_conv3d_bn(dc[0], dtype, sd, cr + "conv7.", 64, 32, 2, true)) return rc;
+  if (int rc = init_conv3d_bn(dc[1], dtype, sd, cr + "conv9.", 32, 16, 2, true)) return rc;
+  if (int rc = init_conv3d_bn(dc[2], dtype, sd, cr + "conv11.", 16, 8, 2, true)) return rc;
+  {
+    GET(w, cr + "prob.weight");
+    RGBM_REQUIRE(w->numel() == 8 * 27, "prob weight shape");
+    std::vector<float> wp(27 * 8);
+    for (int c = 0; c < 8; ++c) for (int t = 0; t < 27; ++t) wp[t * 8 + c] = w->data[c * 27 + t];
+    if (upload_f32(wp.data(), wp.size(), &wprob)) return -2;
+  }
+  // fp32 point heads as 1x1 convs
+  if (int rc = init_linear(inst, sd, "instance_color.0", 32, 64, ACT_RELU, 32, 64)) return rc;
+  if (int rc = init_linear(nh[0], sd, "nocs_head.0", 64, 128, ACT_RELU, 64, 128)) return rc;
+  if (int rc = init_linear(nh[1], sd, "nocs_head.2", 128, 64, ACT_RELU, 128, 64)) return rc;
+  if (int rc = init_linear(nh[2], sd, "nocs_head.4", 64, 3, ACT_TANH, 64, 4)) return rc;
+  if (int rc = init_linear(npm[0], sd, "nocs_pts_mlp.0", 3, 32, ACT_RELU, 4, 32)) return rc;
+  if (int rc = init_linear(npm[1], sd, "nocs_pts_mlp.2", 32, 64, ACT_RELU, 32, 64)) return rc;
+  if (int rc = init_linear(pm1[0], sd, "pose_mlp1.0", 96, 128, ACT_RELU, 96, 128)) return rc;
+  if (int rc = init_linear(pm1[1], sd, "pose_mlp1.2", 128, 128, ACT_RELU, 128, 128)) return rc;
+  {
+    // pose_mlp2.0 sees cat(point feature[128], global mean[128]); the global half becomes a per-view bias
+    GET(w, "pose_mlp2.0.weight"); GET(b, "pose_mlp2.0.bias");
+    RGBM_REQUIRE(w->numel() == 256 * 256, "pose_mlp2.0 shape");
+    std::vector<float> wl(256 * 128);
+    for (int o = 0; o < 256; ++o) for (int i = 0; i < 128; ++i) wl[o * 128 + i] = w->data[o * 256 + i];
+    if (int rc = init_linear(pm2[0], sd, "pose_mlp2.0", 128, 256, ACT_RELU, 128, 256, wl.data())) return rc;
+    if (upload_f32(w->data, 256 * 256, &pm2_0_wfull)) return -2;
+    if (upload_f32(b->data, 256, &pm2_0_bias)) return -2;
+  }
+  if (int rc = init_linear(pm2[1], sd, "pose_mlp2.2", 256, 256, ACT_RELU, 256, 256)) return rc;
+  const char* hn[3] = {"rotation_estimator", "translation_estimator", "size_estimator"};
+  const int hout[3] = {6, 3, 3};
+  for (int h = 0; h < 3; ++h) {
+    const int dims[4] = {256, 256, 128, hout[h]};
+    for (int l = 0; l < 3; ++l) {
+      GET(w, std::string(hn[h]) + "." + std::to_string(2 * l) + ".weight");
+      GET(b, std::string(hn[h]) + "." + std::to_string(2 * l) + ".bias");
+      RGBM_REQUIRE(w->numel() == (long long)dims[l] * dims[l + 1], "head weight shape");
+      if (upload_f32(w->data, w->numel(), &head_w[h][l])) return -2;
+      if (upload_f32(b->data, b->numel(), &head_b[h][l])) return -2;
+    }
+  }
+  return 0;
+}
+
+void AdaPose::destroy() {
+  conv1.destroy();
+  for (int i = 0; i < n_blocks; ++i) { blocks[i].c1.destroy(); blocks[i].c2.destroy(); if (blocks[i].has_ds) blocks[i].ds.destroy(); }
+  for (auto& l : psp) l.destroy();
+  up1.destroy(); up2.destroy(); up3.destroy(); fin.destroy();
+  for (auto& l : c3d) l.destroy();
+  for (auto& l : dc) l.destroy();
+  inst.destroy();
+  for (auto& l : nh) l.destroy();
+  for (auto& l : npm) l.destroy();
+  for (auto& l : pm1) l.destroy();
+  for (auto& l : pm2) l.destroy();
+  if (wprob) (void)hipFree(wprob);
+  if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
+  if (pm2_0_bias) (void)hipFree(pm2_0_bias);
+  for (int h = 0; h < 3; ++h) for (int l = 0; l < 3; ++l) { if (head_w[h][l]) (void)hipFree(head_w[h][l]); if (head_b[h][l]) (void)hipFree(head_b[h][l]); }
+}
+
+int AdaPose::chunk_views(int V) const { return V < max_chunk ? V : max_chunk; }
+
+// Shared by workspace_bytes() (base == nullptr) and forward(): identical allocation order => identical offsets.
+int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
+  const int V = 2 * B, P = n_pts, S = img;
+  const size_t es = dtype_size(dtype);
+  const size_t VP = (size_t)V * P;
+  bf.Pviews = (float*)A.alloc((size_t)V * 16 * 4);
+  bf.homog = (float*)A.alloc((size_t)V * 12 * 4);
+  bf.choose = (int*)A.alloc(VP * 4);
+  bf.feat = A.alloc((size_t)V * S * S * 32 * es);
+  bf.X0 = (float*)A.alloc(VP * 32 * 4);
+  bf.X1 = (float*)A.alloc(VP * 64 * 4);
+  bf.H128 = (float*)A.alloc(VP * 128 * 4);
+  bf.H64 = (float*)A.alloc(VP * 64 * 4);
+  bf.nocs4 = (float*)A.alloc(VP * 4 * 4);
+  bf.N32 = (float*)A.alloc(VP * 32 * 4);
+  bf.PF96 = (float*)A.alloc(VP * 96 * 4);
+  bf.prob = (float*)A.alloc(VP * n_depth * 4);
+  bf.depth = (float*)A.alloc(VP * 4);
+  bf.Q128a = (float*)A.alloc(VP * 128 * 4);
+  bf.Q128b = (float*)A.alloc(VP * 128 * 4);
+  bf.G256a = (float*)A.alloc(VP * 256 * 4);
+  bf.G256b = (float*)A.alloc(VP * 256 * 4);
+  bf.glob = (float*)A.alloc((size_t)V * 128 * 4);
+  bf.vbias = (float*)A.alloc((size_t)V * 256 * 4);
+  bf.pf2 = (float*)A.alloc((size_t)V * 256 * 4);
+  bf.h1 = (float*)A.alloc((size_t)V * 256 * 4);
+  bf.h2 = (float*)A.alloc((size_t)V * 128 * 4);
+  bf.r6 = (float*)A.alloc((size_t)V * 8 * 4);
+  bf.R = (float*)A.alloc((size_t)V * 9 * 4);
+  bf.tv = (float*)A.alloc((size_t)V * 4 * 4);
+  bf.sv = (float*)A.alloc((size_t)V * 4 * 4);
+  const size_t m0 = A.mark();
+  // ---- phase A: PSPNet ----
+  bf.imgpad = A.alloc((size_t)V * S * S * img_cpad * es);
+  bf.c1 = A.alloc((size_t)V * (S / 2) * (S / 2) * 64 * es);
+  const size_t lbuf = (size_t)V * ((size_t)(S / 4) * (S / 4) * 64 > (size_t)(S / 8) * (S / 8) * 512 ? (size_t)(S / 4) * (S / 4) * 64 : (size_t)(S / 8) * (S / 8) * 512) * es;
+  for (int i = 0; i < 4; ++i) bf.lb[i] = A.alloc(lbuf);
+  for (int i = 0; i < 4; ++i) {
+    bf.pooled[i] = A.alloc((size_t)V * kPspBins[i] * kPspBins[i] * 512 * es);
+    bf.stage[i] = A.alloc((size_t)V * kPspBins[i] * kPspBins[i] * 128 * es);
+  }
+  const size_t f8 = (size_t)(S / 8) * (S / 8), f4 = (size_t)(S / 4) * (S / 4), f2 = (size_t)(S / 2) * (S / 2), f1 = (size_t)S * S;
+  bf.cat = A.alloc((size_t)V * f8 * 1024 * es);
+  bf.ups = A.alloc((size_t)V * f4 * 1024 * es);      // == f2*256 == f1*64
+  bf.u1 = A.alloc((size_t)V * f4 * 256 * es);
+  bf.u2 = A.alloc((size_t)V * f2 * 64 * es);
+  bf.u3 = A.alloc((size_t)V * f1 * 64 * es);
+  A.release(m0);
+  // ---- phase B: cost volume, per chunk of views ----
+  const int Vc = chunk_views(V);
+  const int D = n_depth;
+  const size_t vox = (size_t)D * S * S;
+  bf.vol = A.alloc((size_t)Vc * vox * 32 * es);
+  bf.c[0] = A.alloc((size_t)Vc * vox * 8 * es);
+  bf.c[1] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
+  bf.c[2] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
+  bf.c[3] = A.alloc((size_t)Vc * (vox / 64) * 32 * es);
+  bf.c[4] = A.alloc((size_t)Vc * (vox / 64) * 32 * es);
+  bf.c[5] = A.alloc((size_t)Vc * (vox / 512) * 64 * es);
+  bf.c[6] = A.alloc((size_t)Vc * (vox / 512) * 64 * es);
+  bf.u7 = A.alloc((size_t)Vc * (vox / 64) * 32 * es);
+  bf.u9 = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
+  bf.u11 = A.alloc((size_t)Vc * vox * 8 * es);
+  A.release(m0);
+  return 0;
+}
+
+size_t AdaPose::workspace_bytes(int B) const {
+  Arena A(nullptr, 0);
+  Buffers bf;
+  plan(B, A, bf);
+  return A.peak + 256;
+}
+
+int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
+  const int S = img;
+  int H = S / 2, W = S / 2;
+  if (int rc = conv1.run(bf.imgpad, bf.c1, V, 1, S, S, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_maxpool3x3s2(dtype, bf.c1, bf.lb[0], V, H, W, 64, s)) return rc;
+  H = S / 4; W = S / 4;
+  int xi = 0;                                   // index of the buffer holding x
+  for (int i = 0; i < n_blocks; ++i) {
+    const Block& blk = blocks[i];
+    void* x = bf.lb[xi];
+    void* t = bf.lb[(xi + 1) & 3];
+    void* r = bf.lb[(xi + 2) & 3];
+    void* y = bf.lb[(xi + 3) & 3];
+    int Do, Ho, Wo;
+    blk.c1.out_dims(1, H, W, Do, Ho, Wo);
+    if (int rc = blk.c1.run(x, t, V, 1, H, W, blk.planes, nullptr, 0, nullptr, 0, s)) return rc;
+    const void* res = x;
+    if (blk.has_ds) {
+      if (int rc = blk.ds.run(x, r, V, 1, H, W, blk.planes, nullptr, 0, nullptr, 0, s)) return rc;
+      res = r;
+    }
+    if (int rc = blk.c2.run(t, y, V, 1, Ho, Wo, blk.planes, res, RES_PRE_ACT, nullptr, 0, s)) return rc;
+    H = Ho; W = Wo;
+    xi = (xi + 3) & 3;
+  }
+  const void* f = bf.lb[xi];                    // [V][H][W][512], H = W = S/8
+  last_f_index = xi;
+  RGBM_REQUIRE(H == S / 8 && W == S / 8, "feature stride");
+  if (int rc = launch_copy_channels(dtype, f, bf.cat, (long long)V * H * W, 512, 1024, 0, s)) return rc;
+  for (int i = 0; i < 4; ++i) {
+    const int Sb = kPspBins[i];
+    if (int rc = launch_adaptive_avgpool(dtype, f, bf.pooled[i], V, H, W, 512, Sb, s)) return rc;
+    if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, Sb, Sb, 128, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = launch_resize_bilinear_ac(dtype, bf.stage[i], bf.cat, V, Sb, Sb, 128, H, W, 1024, 512 + 128 * i, s)) return rc;
+  }
+  if (int rc = launch_resize_bilinear_ac(dtype, bf.cat, bf.ups, V, H, W, 1024, 2 * H, 2 * W, 1024, 0, s)) return rc;
+  if (int rc = up1.run(bf.ups, bf.u1, V, 1, 2 * H, 2 * W, 256, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_resize_bilinear_ac(dtype, bf.u1, bf.ups, V, 2 * H, 2 * W, 256, 4 * H, 4 * W, 256, 0, s)) return rc;
+  if (int rc = up2.run(bf.ups, bf.u2, V, 1, 4 * H, 4 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
+  if (int rc = up3.run(bf.ups, bf.u3, V, 1, 8 * H, 8 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = fin.run(bf.u3, bf.feat, V, 1, 8 * H, 8 * W, 32, nullptr, 0, nullptr, 0, s)) return rc;
+  return 0;
+}
+
+int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const {
+  const int S = img, D = n_depth, P = n_pts;
+  const int Vc0 = chunk_views(V);
+  for (int v0 = 0; v0 < V; v0 += Vc0) {
+    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+    if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
+    if (int rc = c3d[0].run(bf.vol, bf.c[0], Vc, D, S, S, 8, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[1].run(bf.c[0], bf.c[1], Vc, D, S, S, 16, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[2].run(bf.c[1], bf.c[2], Vc, D / 2, S / 2, S / 2, 16, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[3].run(bf.c[2], bf.c[3], Vc, D / 2, S / 2, S / 2, 32, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[4].run(bf.c[3], bf.c[4], Vc, D / 4, S / 4, S / 4, 32, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[5].run(bf.c[4], bf.c[5], Vc, D / 4, S / 4, S / 4, 64, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = c3d[6].run(bf.c[5], bf.c[6], Vc, D / 8, S / 8, S / 8, 64, nullptr, 0, nullptr, 0, s)) return rc;
+    // skip adds are post-ReLU (network_v5.py:287-289)
+    if (int rc = dc[0].run(bf.c[6], bf.u7, Vc, D / 8, S / 8, S / 8, 32, bf.c[4], RES_POST_ACT, nullptr, 0, s)) return rc;
+    if (int rc = dc[1].run(bf.u7, bf.u9, Vc, D / 4, S / 4, S / 4, 16, bf.c[2], RES_POST_ACT, nullptr, 0, s)) return rc;
+    if (int rc = dc[2].run(bf.u9, bf.u11, Vc, D / 2, S / 2, S / 2, 8, bf.c[0], RES_POST_ACT, nullptr, 0, s)) return rc;
+    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, s)) return rc;
+  }
+  return 0;
+}
+
+int AdaPose::forward(int B, const float* img1, const float* img2, const int* choose1, const int* choose2, const float* P1,
+                     const float* P2, const float* depths, void* workspace, size_t workspace_size, const Outputs& out,
+                     hipStream_t s, int stop_after) const {
+  RGBM_REQUIRE(B > 0, "batch");
+  RGBM_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  RGBM_REQUIRE(n_depth % 8 == 0 && img % 8 == 0, "depth/img must be multiples of 8");
+  const size_t need = workspace_bytes(B);
+  RGBM_REQUIRE(workspace_size >= need, "workspace too small: need " + std::to_string(need));
+  Arena A(workspace, workspace_size);
+  Buffers bf;
+  plan(B, A, bf);
+  const int V = 2 * B, P = n_pts, S = img, D = n_depth;
+  const size_t VP = (size_t)V * P;
+
+  // ---- stage inputs: views = [view1 batch ; view2 batch] ----
+  RGBM_CHECK_HIP(hipMemcpyAsync(bf.Pviews, P1, (size_t)B * 64, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(bf.Pviews + (size_t)B * 16, P2, (size_t)B * 64, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose, choose1, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose + (size_t)B * P, choose2, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
+  const size_t es = dtype_size(dtype);
+  if (int rc = launch_nchw_to_nhwc_pad(dtype, img1, bf.imgpad, B, 3, S, S, img_cpad, s)) return rc;
+  if (int rc = launch_nchw_to_nhwc_pad(dtype, img2, (char*)bf.imgpad + (size_t)B * S * S * img_cpad * es, B, 3, S, S, img_cpad, s)) return rc;
+
+  if (int rc = pspnet(bf, V, s)) return rc;
+  if (int rc = launch_homography(bf.Pviews, bf.homog, V, B, s)) return rc;
+  if (stop_after == 1) return 0;
+
+  // ---- per-point NOCS branch (network_v5.py:432-444) ----
+  if (int rc = launch_gather_points(dtype, bf.feat, bf.choose, bf.X0, V, P, S * S, 32, s)) return rc;
+  if (int rc = inst.run(bf.X0, bf.X1, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[0].run(bf.X1, bf.H128, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[1].run(bf.H128, bf.H64, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[2].run(bf.H64, bf.nocs4, V, 1, 1, P, 4, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = npm[0].run(bf.nocs4, bf.N32, V, 1, 1, P, 32, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = npm[1].run(bf.N32, bf.PF96 + 32, V, 1, 1, P, 96, nullptr, 0, nullptr, 0, s)) return rc;
+
+  // ---- plane-sweep cost volume -> probability at the sampled pixels -> depth ----
+  if (int rc = cost_volume(bf, V, B, depths, s)) return rc;
+  if (stop_after == 2) return 0;
+
+  // ---- depth-guided fusion + pose regression (network_v5.py:457-508) ----
+  if (int rc = launch_fuse_points(dtype, bf.feat, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s)) return rc;
+  if (int rc = pm1[0].run(bf.PF96, bf.Q128a, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_mean_points(bf.Q128b, bf.glob, V, P, 128, s)) return rc;
+  if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, V, 128, 256, 256, 128, 0, s)) return rc;
+  if (int rc = pm2[0].run(bf.Q128b, bf.G256a, V, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
+  if (int rc = pm2[1].run(bf.G256a, bf.G256b, V, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_mean_points(bf.G256b, bf.pf2, V, P, 256, s)) return rc;
+  float* hout[3] = {bf.r6, bf.tv, bf.sv};
+  const int hdim[3] = {6, 3, 3};
+  for (int h = 0; h < 3; ++h) {
+    if (int rc = launch_view_linear(bf.pf2, head_w[h][0], head_b[h][0], bf.h1, V, 256, 256, 256, 0, 1, s)) return rc;
+    if (int rc = launch_view_linear(bf.h1, head_w[h][1], head_b[h][1], bf.h2, V, 256, 128, 256, 0, 1, s)) return rc;
+    if (int rc = launch_view_linear(bf.h2, head_w[h][2], head_b[h][2], hout[h], V, 128, hdim[h], 128, 0, 0, s)) return rc;
+  }
+  if (int rc = launch_ortho6d(bf.r6, bf.R, V, s)) return rc;
+
+  // ---- outputs (fp32, reference shapes) ----
+  const size_t BP = (size_t)B * P;
+  if (int rc = launch_copy_cols(bf.nocs4, out.nocs1, (long long)BP, 4, 3, 3, s)) return rc;
+  if (int rc = launch_copy_cols(bf.nocs4 + BP * 4, out.nocs2, (long long)BP, 4, 3, 3, s)) return rc;
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.depth1, bf.depth, BP * 4, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.depth2, bf.depth + BP, BP * 4, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.r1, bf.R, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.r2, bf.R + (size_t)B * 9, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.t1, bf.tv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.t2, bf.tv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.s1, bf.sv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  RGBM_CHECK_HIP(hipMemcpyAsync(out.s2, bf.sv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  (void)VP;
+  return 0;
+}
+
+}  // namespace rgbm

@@ -1,0 +1,71 @@
+#pragma once
+#include "kernels.h"
+#include "layers.h"
+
+namespace rgbm {
+
+struct Arena {
+  char* base; size_t off; size_t cap; size_t peak;
+  explicit Arena(void* b, size_t c) : base((char*)b), off(0), cap(c), peak(0) {}
+  void* alloc(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    if (off > peak) peak = off;
+    return p;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+struct AdaPose {
+  int dtype = F32;
+  int img = 224, n_pts = 1024, n_depth = 24;
+  int img_cpad = 4;
+  int max_chunk = 32;            // views per cost-volume chunk (bounds the workspace)
+
+  struct Block { ConvLayer c1, c2, ds; bool has_ds = false; int stride = 1, planes = 0; };
+  ConvLayer conv1;
+  Block blocks[16];
+  int n_blocks = 0;
+  ConvLayer psp[4], up1, up2, up3, fin;
+  ConvLayer c3d[7], dc[3];
+  float* wprob = nullptr;
+  ConvLayer inst, nh[3], npm[2], pm1[2], pm2[2];
+  float* pm2_0_wfull = nullptr;
+  float* pm2_0_bias = nullptr;
+  float* head_w[3][3] = {{nullptr}};
+  float* head_b[3][3] = {{nullptr}};
+
+  struct Buffers {
+    float *Pviews, *homog; int* choose; void* feat;
+    float *X0, *X1, *H128, *H64, *nocs4, *N32, *PF96, *prob, *depth, *Q128a, *Q128b, *G256a, *G256b;
+    float *glob, *vbias, *pf2, *h1, *h2, *r6, *R, *tv, *sv;
+    void *imgpad, *c1, *lb[4], *pooled[4], *stage[4], *cat, *ups, *u1, *u2, *u3;
+    void *vol, *c[7], *u7, *u9, *u11;
+  };
+  struct Outputs {   // device fp32, reference shapes (network_v5.py:510-515)
+    float *nocs1, *nocs2;   // [B,P,3]
+    float *depth1, *depth2; // [B,P]
+    float *r1, *r2;         // [B,3,3]
+    float *t1, *t2, *s1, *s2;  // [B,3]
+  };
+
+  int create(const StateDict& sd, int dtype);
+  void destroy();
+  size_t workspace_bytes(int B) const;
+  int forward(int B, const float* img1, const float* img2, const int* choose1, const int* choose2, const float* P1,
+              const float* P2, const float* depths, void* workspace, size_t workspace_size, const Outputs& out,
+              hipStream_t s, int stop_after = 0) const;
+  mutable int last_f_index = 0;   // which rotating buffer holds the layer4 output (debug fetch)
+
+  // exposed for layer-level tests
+  int plan(int B, Arena& A, Buffers& bf) const;
+  int pspnet(const Buffers& bf, int V, hipStream_t s) const;
+  int cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const;
+  int chunk_views(int V) const;
+};
+
+const char* last_error_cstr();
+
+}  // namespace rgbm

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds librgbm_hip.so for gfx950 in-tree (no cmake; hipcc only).  Usage: build.sh [outdir]
+set -e
+cd "$(dirname "$0")"
+OUT=${1:-..}
+mkdir -p build
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+pids=()
+for f in conv_igemm.hip misc_kernels.hip head_kernels.hip postproc.hip ppo_kernels.hip policy_kernels.hip; do
+  [ -f "$f" ] || continue
+  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ]; then
+    hipcc $FLAGS -c "$f" -o build/${f%.hip}.o &
+    pids+=($!)
+  fi
+done
+for f in layers.cpp adapose.cpp capi.cpp; do
+  hipcc $FLAGS -x hip -c "$f" -o build/${f%.cpp}.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librgbm_hip.so" build/*.o
+echo "built $OUT/librgbm_hip.so"

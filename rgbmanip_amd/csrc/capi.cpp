@@ -1,0 +1,175 @@
+// extern "C" boundary of librgbm_hip.so — see include/rgbm.h for the contract and the reference
+// interfaces each entry point replaces.
+#include "../../include/rgbm.h"
+
+#include <string.h>
+
+#include <string>
+
+#include "adapose.h"
+
+using namespace rgbm;
+
+struct rgbm_adapose {
+  AdaPose net;
+  int device;
+};
+
+
+extern "C" {
+
+int rgbm_version(void) { return RGBM_VERSION; }
+const char* rgbm_last_error(void) { return last_error_cstr(); }
+
+int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode) {
+  RGBM_REQUIRE(h != nullptr && w != nullptr && n_w > 0, "create arguments");
+  RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16, "dtype must be 0 (fp32) or 1 (bf16)");
+  RGBM_REQUIRE(norm_mode == 0, "only eval-mode (folded) BatchNorm is implemented");
+  RGBM_CHECK_HIP(hipSetDevice(device));
+  StateDict sd;
+  for (int i = 0; i < n_w; ++i) {
+    std::string name = w[i].name;
+    if (name.rfind("module.", 0) == 0) name = name.substr(7);
+    HostTensor t;
+    t.data = w[i].data;
+    for (int d = 0; d < w[i].ndim; ++d) t.shape.push_back(w[i].shape[d]);
+    sd[name] = t;
+  }
+  rgbm_adapose* obj = new rgbm_adapose();
+  obj->device = device;
+  int rc = obj->net.create(sd, dtype);
+  if (rc) { obj->net.destroy(); delete obj; return rc; }
+  *h = obj;
+  return 0;
+}
+
+int rgbm_adapose_destroy(rgbm_adapose_t* h) {
+  if (!h) return 0;
+  h->net.destroy();
+  delete h;
+  return 0;
+}
+
+int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views) {
+  RGBM_REQUIRE(h && max_chunk_views > 0, "set_chunk arguments");
+  h->net.max_chunk = max_chunk_views;
+  return 0;
+}
+
+int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes) {
+  RGBM_REQUIRE(h && bytes && B > 0, "workspace_bytes arguments");
+  *bytes = h->net.workspace_bytes(B);
+  return 0;
+}
+
+static AdaPose::Outputs to_out(const rgbm_adapose_out* o) {
+  AdaPose::Outputs r;
+  r.nocs1 = o->view1_nocs; r.nocs2 = o->view2_nocs; r.depth1 = o->view1_depth; r.depth2 = o->view2_depth;
+  r.r1 = o->view1_r; r.r2 = o->view2_r; r.t1 = o->view1_t; r.t2 = o->view2_t; r.s1 = o->view1_s; r.s2 = o->view2_s;
+  return r;
+}
+
+int rgbm_adapose_forward_ex(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                            const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                            size_t workspace_bytes, const rgbm_adapose_out* out, int stop_after, void* stream) {
+  RGBM_REQUIRE(h && img1 && img2 && choose1 && choose2 && P1 && P2 && depths && workspace && out, "forward arguments");
+  return h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out),
+                        (hipStream_t)stream, stop_after);
+}
+
+int rgbm_adapose_forward(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                         const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                         size_t workspace_bytes, const rgbm_adapose_out* out, void* stream) {
+  return rgbm_adapose_forward_ex(h, B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, out, 0, stream);
+}
+
+int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* name, float* out_dev, size_t capacity,
+                       size_t* n_elems, void* stream) {
+  RGBM_REQUIRE(h && workspace && name && out_dev && n_elems, "fetch arguments");
+  const AdaPose& n = h->net;
+  Arena A(workspace, 0);
+  AdaPose::Buffers bf;
+  n.plan(B, A, bf);
+  const size_t V = 2 * (size_t)B, S = n.img, P = n.n_pts, D = n.n_depth;
+  const size_t Vc = n.chunk_views((int)V);
+  const std::string nm = name;
+  const void* src = nullptr; size_t cnt = 0; int dt = n.dtype;
+  if (nm == "imgpad") { src = bf.imgpad; cnt = V * S * S * n.img_cpad; }
+  else if (nm == "conv1") { src = bf.c1; cnt = V * (S / 2) * (S / 2) * 64; }
+  else if (nm == "layer4") { src = bf.lb[n.last_f_index]; cnt = V * (S / 8) * (S / 8) * 512; }
+  else if (nm == "cat") { src = bf.cat; cnt = V * (S / 8) * (S / 8) * 1024; }
+  else if (nm == "u1") { src = bf.u1; cnt = V * (S / 4) * (S / 4) * 256; }
+  else if (nm == "u2") { src = bf.u2; cnt = V * (S / 2) * (S / 2) * 64; }
+  else if (nm == "u3") { src = bf.u3; cnt = V * S * S * 64; }
+  else if (nm == "feat") { src = bf.feat; cnt = V * S * S * 32; }
+  else if (nm == "vol") { src = bf.vol; cnt = Vc * D * S * S * 32; }
+  else if (nm == "c0") { src = bf.c[0]; cnt = Vc * D * S * S * 8; }
+  else if (nm == "c2") { src = bf.c[2]; cnt = Vc * (D / 2) * (S / 2) * (S / 2) * 16; }
+  else if (nm == "c4") { src = bf.c[4]; cnt = Vc * (D / 4) * (S / 4) * (S / 4) * 32; }
+  else if (nm == "c6") { src = bf.c[6]; cnt = Vc * (D / 8) * (S / 8) * (S / 8) * 64; }
+  else if (nm == "u7") { src = bf.u7; cnt = Vc * (D / 4) * (S / 4) * (S / 4) * 32; }
+  else if (nm == "u9") { src = bf.u9; cnt = Vc * (D / 2) * (S / 2) * (S / 2) * 16; }
+  else if (nm == "u11") { src = bf.u11; cnt = Vc * D * S * S * 8; }
+  else if (nm == "homog") { src = bf.homog; cnt = V * 12; dt = F32; }
+  else if (nm == "prob") { src = bf.prob; cnt = V * P * D; dt = F32; }
+  else if (nm == "pf96") { src = bf.PF96; cnt = V * P * 96; dt = F32; }
+  else if (nm == "pf2") { src = bf.pf2; cnt = V * 256; dt = F32; }
+  else if (nm == "r6") { src = bf.r6; cnt = V * 6; dt = F32; }
+  RGBM_REQUIRE(src != nullptr, "unknown intermediate name: " + nm);
+  *n_elems = cnt;
+  RGBM_REQUIRE(cnt <= capacity, "fetch capacity too small");
+  return launch_to_f32(dt, src, out_dev, (long long)cnt, (hipStream_t)stream);
+}
+
+int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, const float* depth1, const float* r1,
+                             const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
+                             int32_t* valid, void* stream) {
+  RGBM_REQUIRE(B > 0 && nocs1 && depth1 && r1 && choose1 && Kcrop && E1 && bbox_world && ts && valid, "postprocess arguments");
+  return launch_postprocess(nocs1, depth1, r1, choose1, Kcrop, E1, bbox_world, ts, valid, B, P, img_size, (hipStream_t)stream);
+}
+
+int rgbm_gae(int T, int N, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+             float gamma, float lam, float* returns, float* adv, double* sums, void* stream) {
+  RGBM_REQUIRE(rewards && dones && values && last_values && returns && adv && sums, "gae arguments");
+  return launch_gae(T, N, rewards, dones, values, last_values, gamma, lam, returns, adv, sums, (hipStream_t)stream);
+}
+
+int rgbm_adv_normalise(int64_t n_local, float* adv, const double* sums, double count_total, void* stream) {
+  RGBM_REQUIRE(adv && sums && n_local > 0 && count_total > 1.0, "adv_normalise arguments");
+  return launch_adv_normalise(n_local, adv, sums, count_total, (hipStream_t)stream);
+}
+
+int rgbm_conv_nd(int dtype, const void* in_dev, int N, int D, int H, int W, int Cin, int Cin_pad, const float* w_host,
+                 int Cout, int Cout_pad, int KD, int KH, int KW, int stride_d, int stride_hw, int pad_d, int pad_hw,
+                 int dil_hw, int transposed, const float* bias_host, const float* bn_scale_host, const float* bn_shift_host,
+                 const void* res_dev, int res_mode, int act, float slope, void* out_dev, void* stream) {
+  RGBM_REQUIRE(in_dev && w_host && out_dev, "conv arguments");
+  ConvGeom g;
+  g.Cin = Cin; g.Cout = Cout; g.KD = KD; g.KH = KH; g.KW = KW;
+  g.sd = stride_d; g.sh = g.sw = stride_hw; g.pd = pad_d; g.ph = g.pw = pad_hw;
+  g.dild = 1; g.dilh = g.dilw = dil_hw; g.transposed = transposed != 0; g.act = act; g.slope = slope;
+  ConvLayer L;
+  int rc = L.init(dtype, g, w_host, bias_host, bn_scale_host, bn_shift_host, Cin_pad, Cout_pad);
+  if (!rc) rc = L.run(in_dev, out_dev, N, D, H, W, Cout_pad, res_dev, res_mode, nullptr, 0, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  L.destroy();
+  return rc;
+}
+
+int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream) {
+  return launch_maxpool3x3s2(dtype, in_dev, out_dev, V, H, W, C, (hipStream_t)stream);
+}
+int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
+                            void* stream) {
+  return launch_resize_bilinear_ac(dtype, in_dev, out_dev, V, Hs, Ws, C, Ho, Wo, C, 0, (hipStream_t)stream);
+}
+int rgbm_adaptive_avgpool(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, int S, void* stream) {
+  return launch_adaptive_avgpool(dtype, in_dev, out_dev, V, H, W, C, S, (hipStream_t)stream);
+}
+int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                      void* vol_dev, int V, int B, int D, int H, int W, void* stream) {
+  if (int rc = launch_homography(P_views_dev, homog_scratch, V, B, (hipStream_t)stream)) return rc;
+  return launch_build_volume(dtype, feat_dev, homog_scratch, depths_dev, vol_dev, 0, V, V, B, D, H, W, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// Shared declarations for the rgbmanip_amd HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace rgbm {
+
+enum DType { F32 = 0, BF16 = 1 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2, ACT_TANH = 3 };
+enum ResMode { RES_NONE = 0, RES_PRE_ACT = 1, RES_POST_ACT = 2 };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void set_error(const std::string& s);
+int fail(const char* what, const char* file, int line);
+
+#define RGBM_CHECK_HIP(expr)                                                             \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      rgbm::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+#define RGBM_REQUIRE(cond, msg)                                                          \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      rgbm::set_error(std::string(msg) + " [" #cond "] at " __FILE__ ":" + std::to_string(__LINE__)); \
+      return -1;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+static inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : 4; }
+static inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  // round to nearest even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;  // elements per 16 bytes
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<unsigned short> {
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float ld(const unsigned short* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// load/store 4 consecutive elements as floats
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const unsigned short* p, float v[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(unsigned short* p, const float v[4]) {
+  uint2 t;
+  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, float /*tag*/) {
+  v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y); v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
+}
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, unsigned short /*tag*/) {
+  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
+  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack_chunk(const float* v, float /*tag*/) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+__device__ __forceinline__ uint4 pack_chunk(const float* v, unsigned short /*tag*/) {
+  uint4 c;
+  c.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+  c.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  c.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+  c.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+  return c;
+}
+
+// ---- generic implicit-GEMM convolution descriptor (conv_igemm.hip) -------------------
+struct ConvDesc {
+  const void* in; const void* wgt; void* out; const float* bias; const void* res;
+  int N, Di, Hi, Wi, Cin, lcin;           // input tensor NDHWC, Cin power of two
+  int Dq, Hq, Wq;                         // enumeration grid of output positions
+  int sd, sh, sw, pd, ph, pw;             // input coord = q*s - p + k*dil
+  int KD, KH, KW, dild, dilh, dilw;
+  int ntaps, KT, Kpad;                    // taps, #K tiles, weight row stride (elements)
+  int Cout, ldo;                          // real out channels (mult of 4), out channel stride
+  int Do, Ho, Wo;                         // output tensor dims
+  int osd, osh, osw, opd, oph, opw;       // output coord = q*os + op
+  int act; float slope; int res_mode; int bias_stride;  // bias index = n*bias_stride + ch
+  long long M;                            // N*Dq*Hq*Wq
+  int n_pix_tiles, n_ch_tiles;
+};
+
+int launch_conv(const ConvDesc& d, int dtype, hipStream_t s);
+// picks the channel-tile size used by launch_conv for Cout (weights must be padded to it)
+int conv_ch_tile(int Cout);
+int conv_bk(int dtype);  // K-tile in elements
+
+}  // namespace rgbm

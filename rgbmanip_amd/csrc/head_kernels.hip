@@ -1,0 +1,312 @@
+// Point-sampled head kernels of the AdaPose forward (network_v5.py:432-508), gfx950.
+// Everything here is fp32 (fp32 from the probability volume onward); feature maps /
+// cost-volume activations may be bf16 or f32 (template T).  The per-point MLPs themselves run
+// through the generic implicit-GEMM kernel as 1x1 convolutions; this file holds the glue:
+// gathers at `choose`, the sparse probability conv + softmax + depth regression, the depth-guided
+// fusion (re-warping only the 1024x24 samples that are consumed), reductions and the tiny
+// per-view regressors + Ortho6d.
+#include "common.h"
+#include "kernels.h"
+
+namespace rgbm {
+
+// ---------------------------------------------------------------- gather feat at choose -> fp32 rows
+template <typename T>
+__global__ void gather_points_kernel(const T* __restrict__ feat, const int* __restrict__ choose, float* __restrict__ out,
+                                     int V, int P, int HW, int C) {
+  // one thread per (point, 4 channels)
+  const int q = C / 4;
+  const long long total = (long long)V * P * q;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % q);
+    const long long vp = i / q;
+    const long long v = vp / P;
+    const int pix = choose[vp];
+    float x[4];
+    load4(feat + (v * HW + pix) * C + c4 * 4, x);
+    store4(out + vp * C + c4 * 4, x);
+  }
+}
+
+int launch_gather_points(int dtype, const void* feat, const int* choose, float* out, int V, int P, int HW, int C,
+                         hipStream_t s) {
+  const long long total = (long long)V * P * (C / 4);
+  const unsigned g = (unsigned)((total + 255) / 256);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(gather_points_kernel<unsigned short>, dim3(g), dim3(256), 0, s, (const unsigned short*)feat, choose,
+                       out, V, P, HW, C);
+  else
+    hipLaunchKernelGGL(gather_points_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)feat, choose, out, V, P, HW, C);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- sparse prob conv + softmax + depth
+// prob = Conv3d(8->1, 3^3, pad 1, no bias) evaluated only at the P chosen pixels x D depths
+// (network_v5.py:280,290,449-455); softmax over depth; depth = sum p*d (network_v5.py:293-299).
+// block = 256 threads = 64 points x 4 depth groups.
+template <typename T>
+__global__ __launch_bounds__(256) void prob_softmax_depth_kernel(const T* __restrict__ u11, const float* __restrict__ wprob,
+                                                                 const int* __restrict__ choose,
+                                                                 const float* __restrict__ depths, float* __restrict__ prob,
+                                                                 float* __restrict__ depth_out, int v0, int Vc, int B, int P,
+                                                                 int D, int H, int W) {
+  constexpr int C = 8;
+  __shared__ float w[27 * C];
+  __shared__ float logit[64][25];
+  for (int i = threadIdx.x; i < 27 * C; i += 256) w[i] = wprob[i];
+  __syncthreads();
+  const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long pidx = (long long)blockIdx.x * 64 + pl;      // point index within the chunk
+  const bool active = pidx < (long long)Vc * P;
+  const int vl = active ? (int)(pidx / P) : 0;                 // local view
+  const int v = v0 + vl;
+  const int pix = active ? choose[(long long)v * P + (pidx - (long long)vl * P)] : 0;
+  const int y = pix / W, x = pix - y * W;
+  const int dper = (D + 3) / 4;
+  if (active) {
+    for (int dz = g * dper; dz < D && dz < (g + 1) * dper; ++dz) {
+      float acc = 0.f;
+      for (int kd = 0; kd < 3; ++kd) {
+        const int zz = dz + kd - 1;
+        if ((unsigned)zz >= (unsigned)D) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int yy = y + kh - 1;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int xx = x + kw - 1;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const T* p = u11 + ((((long long)vl * D + zz) * H + yy) * W + xx) * C;
+            float a[4], b[4];
+            load4(p, a);
+            load4(p + 4, b);
+            const float* ww = w + ((kd * 3 + kh) * 3 + kw) * C;
+            acc += a[0] * ww[0] + a[1] * ww[1] + a[2] * ww[2] + a[3] * ww[3] + b[0] * ww[4] + b[1] * ww[5] + b[2] * ww[6] +
+                   b[3] * ww[7];
+          }
+        }
+      }
+      logit[pl][dz] = acc;
+    }
+  }
+  __syncthreads();
+  if (active && g == 0) {
+    float m = -INFINITY;
+    for (int dz = 0; dz < D; ++dz) m = fmaxf(m, logit[pl][dz]);
+    float sum = 0.f;
+    for (int dz = 0; dz < D; ++dz) { const float e = expf(logit[pl][dz] - m); logit[pl][dz] = e; sum += e; }
+    const float inv = 1.f / sum;
+    float dep = 0.f;
+    const int b = v % B;
+    const long long o = ((long long)v * P + (pidx - (long long)vl * P));
+    for (int dz = 0; dz < D; ++dz) {
+      const float pr = logit[pl][dz] * inv;
+      prob[o * D + dz] = pr;
+      dep += pr * depths[b * D + dz];
+    }
+    depth_out[o] = dep;
+  }
+}
+
+int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, const int* choose, const float* depths,
+                              float* prob, float* depth_out, int v0, int Vc, int B, int P, int D, int H, int W,
+                              hipStream_t s) {
+  RGBM_REQUIRE(D <= 24, "prob kernel supports up to 24 depth planes");
+  const unsigned g = (unsigned)(((long long)Vc * P + 63) / 64);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(prob_softmax_depth_kernel<unsigned short>, dim3(g), dim3(256), 0, s, (const unsigned short*)u11, wprob,
+                       choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W);
+  else
+    hipLaunchKernelGGL(prob_softmax_depth_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)u11, wprob, choose, depths,
+                       prob, depth_out, v0, Vc, B, P, D, H, W);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- depth-guided fusion (network_v5.py:457-465)
+// fg[v,p,c] = sum_d prob[v,p,d] * (feat[v,pix,c] + warp(feat[partner], v, d, pix)[c]);  written into a
+// row-major [V*P][ldo] fp32 matrix at channel offset ch_off (the pose_mlp1 input concat).
+__device__ __forceinline__ void warp_coords_h(const float* __restrict__ hm, float x, float y, float depth, int H, int W,
+                                              float& ix, float& iy) {
+  const float rx = hm[0] * x + hm[1] * y + hm[2];
+  const float ry = hm[3] * x + hm[4] * y + hm[5];
+  const float rz = hm[6] * x + hm[7] * y + hm[8];
+  const float px = rx * depth + hm[9], py = ry * depth + hm[10], pz = rz * depth + hm[11];
+  const float u = px / pz, vv = py / pz;
+  const float gx = u / ((float)(W - 1) / 2.f) - 1.f;
+  const float gy = vv / ((float)(H - 1) / 2.f) - 1.f;
+  ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+  iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+}
+
+template <typename T, bool ROUND_BF16>
+__global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __restrict__ homog, const float* __restrict__ depths,
+                                   const int* __restrict__ choose, const float* __restrict__ prob, float* __restrict__ out,
+                                   int V, int B, int P, int D, int H, int W, int ldo, int ch_off) {
+  // one thread per (point, 4-channel group): 8 threads per point for C=32
+  constexpr int C = 32;
+  const long long total = (long long)V * P * (C / 4);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i & 7);
+    const long long vp = i >> 3;
+    const int v = (int)(vp / P);
+    const int partner = (v + B) % V;
+    const int b = v % B;
+    const int pix = choose[vp];
+    const int y = pix / W, x = pix - y * W;
+    float ref[4];
+    load4(feat + (((long long)v * H + y) * W + x) * C + c4 * 4, ref);
+    const T* src = feat + (long long)partner * H * W * C + c4 * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int dz = 0; dz < D; ++dz) {
+      float ix, iy;
+      warp_coords_h(homog + (long long)v * 12, (float)x, (float)y, depths[b * D + dz], H, W, ix, iy);
+      float wv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!(isfinite(ix) && isfinite(iy))) {
+        wv[0] = wv[1] = wv[2] = wv[3] = __builtin_nanf("");
+      } else {
+        ix = fminf(fmaxf(ix, -4.f), 1.0e6f);
+        iy = fminf(fmaxf(iy, -4.f), 1.0e6f);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float tx = ix - fx, ty = iy - fy;
+        float sv[4];
+        if ((unsigned)x0 < (unsigned)W && (unsigned)y0 < (unsigned)H) {
+          load4(src + ((long long)y0 * W + x0) * C, sv);
+          const float wgt = (1.f - tx) * (1.f - ty);
+          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
+        }
+        if ((unsigned)(x0 + 1) < (unsigned)W && (unsigned)y0 < (unsigned)H) {
+          load4(src + ((long long)y0 * W + x0 + 1) * C, sv);
+          const float wgt = tx * (1.f - ty);
+          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
+        }
+        if ((unsigned)x0 < (unsigned)W && (unsigned)(y0 + 1) < (unsigned)H) {
+          load4(src + ((long long)(y0 + 1) * W + x0) * C, sv);
+          const float wgt = (1.f - tx) * ty;
+          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
+        }
+        if ((unsigned)(x0 + 1) < (unsigned)W && (unsigned)(y0 + 1) < (unsigned)H) {
+          load4(src + ((long long)(y0 + 1) * W + x0 + 1) * C, sv);
+          const float wgt = tx * ty;
+          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
+        }
+      }
+      const float pr = prob[vp * D + dz];
+      for (int e = 0; e < 4; ++e) {
+        float f = ref[e] + wv[e];
+        if (ROUND_BF16) f = bf16_to_f32(f32_to_bf16(f));   // the volume the cost net saw was stored in bf16
+        acc[e] += f * pr;
+      }
+    }
+    store4(out + vp * ldo + ch_off + c4 * 4, acc);
+  }
+}
+
+int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
+                       const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
+                       hipStream_t s) {
+  const long long total = (long long)V * P * 8;
+  const unsigned g = (unsigned)((total + 255) / 256);
+  if (dtype == BF16)
+    hipLaunchKernelGGL((fuse_points_kernel<unsigned short, true>), dim3(g), dim3(256), 0, s, (const unsigned short*)feat,
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+  else
+    hipLaunchKernelGGL((fuse_points_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)feat, homog, depths,
+                       choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- mean over the P points of each view
+// in [V*P][C] fp32 -> out [V][C].  grid = V x ceil(C/64) blocks of 256 threads (64 channels x 4 point slices).
+__global__ __launch_bounds__(256) void mean_points_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int C) {
+  __shared__ float part[4][64];
+  const int v = blockIdx.x, cb = blockIdx.y * 64;
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (cb + c < C)
+    for (int p = sl; p < P; p += 4) acc += in[((long long)v * P + p) * C + cb + c];
+  part[sl][c] = acc;
+  __syncthreads();
+  if (sl == 0 && cb + c < C) out[(long long)v * C + cb + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)P;
+}
+
+int launch_mean_points(const float* in, float* out, int V, int P, int C, hipStream_t s) {
+  hipLaunchKernelGGL(mean_points_kernel, dim3(V, (C + 63) / 64), dim3(256), 0, s, in, out, P, C);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- small dense layer on per-view vectors
+// out[v][o] = act(bias[o] + sum_i W[o][i0 + i] * x[v][i]),  W row-major [O][ldw].  One block per view.
+__global__ __launch_bounds__(256) void view_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int I,
+                                                          int O, int ldw, int i0, int relu) {
+  extern __shared__ float xs[];
+  const int v = blockIdx.x;
+  for (int i = threadIdx.x; i < I; i += blockDim.x) xs[i] = x[(long long)v * I + i];
+  __syncthreads();
+  for (int o = threadIdx.x; o < O; o += blockDim.x) {
+    float acc = bias ? bias[o] : 0.f;
+    const float* wr = W + (long long)o * ldw + i0;
+    for (int i = 0; i < I; ++i) acc = fmaf(wr[i], xs[i], acc);
+    if (relu) acc = fmaxf(acc, 0.f);
+    out[(long long)v * O + o] = acc;
+  }
+}
+
+int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
+                       int relu, hipStream_t s) {
+  hipLaunchKernelGGL(view_linear_kernel, dim3(V), dim3(256), I * sizeof(float), s, x, W, bias, out, I, O, ldw, i0, relu);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- Ortho6d -> rotation matrix (rotation_utils.py:18-27)
+__global__ void ortho6d_kernel(const float* __restrict__ r6, float* __restrict__ R, int V) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float* a = r6 + (long long)v * 6;        // [x_raw(3), y_raw(3)]
+  float xr[3] = {a[0], a[1], a[2]}, y[3] = {a[3], a[4], a[5]}, z[3], x[3];
+  float n = fmaxf(sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]), 1e-8f);
+  for (int i = 0; i < 3; ++i) y[i] /= n;
+  z[0] = xr[1] * y[2] - xr[2] * y[1];
+  z[1] = xr[2] * y[0] - xr[0] * y[2];
+  z[2] = xr[0] * y[1] - xr[1] * y[0];
+  n = fmaxf(sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]), 1e-8f);
+  for (int i = 0; i < 3; ++i) z[i] /= n;
+  x[0] = y[1] * z[2] - y[2] * z[1];
+  x[1] = y[2] * z[0] - y[0] * z[2];
+  x[2] = y[0] * z[1] - y[1] * z[0];
+  float* o = R + (long long)v * 9;               // columns [x y z]
+  for (int i = 0; i < 3; ++i) { o[i * 3 + 0] = x[i]; o[i * 3 + 1] = y[i]; o[i * 3 + 2] = z[i]; }
+}
+
+int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s) {
+  hipLaunchKernelGGL(ortho6d_kernel, dim3((V + 63) / 64), dim3(64), 0, s, r6, R, V);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- strided row copy (fp32), e.g. [rows][4] -> [rows][3]
+__global__ void copy_cols_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int ldi, int ldo, int n) {
+  const long long total = rows * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / n;
+    const int c = (int)(i - r * n);
+    out[r * ldo + c] = in[r * ldi + c];
+  }
+}
+
+int launch_copy_cols(const float* in, float* out, long long rows, int ldi, int ldo, int n, hipStream_t s) {
+  const long long total = rows * n;
+  unsigned g = (unsigned)((total + 255) / 256);
+  if (g > 65536) g = 65536;
+  if (g == 0) g = 1;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(g), dim3(256), 0, s, in, out, rows, ldi, ldo, n);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rgbm

@@ -1,0 +1,42 @@
+// Host-side launchers of the helper kernels (misc_kernels.hip, head_kernels.hip, postproc.hip, ppo_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace rgbm {
+
+// misc_kernels.hip
+int launch_nchw_to_nhwc_pad(int dtype, const float* in, void* out, int V, int C, int H, int W, int Cp, hipStream_t s);
+int launch_maxpool3x3s2(int dtype, const void* in, void* out, int V, int H, int W, int C, hipStream_t s);
+int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int Hs, int Ws, int C, int Ho, int Wo, int ldo,
+                              int ch_off, hipStream_t s);
+int launch_copy_channels(int dtype, const void* in, void* out, long long npix, int C, int ldo, int ch_off, hipStream_t s);
+int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s);
+int launch_homography(const float* P_views, float* out, int V, int B, hipStream_t s);
+int launch_build_volume(int dtype, const void* feat, const float* homog, const float* depths, void* vol, int v0, int Vc, int V,
+                        int B, int D, int H, int W, hipStream_t s);
+
+int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_t s);
+
+// head_kernels.hip
+int launch_gather_points(int dtype, const void* feat, const int* choose, float* out, int V, int P, int HW, int C, hipStream_t s);
+int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, const int* choose, const float* depths,
+                              float* prob, float* depth_out, int v0, int Vc, int B, int P, int D, int H, int W, hipStream_t s);
+int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
+                       const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
+                       hipStream_t s);
+int launch_mean_points(const float* in, float* out, int V, int P, int C, hipStream_t s);
+int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
+                       int relu, hipStream_t s);
+int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
+int launch_copy_cols(const float* in, float* out, long long rows, int ldi, int ldo, int n, hipStream_t s);
+
+// postproc.hip
+int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
+                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s);
+
+// ppo_kernels.hip
+int launch_gae(int T, int N, const float* rewards, const unsigned char* dones, const float* values, const float* last_values,
+               float gamma, float lam, float* returns, float* adv, double* sums, hipStream_t s);
+int launch_adv_normalise(long long n_local, float* adv, const double* sums, double count_total, hipStream_t s);
+
+}  // namespace rgbm

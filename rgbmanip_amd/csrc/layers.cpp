@@ -1,0 +1,178 @@
+#include "layers.h"
+
+#include <string.h>
+
+#include <vector>
+
+namespace rgbm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+const char* last_error_cstr() { return g_err.c_str(); }
+
+static inline unsigned short host_f32_to_bf16(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+int upload_f32(const float* host, size_t n, float** dev) {
+  RGBM_CHECK_HIP(hipMalloc((void**)dev, n * sizeof(float)));
+  RGBM_CHECK_HIP(hipMemcpy(*dev, host, n * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int upload_packed(const std::vector<float>& w, int dtype, void** dev) {
+  if (dtype == BF16) {
+    std::vector<unsigned short> h(w.size());
+    for (size_t i = 0; i < w.size(); ++i) h[i] = host_f32_to_bf16(w[i]);
+    RGBM_CHECK_HIP(hipMalloc(dev, h.size() * 2));
+    RGBM_CHECK_HIP(hipMemcpy(*dev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    RGBM_CHECK_HIP(hipMalloc(dev, w.size() * 4));
+    RGBM_CHECK_HIP(hipMemcpy(*dev, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int ConvLayer::init(int dtype_, const ConvGeom& g_, const float* w, const float* bias_h, const float* bn_scale,
+                    const float* bn_shift, int Cin_pad_, int Cout_pad_) {
+  g = g_;
+  dtype = dtype_;
+  Cin_pad = Cin_pad_;
+  Cout_pad = Cout_pad_;
+  const int E = dtype == BF16 ? 8 : 4;
+  const int BK = conv_bk(dtype);
+  RGBM_REQUIRE(Cin_pad % E == 0 && Cin_pad >= g.Cin, "Cin_pad");
+  RGBM_REQUIRE(Cout_pad % 4 == 0 && Cout_pad >= g.Cout, "Cout_pad");
+  const int bch = conv_ch_tile(Cout_pad);
+  const int rows = (Cout_pad + bch - 1) / bch * bch;   // weight rows padded to the channel tile
+
+  // bias (conv bias and/or folded BN shift)
+  if (bias_h || bn_shift) {
+    std::vector<float> b(Cout_pad, 0.f);
+    for (int o = 0; o < g.Cout; ++o) {
+      float v = bias_h ? bias_h[o] : 0.f;
+      if (bn_scale) v *= bn_scale[o];
+      if (bn_shift) v += bn_shift[o];
+      b[o] = v;
+    }
+    if (upload_f32(b.data(), b.size(), &bias)) return -2;
+    owned.push_back(bias);
+  }
+
+  auto finish = [&](PackedConv& pc, std::vector<float>& packed) -> int {
+    if (upload_packed(packed, dtype, &pc.w)) return -2;
+    owned.push_back(pc.w);
+    packs.push_back(pc);
+    return 0;
+  };
+
+  if (!g.transposed) {
+    PackedConv pc;
+    pc.KD = g.KD; pc.KH = g.KH; pc.KW = g.KW;
+    pc.ntaps = g.KD * g.KH * g.KW;
+    if (pc.ntaps > 1) RGBM_REQUIRE(is_pow2(Cin_pad), "multi-tap conv needs power-of-two Cin_pad");
+    const int K = pc.ntaps * Cin_pad;
+    pc.Kpad = (K + BK - 1) / BK * BK;
+    pc.KT = pc.Kpad / BK;
+    std::vector<float> packed((size_t)rows * pc.Kpad, 0.f);
+    const long long kvol = (long long)g.KD * g.KH * g.KW;
+    for (int o = 0; o < g.Cout; ++o) {
+      const float sc = bn_scale ? bn_scale[o] : 1.f;
+      for (int c = 0; c < g.Cin; ++c)
+        for (int t = 0; t < pc.ntaps; ++t)
+          packed[(size_t)o * pc.Kpad + (size_t)t * Cin_pad + c] = w[((long long)o * g.Cin + c) * kvol + t] * sc;
+    }
+    return finish(pc, packed);
+  }
+
+  // ConvTranspose3d(k=3, s=2, p=1, op=1): out o = 2q+p.  p=0 -> single tap k=1 at input q;
+  // p=1 -> taps (delta=0 -> k=2 at q), (delta=1 -> k=0 at q+1).   weight layout [Cin][Cout][3][3][3].
+  RGBM_REQUIRE(g.KD == 3 && g.KH == 3 && g.KW == 3 && g.sd == 2 && g.sh == 2 && g.sw == 2, "transposed conv geometry");
+  RGBM_REQUIRE(is_pow2(Cin_pad), "transposed conv needs power-of-two Cin_pad");
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pd_ = (cls >> 2) & 1, ph_ = (cls >> 1) & 1, pw_ = cls & 1;
+    PackedConv pc;
+    pc.KD = 1 + pd_; pc.KH = 1 + ph_; pc.KW = 1 + pw_;
+    pc.ntaps = pc.KD * pc.KH * pc.KW;
+    const int K = pc.ntaps * Cin_pad;
+    pc.Kpad = (K + BK - 1) / BK * BK;
+    pc.KT = pc.Kpad / BK;
+    std::vector<float> packed((size_t)rows * pc.Kpad, 0.f);
+    auto kidx = [](int p, int delta) { return p == 0 ? 1 : (delta == 0 ? 2 : 0); };
+    for (int o = 0; o < g.Cout; ++o) {
+      const float sc = bn_scale ? bn_scale[o] : 1.f;
+      for (int c = 0; c < g.Cin; ++c)
+        for (int dd = 0; dd < pc.KD; ++dd)
+          for (int dh = 0; dh < pc.KH; ++dh)
+            for (int dw = 0; dw < pc.KW; ++dw) {
+              const int t = (dd * pc.KH + dh) * pc.KW + dw;
+              const int kd = kidx(pd_, dd), kh = kidx(ph_, dh), kw = kidx(pw_, dw);
+              packed[(size_t)o * pc.Kpad + (size_t)t * Cin_pad + c] =
+                  w[(((long long)c * g.Cout + o) * 3 + kd) * 9 + kh * 3 + kw] * sc;
+            }
+    }
+    if (finish(pc, packed)) return -2;
+  }
+  return 0;
+}
+
+void ConvLayer::destroy() {
+  for (void* p : owned) (void)hipFree(p);
+  owned.clear();
+  packs.clear();
+  bias = nullptr;
+}
+
+void ConvLayer::out_dims(int Di, int Hi, int Wi, int& Do, int& Ho, int& Wo) const {
+  if (g.transposed) { Do = 2 * Di; Ho = 2 * Hi; Wo = 2 * Wi; return; }
+  Do = (Di + 2 * g.pd - g.dild * (g.KD - 1) - 1) / g.sd + 1;
+  Ho = (Hi + 2 * g.ph - g.dilh * (g.KH - 1) - 1) / g.sh + 1;
+  Wo = (Wi + 2 * g.pw - g.dilw * (g.KW - 1) - 1) / g.sw + 1;
+}
+
+int ConvLayer::run(const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
+                   const float* bias_override, int bias_stride, hipStream_t s) const {
+  RGBM_REQUIRE(!packs.empty(), "conv layer not initialised");
+  int Do, Ho, Wo;
+  out_dims(Di, Hi, Wi, Do, Ho, Wo);
+  ConvDesc d;
+  memset(&d, 0, sizeof(d));
+  d.in = in; d.out = out; d.res = res;
+  d.bias = bias_override ? bias_override : bias;
+  d.bias_stride = bias_override ? bias_stride : 0;
+  d.N = N; d.Di = Di; d.Hi = Hi; d.Wi = Wi;
+  d.Cin = Cin_pad;
+  d.Cout = Cout_pad; d.ldo = ldo;
+  d.Do = Do; d.Ho = Ho; d.Wo = Wo;
+  d.act = g.act; d.slope = g.slope; d.res_mode = res ? res_mode : RES_NONE;
+  const int nclass = g.transposed ? 8 : 1;
+  for (int cls = 0; cls < nclass; ++cls) {
+    const PackedConv& pc = packs[cls];
+    d.wgt = pc.w;
+    d.KD = pc.KD; d.KH = pc.KH; d.KW = pc.KW;
+    d.ntaps = pc.ntaps; d.KT = pc.KT; d.Kpad = pc.Kpad;
+    d.lcin = (pc.ntaps > 1 || is_pow2(Cin_pad)) ? ilog2(Cin_pad) : -1;
+    if (g.transposed) {
+      d.Dq = Di; d.Hq = Hi; d.Wq = Wi;
+      d.sd = d.sh = d.sw = 1; d.pd = d.ph = d.pw = 0;
+      d.dild = d.dilh = d.dilw = 1;
+      d.osd = d.osh = d.osw = 2;
+      d.opd = (cls >> 2) & 1; d.oph = (cls >> 1) & 1; d.opw = cls & 1;
+    } else {
+      d.Dq = Do; d.Hq = Ho; d.Wq = Wo;
+      d.sd = g.sd; d.sh = g.sh; d.sw = g.sw; d.pd = g.pd; d.ph = g.ph; d.pw = g.pw;
+      d.dild = g.dild; d.dilh = g.dilh; d.dilw = g.dilw;
+      d.osd = d.osh = d.osw = 1;
+      d.opd = d.oph = d.opw = 0;
+    }
+    d.M = (long long)N * d.Dq * d.Hq * d.Wq;
+    if (int rc = launch_conv(d, dtype, s)) return rc;
+  }
+  return 0;
+}
+
+}  // namespace rgbm

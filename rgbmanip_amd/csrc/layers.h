@@ -1,0 +1,61 @@
+// Host-side layer objects: weight packing (BN folding, NDHWC/K-major repack, bf16 conversion) and
+// ConvDesc construction for the generic implicit-GEMM kernel.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rgbm {
+
+struct HostTensor {
+  const float* data = nullptr;   // fp32 host pointer (int64 tensors such as num_batches_tracked are skipped)
+  std::vector<long long> shape;
+  long long numel() const { long long n = 1; for (auto s : shape) n *= s; return n; }
+};
+typedef std::map<std::string, HostTensor> StateDict;
+
+struct ConvGeom {
+  int Cin = 0, Cout = 0;         // logical channels
+  int KD = 1, KH = 1, KW = 1;
+  int sd = 1, sh = 1, sw = 1;
+  int pd = 0, ph = 0, pw = 0;
+  int dild = 1, dilh = 1, dilw = 1;
+  bool transposed = false;       // ConvTranspose3d k3 s2 p1 op1 (sub-pixel decomposition)
+  int act = ACT_NONE;
+  float slope = 0.f;
+};
+
+// One packed weight set (a transposed conv owns 8, one per output parity class).
+struct PackedConv {
+  void* w = nullptr;             // [Cout_pad][Kpad] in the layer dtype
+  int KD = 1, KH = 1, KW = 1, ntaps = 1, Kpad = 0, KT = 0;
+};
+
+struct ConvLayer {
+  ConvGeom g;
+  int dtype = F32;
+  int Cin_pad = 0;               // physical input channels (>= Cin, multiple of the 16-byte chunk)
+  int Cout_pad = 0;              // physical output channels written (multiple of 4)
+  float* bias = nullptr;         // [Cout_pad] fp32 or null
+  std::vector<PackedConv> packs; // 1, or 8 for transposed
+  std::vector<void*> owned;      // device allocations to free
+
+  // weights: [Cout][Cin][KD][KH][KW] (or [Cin][Cout][3][3][3] when transposed), optional per-Cout scale/shift
+  // (folded BN) and bias.  Cin_pad: physical channel count of the input tensor.
+  int init(int dtype, const ConvGeom& g, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
+           int Cin_pad, int Cout_pad);
+  void destroy();
+
+  // Run on input [N][Di][Hi][Wi][Cin_pad] -> output [N][Do][Ho][Wo][ldo] (+ch offset via out pointer).
+  // res: optional residual with the output's layout.  bias_override/bias_stride: per-sample bias.
+  int run(const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
+          const float* bias_override, int bias_stride, hipStream_t s) const;
+  void out_dims(int Di, int Hi, int Wi, int& Do, int& Ho, int& Wo) const;
+};
+
+// device upload helpers
+int upload_f32(const float* host, size_t n, float** dev);
+
+}  // namespace rgbm

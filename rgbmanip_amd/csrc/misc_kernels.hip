@@ -1,0 +1,374 @@
+// Bandwidth-bound helper kernels of the AdaPose forward (gfx950): layout conversion, max-pool,
+// bilinear x2 up-sampling, PSP pooling/concat, plane-sweep volume construction.
+// All tensors are channels-last (NDHWC); every thread moves 16-byte chunks (8 bf16 / 4 f32).
+#include "common.h"
+#include "kernels.h"
+
+namespace rgbm {
+
+static inline unsigned grid_for(long long n, int block = 256) {
+  long long g = (n + block - 1) / block;
+  const long long cap = 256ll * 32;   // 256 CUs x 8 blocks, x4 oversubscription; grid-stride the rest
+  return (unsigned)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC(T), channel pad
+template <typename T>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, T* __restrict__ out, int V, int C, int H, int W,
+                                        int Cp) {
+  const long long total = (long long)V * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long v = i / ((long long)H * W);
+    const long long hw = i - v * H * W;
+    for (int c0 = 0; c0 < Cp; c0 += 4) {
+      float vals[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        vals[e] = c < C ? in[(v * C + c) * H * W + hw] : 0.f;
+      }
+      store4(out + i * Cp + c0, vals);
+    }
+  }
+}
+
+int launch_nchw_to_nhwc_pad(int dtype, const float* in, void* out, int V, int C, int H, int W, int Cp, hipStream_t s) {
+  const long long total = (long long)V * H * W;
+  if (dtype == BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s, in,
+                       (unsigned short*)out, V, C, H, W, Cp);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, (float*)out, V, C, H, W, Cp);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- max-pool 3x3 s2 p1 (pspnet.py:39)
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int H, int W, int C, int Ho, int Wo) {
+  constexpr int E = 16 / sizeof(T);
+  const int cpp = C / E;
+  const long long total = (long long)V * Ho * Wo * cpp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpp);
+    long long t = i / cpp;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho); t /= Ho;
+    const long long v = t;
+    float m[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const uint4 c = *reinterpret_cast<const uint4*>(in + ((v * H + h) * W + w) * C + cc * E);
+        float x[E];
+        unpack_chunk(c, x, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = (x[e] > m[e] || x[e] != x[e]) ? x[e] : m[e];
+      }
+    }
+    *reinterpret_cast<uint4*>(out + ((v * Ho + ho) * Wo + wo) * C + cc * E) = pack_chunk(m, T());
+  }
+}
+
+int launch_maxpool3x3s2(int dtype, const void* in, void* out, int V, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int E = dtype == BF16 ? 8 : 4;
+  RGBM_REQUIRE(C % E == 0, "maxpool channels");
+  const long long total = (long long)V * Ho * Wo * (C / E);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const unsigned short*)in, (unsigned short*)out, V, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out, V,
+                       H, W, C, Ho, Wo);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- bilinear resize, align_corners=True
+// (pspnet.py:93,106; torch upsample_bilinear2d: src = dst*(in-1)/(out-1), i1 = i0 + (i0 < in-1))
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_ac(int dst, int in_size, float scale) {
+  Lerp l;
+  const float src = scale * (float)dst;
+  l.i0 = (int)src;
+  if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+  l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+  l.w1 = src - (float)l.i0;
+  l.w1 = l.w1 < 0.f ? 0.f : (l.w1 > 1.f ? 1.f : l.w1);
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+template <typename T>
+__global__ void resize_bilinear_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int Hs, int Ws, int C,
+                                          int Ho, int Wo, int ldo, int ch_off, float sy, float sx) {
+  constexpr int E = 16 / sizeof(T);
+  const int cpp = C / E;
+  const long long total = (long long)V * Ho * Wo * cpp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpp);
+    long long t = i / cpp;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho); t /= Ho;
+    const long long v = t;
+    const Lerp ly = lerp_ac(ho, Hs, sy), lx = lerp_ac(wo, Ws, sx);
+    const T* base = in + v * Hs * Ws * C + cc * E;
+    float a[E], b[E], c[E], dd[E], r[E];
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lx.i0) * C), a, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lx.i1) * C), b, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lx.i0) * C), c, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lx.i1) * C), dd, T());
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      r[e] = ly.w0 * (lx.w0 * a[e] + lx.w1 * b[e]) + ly.w1 * (lx.w0 * c[e] + lx.w1 * dd[e]);
+    *reinterpret_cast<uint4*>(out + ((v * Ho + ho) * Wo + wo) * ldo + ch_off + cc * E) = pack_chunk(r, T());
+  }
+}
+
+int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int Hs, int Ws, int C, int Ho, int Wo, int ldo,
+                              int ch_off, hipStream_t s) {
+  const int E = dtype == BF16 ? 8 : 4;
+  RGBM_REQUIRE(C % E == 0 && ldo % E == 0 && ch_off % E == 0, "resize channel alignment");
+  const float sy = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+  const long long total = (long long)V * Ho * Wo * (C / E);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(resize_bilinear_ac_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const unsigned short*)in, (unsigned short*)out, V, Hs, Ws, C, Ho, Wo, ldo, ch_off, sy, sx);
+  else
+    hipLaunchKernelGGL(resize_bilinear_ac_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in,
+                       (float*)out, V, Hs, Ws, C, Ho, Wo, ldo, ch_off, sy, sx);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- channel-slice copy (concat helper)
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ in, T* __restrict__ out, long long npix, int C, int ldo, int ch_off) {
+  constexpr int E = 16 / sizeof(T);
+  const int cpp = C / E;
+  const long long total = npix * cpp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpp);
+    const long long p = i / cpp;
+    *reinterpret_cast<uint4*>(out + p * ldo + ch_off + cc * E) = *reinterpret_cast<const uint4*>(in + p * C + cc * E);
+  }
+}
+
+int launch_copy_channels(int dtype, const void* in, void* out, long long npix, int C, int ldo, int ch_off, hipStream_t s) {
+  const int E = dtype == BF16 ? 8 : 4;
+  RGBM_REQUIRE(C % E == 0 && ldo % E == 0 && ch_off % E == 0, "copy channel alignment");
+  const long long total = npix * (C / E);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(copy_channels_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const unsigned short*)in, (unsigned short*)out, npix, C, ldo, ch_off);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out,
+                       npix, C, ldo, ch_off);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- adaptive average pool (pspnet.py:83)
+// window of output cell i over an axis of length L with S bins: [floor(i*L/S), ceil((i+1)*L/S))
+template <typename T>
+__global__ void adaptive_avgpool_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int H, int W, int C, int S) {
+  // grid: (V*S*S), block: C/E threads x up to 256; one thread = one 16-byte channel chunk
+  constexpr int E = 16 / sizeof(T);
+  const int cell = blockIdx.x % (S * S);
+  const long long v = blockIdx.x / (S * S);
+  const int sy = cell / S, sx = cell % S;
+  const int h0 = (sy * H) / S, h1 = ((sy + 1) * H + S - 1) / S;
+  const int w0 = (sx * W) / S, w1 = ((sx + 1) * W + S - 1) / S;
+  const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+  for (int cc = threadIdx.x; cc < C / E; cc += blockDim.x) {
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) {
+        float x[E];
+        unpack_chunk(*reinterpret_cast<const uint4*>(in + ((v * H + h) * W + w) * C + cc * E), x, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += x[e];
+      }
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] *= inv;
+    *reinterpret_cast<uint4*>(out + ((long long)blockIdx.x) * C + cc * E) = pack_chunk(acc, T());
+  }
+}
+
+int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s) {
+  const int E = dtype == BF16 ? 8 : 4;
+  RGBM_REQUIRE(C % E == 0, "avgpool channels");
+  int threads = C / E;
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<unsigned short>, dim3(V * S * S), dim3(threads), 0, s,
+                       (const unsigned short*)in, (unsigned short*)out, V, H, W, C, S);
+  else
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<float>, dim3(V * S * S), dim3(threads), 0, s, (const float*)in, (float*)out, V,
+                       H, W, C, S);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- plane-sweep homography (network_v5.py:390-392)
+// proj = P_src @ inverse(P_ref).  The 4x4 inverse is done in fp64 (Gauss-Jordan, partial pivoting) and
+// rounded to fp32; the product is accumulated in fp32 like torch.matmul.  out[v] = {rot[9] row-major, trans[3]}.
+__global__ void homography_kernel(const float* __restrict__ P, float* __restrict__ out, int V, int B) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int partner = (v + B) % V;
+  const float* Pref = P + (long long)v * 16;
+  const float* Psrc = P + (long long)partner * 16;
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int jj = 0; jj < 4; ++jj) { a[i][jj] = (double)Pref[i * 4 + jj]; a[i][4 + jj] = i == jj ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c; double best = fabs(a[c][c]);
+    for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+    if (piv != c) for (int k = 0; k < 8; ++k) { double t = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = t; }
+    const double inv = 1.0 / a[c][c];     // singular -> inf/nan, propagates like torch.inverse garbage -> default bbox
+    for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k]; }
+  }
+  float inv32[16];
+  for (int i = 0; i < 4; ++i) for (int jj = 0; jj < 4; ++jj) inv32[i * 4 + jj] = (float)a[i][4 + jj];
+  float* o = out + (long long)v * 12;
+  for (int i = 0; i < 3; ++i)
+    for (int jj = 0; jj < 4; ++jj) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc = fmaf(Psrc[i * 4 + k], inv32[k * 4 + jj], acc);
+      if (jj < 3) o[i * 3 + jj] = acc; else o[9 + i] = acc;
+    }
+}
+
+int launch_homography(const float* P_views, float* out, int V, int B, hipStream_t s) {
+  hipLaunchKernelGGL(homography_kernel, dim3((V + 63) / 64), dim3(64), 0, s, P_views, out, V, B);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused plane-sweep volume (network_v5.py:378-430)
+// vol[v,d,y,x,:] = feat[v,y,x,:] + grid_sample(feat[partner(v)], homography(v,d,y,x))   (bilinear, zeros,
+// align_corners=False fed with the align_corners=True normalisation, exactly as the reference does).
+__device__ __forceinline__ void warp_coords(const float* __restrict__ hm, float x, float y, float depth, int H, int W,
+                                            float& ix, float& iy) {
+  // rot_xyz = rot @ [x,y,1]; * depth; + trans; perspective divide; normalise; un-normalise (grid_sample)
+  const float rx = hm[0] * x + hm[1] * y + hm[2];
+  const float ry = hm[3] * x + hm[4] * y + hm[5];
+  const float rz = hm[6] * x + hm[7] * y + hm[8];
+  const float px = rx * depth + hm[9], py = ry * depth + hm[10], pz = rz * depth + hm[11];
+  const float u = px / pz, vv = py / pz;
+  const float gx = u / ((float)(W - 1) / 2.f) - 1.f;
+  const float gy = vv / ((float)(H - 1) / 2.f) - 1.f;
+  ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+  iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+}
+
+struct Bilin { int x0, y0; float w00, w01, w10, w11; bool nan; };
+__device__ __forceinline__ Bilin bilin_setup(float ix, float iy) {
+  Bilin b;
+  b.nan = !(isfinite(ix) && isfinite(iy));
+  if (b.nan) { b.x0 = b.y0 = -100; b.w00 = b.w01 = b.w10 = b.w11 = 0.f; return b; }
+  // clamp far-out-of-range coordinates before the int conversion (all four taps are outside anyway)
+  ix = fminf(fmaxf(ix, -4.f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -4.f), 1.0e6f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  b.x0 = (int)fx; b.y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  b.w00 = (1.f - tx) * (1.f - ty);   // (x0,y0)  "nw"
+  b.w01 = tx * (1.f - ty);           // (x1,y0)  "ne"
+  b.w10 = (1.f - tx) * ty;           // (x0,y1)  "sw"
+  b.w11 = tx * ty;                   // (x1,y1)  "se"
+  return b;
+}
+
+template <typename T>
+__global__ void build_volume_kernel(const T* __restrict__ feat, const float* __restrict__ homog, const float* __restrict__ depths,
+                                    T* __restrict__ vol, int v0, int Vc, int V, int B, int D, int H, int W) {
+  constexpr int C = 32;
+  constexpr int E = 16 / sizeof(T);
+  constexpr int NCH = C / E;
+  const long long total = (long long)Vc * D * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long t = i;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); t /= H;
+    const int dz = (int)(t % D); t /= D;
+    const int v = v0 + (int)t;
+    const int partner = (v + B) % V;
+    const int b = v % B;
+    float ix, iy;
+    warp_coords(homog + (long long)v * 12, (float)x, (float)y, depths[b * D + dz], H, W, ix, iy);
+    const Bilin bl = bilin_setup(ix, iy);
+    const T* ref = feat + (((long long)v * H + y) * W + x) * C;
+    const T* src = feat + (long long)partner * H * W * C;
+    const bool in00 = (unsigned)bl.x0 < (unsigned)W && (unsigned)bl.y0 < (unsigned)H;
+    const bool in01 = (unsigned)(bl.x0 + 1) < (unsigned)W && (unsigned)bl.y0 < (unsigned)H;
+    const bool in10 = (unsigned)bl.x0 < (unsigned)W && (unsigned)(bl.y0 + 1) < (unsigned)H;
+    const bool in11 = (unsigned)(bl.x0 + 1) < (unsigned)W && (unsigned)(bl.y0 + 1) < (unsigned)H;
+    T* o = vol + i * C;
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      float r[E], acc[E];
+      unpack_chunk(*reinterpret_cast<const uint4*>(ref + cc * E), r, T());
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = 0.f;
+      float s[E];
+      if (in00) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)bl.y0 * W + bl.x0) * C + cc * E), s, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += s[e] * bl.w00; }
+      if (in01) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)bl.y0 * W + bl.x0 + 1) * C + cc * E), s, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += s[e] * bl.w01; }
+      if (in10) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)(bl.y0 + 1) * W + bl.x0) * C + cc * E), s, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += s[e] * bl.w10; }
+      if (in11) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)(bl.y0 + 1) * W + bl.x0 + 1) * C + cc * E), s, T());
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += s[e] * bl.w11; }
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = bl.nan ? __builtin_nanf("") : (r[e] + acc[e]);
+      *reinterpret_cast<uint4*>(o + cc * E) = pack_chunk(acc, T());
+    }
+  }
+}
+
+int launch_build_volume(int dtype, const void* feat, const float* homog, const float* depths, void* vol, int v0, int Vc, int V,
+                        int B, int D, int H, int W, hipStream_t s) {
+  const long long total = (long long)Vc * D * H * W;
+  if (dtype == BF16)
+    hipLaunchKernelGGL(build_volume_kernel<unsigned short>, dim3(grid_for(total) * 4), dim3(256), 0, s,
+                       (const unsigned short*)feat, homog, depths, (unsigned short*)vol, v0, Vc, V, B, D, H, W);
+  else
+    hipLaunchKernelGGL(build_volume_kernel<float>, dim3(grid_for(total) * 4), dim3(256), 0, s, (const float*)feat, homog,
+                       depths, (float*)vol, v0, Vc, V, B, D, H, W);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- dtype -> fp32 copy (debug / test fetch)
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = Elem<T>::ld(in + i);
+}
+
+int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_t s) {
+  if (dtype == BF16)
+    hipLaunchKernelGGL(to_f32_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, s, (const unsigned short*)in, out, n);
+  else
+    hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)in, out, n);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rgbm

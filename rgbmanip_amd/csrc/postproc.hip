@@ -1,0 +1,243 @@
+// AdaPose post-processing on the GPU (gfx950): replaces the numpy code the reference runs on the
+// host after every network call
+//   /root/reference/models/pose_estimator/AdaPose/lib/utils.py:76-119  (compute_scale[_and_translation])
+//   /root/reference/models/pose_estimator/AdaPose/lib/utils.py:40-74   (get_3d_bbox, transform_coordinates_3d)
+//   /root/reference/models/pose_estimator/AdaPose/interface_v5.py:354-374 (bbox -> world, default_bbox)
+// One workgroup (1024 threads) per pose.  The O(P^2) pair ratios are never stored: the exact median is
+// found by a 12-bit-digit radix select over the order-preserving bit pattern of the positive fp64
+// ratios, recomputing the ratios each pass from LDS-resident points (only i<j pairs: the reference's
+// flattened P x P list holds every ratio twice and i==j is excluded by the nocs>0.01 filter, so both
+// lists have the same median).  Arithmetic follows the reference's dtypes: NOCS distances in fp32,
+// camera-space distances / ratios / median in fp64 (contraction disabled where numpy rounds twice).
+#include "common.h"
+#include "kernels.h"
+
+// numpy rounds every elementwise op separately: forbid a*b+c -> fma fusion in this file
+#pragma clang fp contract(off)
+
+namespace rgbm {
+
+constexpr int PP_MAXP = 1024;
+constexpr int PP_THREADS = 1024;
+
+__device__ __forceinline__ bool pair_ratio(const double* cx, const double* cy, const double* cz, const float* nx,
+                                           const float* ny, const float* nz, int i, int j, double& ratio) {
+  const float dx = __fsub_rn(nx[i], nx[j]), dy = __fsub_rn(ny[i], ny[j]), dz = __fsub_rn(nz[i], nz[j]);
+  const float nd = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  if (!(nd > 0.01f)) return false;
+  const double ex = __dsub_rn(cx[i], cx[j]), ey = __dsub_rn(cy[i], cy[j]), ez = __dsub_rn(cz[i], cz[j]);
+  const double rd = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez)));
+  if (!(rd < 0.3)) return false;
+  ratio = __ddiv_rn(rd, (double)nd);
+  return true;
+}
+
+// map (row-pair r, q) -> (i, j), i<j, covering all P(P-1)/2 pairs with P-1 pairs per row pair
+__device__ __forceinline__ void pair_ij(int P, int r, int q, int& i, int& j) {
+  if (q < P - 1 - r) { i = r; j = r + 1 + q; }
+  else { i = P - 1 - r; j = q + 1; }
+}
+
+__device__ double block_sum(double v, double* red) {
+  // 1024 threads -> deterministic tree in LDS
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = PP_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
+    const float* __restrict__ nocs /*[B,P,3]*/, const float* __restrict__ depth /*[B,P]*/, const float* __restrict__ rot /*[B,9]*/,
+    const int* __restrict__ choose /*[B,P]*/, const double* __restrict__ Kc /*[B,9]*/, const double* __restrict__ E1 /*[B,16]*/,
+    double* __restrict__ bbox /*[B,8,3]*/, double* __restrict__ ts_out /*[B,4]: t(3), s*/, int* __restrict__ valid, int P, int img) {
+  __shared__ double cx[PP_MAXP], cy[PP_MAXP], cz[PP_MAXP];
+  __shared__ float nx[PP_MAXP], ny[PP_MAXP], nz[PP_MAXP];
+  __shared__ double red[PP_THREADS];
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned long long sel_prefix;
+  __shared__ unsigned sel_rank, sel_lt, sel_eq, total_cnt;
+  __shared__ float hmax[3];
+
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double fx = Kc[b * 9 + 0], fy = Kc[b * 9 + 4], pcx = Kc[b * 9 + 2], pcy = Kc[b * 9 + 5];
+  if (t < P) {
+    const int ch = choose[(long long)b * P + t];
+    const double u = (double)(ch % img), v = (double)(ch / img);
+    const double z = (double)depth[(long long)b * P + t];
+    cx[t] = __ddiv_rn(__dmul_rn(__dsub_rn(u, pcx), z), fx);
+    cy[t] = __ddiv_rn(__dmul_rn(__dsub_rn(v, pcy), z), fy);
+    cz[t] = z;
+    nx[t] = nocs[((long long)b * P + t) * 3 + 0];
+    ny[t] = nocs[((long long)b * P + t) * 3 + 1];
+    nz[t] = nocs[((long long)b * P + t) * 3 + 2];
+  }
+  if (t < 3) hmax[t] = 0.f;
+  __syncthreads();
+
+  // ---- exact median of the valid pair ratios: radix select, digits 12,12,12,12,12,4 bits --------
+  const int npair_rows = P / 2;                  // row pairs (P even)
+  const int per_row = P - 1;
+  const int nthr_per_row = PP_THREADS / npair_rows;   // >=2 for P<=1024 ... 1024/512 = 2
+  const int r = t % npair_rows, part = t / npair_rows;
+  const int q_lo = (int)(((long long)per_row * part) / nthr_per_row);
+  const int q_hi = (int)(((long long)per_row * (part + 1)) / nthr_per_row);
+  const bool worker = part < nthr_per_row;
+
+  unsigned long long prefix = 0ull;     // selected high bits so far (right-aligned)
+  unsigned rank = 0;                    // rank to find within the current prefix bucket
+  double med_hi = __builtin_nan(""), med_lo = __builtin_nan("");
+  bool have = false, need_lower = false;
+  const int shifts[6] = {52, 40, 28, 16, 4, 0};
+  const int widths[6] = {12, 12, 12, 12, 12, 4};
+  unsigned lt_total = 0;                // number of elements strictly below the selected bucket (overall)
+  for (int pass = 0; pass < 6; ++pass) {
+    for (int i = t; i < 4096; i += PP_THREADS) hist[i] = 0u;
+    __syncthreads();
+    const int sh = shifts[pass], wd = widths[pass];
+    if (worker) {
+      for (int q = q_lo; q < q_hi; ++q) {
+        int i, j;
+        pair_ij(P, r, q, i, j);
+        double ratio;
+        if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
+        const unsigned long long key = (unsigned long long)__double_as_longlong(ratio);
+        if (pass > 0 && (key >> (sh + wd)) != prefix) continue;
+        atomicAdd(&hist[(unsigned)((key >> sh) & ((1u << wd) - 1u))], 1u);
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      if (pass == 0) {
+        unsigned n = 0;
+        for (int i = 0; i < 4096; ++i) n += hist[i];
+        total_cnt = n;
+        sel_rank = n / 2;               // upper middle (0-based) of the i<j list
+      }
+      unsigned rk = sel_rank, acc = 0;
+      int d = 0;
+      const int nb = 1 << wd;
+      for (d = 0; d < nb; ++d) {
+        if (acc + hist[d] > rk) break;
+        acc += hist[d];
+      }
+      if (d >= nb) d = nb - 1;
+      sel_prefix = (pass == 0 ? 0ull : (sel_prefix << wd)) | (unsigned long long)d;
+      if (pass == 0) sel_lt = acc; else sel_lt += acc;
+      sel_rank = rk - acc;
+      sel_eq = hist[d];
+    }
+    __syncthreads();
+    prefix = sel_prefix;
+    rank = sel_rank;
+    lt_total = sel_lt;
+    if (total_cnt == 0) break;
+  }
+  const unsigned n_valid = total_cnt;
+  if (n_valid > 0) {
+    med_hi = __longlong_as_double((long long)prefix);
+    have = true;
+    // lower middle: rank n/2-1 when n is even; equals med_hi if it also lies in the final bucket
+    if ((n_valid & 1u) == 0u) {
+      const unsigned k1 = n_valid / 2 - 1;
+      need_lower = k1 < lt_total;       // strictly-smaller elements cover rank k1 -> need max of those
+      if (!need_lower) med_lo = med_hi;
+    } else {
+      med_lo = med_hi;
+    }
+  }
+  if (have && need_lower) {
+    // max over valid ratios strictly below med_hi
+    double best = -1.0;
+    if (worker) {
+      for (int q = q_lo; q < q_hi; ++q) {
+        int i, j;
+        pair_ij(P, r, q, i, j);
+        double ratio;
+        if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
+        if (ratio < med_hi && ratio > best) best = ratio;
+      }
+    }
+    red[t] = best;
+    __syncthreads();
+    for (int s = PP_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) red[t] = red[t] > red[t + s] ? red[t] : red[t + s];
+      __syncthreads();
+    }
+    med_lo = red[0];
+    __syncthreads();
+  }
+  const double scale = have ? 0.5 * (med_lo + med_hi) : __builtin_nan("");
+
+  // ---- translation = mean(cam) - mean(s*R*nocs)   (utils.py:113-118) --------------------------------
+  double R[9];
+  for (int i = 0; i < 9; ++i) R[i] = (double)rot[b * 9 + i];
+  double sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
+  if (t < P) {
+    sx = cx[t]; sy = cy[t]; sz = cz[t];
+    const double a = nx[t], bb = ny[t], c = nz[t];
+    tx = (scale * R[0]) * a + (scale * R[1]) * bb + (scale * R[2]) * c;
+    ty = (scale * R[3]) * a + (scale * R[4]) * bb + (scale * R[5]) * c;
+    tz = (scale * R[6]) * a + (scale * R[7]) * bb + (scale * R[8]) * c;
+    atomicMax((int*)&hmax[0], __float_as_int(fabsf(nx[t])));   // non-negative floats order like ints
+    atomicMax((int*)&hmax[1], __float_as_int(fabsf(ny[t])));
+    atomicMax((int*)&hmax[2], __float_as_int(fabsf(nz[t])));
+  }
+  const double mcx = block_sum(sx, red) / P, mcy = block_sum(sy, red) / P, mcz = block_sum(sz, red) / P;
+  const double mtx = block_sum(tx, red) / P, mty = block_sum(ty, red) / P, mtz = block_sum(tz, red) / P;
+  if (t == 0) {
+    double tr[3] = {mcx - mtx, mcy - mty, mcz - mtz};
+    // NaN in nocs makes np.max propagate NaN; atomicMax on bit patterns would hide it -> re-check via the sums
+    bool nocs_nan = !(mtx == mtx) && (scale == scale);
+    ts_out[b * 4 + 0] = tr[0]; ts_out[b * 4 + 1] = tr[1]; ts_out[b * 4 + 2] = tr[2]; ts_out[b * 4 + 3] = scale;
+    // bbox corners (utils.py:49-56), sRT = [R | t] in float32 (interface_v5.py:358-361), then inv(E1)
+    const double size[3] = {2.0 * (double)hmax[0] * scale, 2.0 * (double)hmax[1] * scale, 2.0 * (double)hmax[2] * scale};
+    const float tf[3] = {(float)tr[0], (float)tr[1], (float)tr[2]};
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { a[i][j] = E1[b * 16 + i * 4 + j]; a[i][4 + j] = i == j ? 1.0 : 0.0; }
+    bool ok = true;
+    for (int c = 0; c < 4; ++c) {
+      int piv = c; double best = fabs(a[c][c]);
+      for (int rr = c + 1; rr < 4; ++rr) if (fabs(a[rr][c]) > best) { best = fabs(a[rr][c]); piv = rr; }
+      if (!(best > 0.0)) { ok = false; break; }
+      if (piv != c) for (int k = 0; k < 8; ++k) { const double tmp = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = tmp; }
+      const double inv = 1.0 / a[c][c];
+      for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+      for (int rr = 0; rr < 4; ++rr) if (rr != c) { const double f = a[rr][c]; for (int k = 0; k < 8; ++k) a[rr][k] -= f * a[c][k]; }
+    }
+    for (int i = 0; i < 4 && ok; ++i) for (int j = 0; j < 4; ++j) if (!isfinite(a[i][4 + j])) ok = false;
+    double out[8][3];
+    const double sg[8][3] = {{1, 1, 1}, {1, 1, -1}, {-1, 1, 1}, {-1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+    for (int k = 0; k < 8 && ok; ++k) {
+      const double p[3] = {sg[k][0] * size[0] / 2, sg[k][1] * size[1] / 2, sg[k][2] * size[2] / 2};
+      double cam[3];
+      for (int i = 0; i < 3; ++i) cam[i] = R[i * 3 + 0] * p[0] + R[i * 3 + 1] * p[1] + R[i * 3 + 2] * p[2] + (double)tf[i];
+      for (int i = 0; i < 3; ++i) {
+        if (!isfinite(cam[i])) ok = false;
+        out[k][i] = a[i][4] * cam[0] + a[i][5] * cam[1] + a[i][6] * cam[2] + a[i][7];
+      }
+    }
+    if (nocs_nan) ok = false;
+    const double dflt[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+    for (int k = 0; k < 8; ++k)
+      for (int i = 0; i < 3; ++i) bbox[((long long)b * 8 + k) * 3 + i] = ok ? out[k][i] : dflt[k][i] + 10.0;
+    valid[b] = ok ? 1 : 0;
+  }
+}
+
+int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
+                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s) {
+  RGBM_REQUIRE(P >= 2 && P <= PP_MAXP && (P % 2) == 0 && (PP_THREADS % (P / 2)) == 0, "postprocess needs even P<=1024 dividing 2048");
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(PP_THREADS), 0, s, nocs, depth, rot, choose, Kc, E1, bbox, ts_out,
+                     valid, P, img);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rgbm

@@ -1,0 +1,153 @@
+"""-m gpu: end-to-end parity of the HIP AdaPose forward (through the C ABI) against
+ (a) the committed golden vectors generated from the reference module itself and
+ (b) the CPU oracle on the same seeded inputs, including intermediates for bisecting."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rgbmanip_amd import synth  # noqa: E402
+
+RTOL_FP32 = 1e-4            # north_star: 1e-4 relative, fp32
+OUT_KEYS = ["view1_nocs", "view2_nocs", "view1_depth", "view2_depth", "view1_r", "view2_r", "view1_t", "view2_t",
+            "view1_s", "view2_s"]
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return synth.adapose_inputs(2, seed=0)
+
+
+@pytest.fixture(scope="module")
+def oracle_taps(inputs):
+    from oracle import adapose_ref
+    sd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+    t = {k: torch.from_numpy(v) for k, v in inputs.items()}
+    taps = {}
+    out = adapose_ref.adapose_forward(sd, t["img1"], t["choose1"], t["img2"], t["choose2"], t["P1"], t["P2"], t["depths"],
+                                      taps=taps)
+    return out, taps
+
+
+def _net(dtype, **kw):
+    from rgbmanip_amd.adapose import AdaPoseNet
+    return AdaPoseNet(synth.adapose_state_dict(seed=0, prefix="module."), dtype=dtype, **kw)
+
+
+def _run(net, inp, **kw):
+    out = net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"], **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_fp32_intermediates_vs_oracle(inputs, oracle_taps):
+    """Bisecting aid: PSPNet stages and cost-volume stages of view 1 against the oracle (fp32)."""
+    _, taps = oracle_taps
+    net = _net("fp32")
+    B, V = 2, 4
+    _run(net, inputs, stop_after=1)
+
+    def nhwc(name, C, H):
+        x = net.fetch(B, name, V * H * H * C).view(V, H, H, C)[:B]      # views 0..B-1 = view 1 of each pose
+        return x.permute(0, 3, 1, 2).cpu().numpy()
+    errs = {}
+    errs["conv1"] = _rel(nhwc("conv1", 64, 112), taps["v1_conv1"].numpy())
+    errs["layer4"] = _rel(nhwc("layer4", 512, 28), taps["v1_layer4"].numpy())
+    errs["cat"] = _rel(nhwc("cat", 1024, 28), taps["v1_psp"].numpy())
+    errs["u1"] = _rel(nhwc("u1", 256, 56), taps["v1_up_1"].numpy())
+    errs["u2"] = _rel(nhwc("u2", 64, 112), taps["v1_up_2"].numpy())
+    errs["u3"] = _rel(nhwc("u3", 64, 224), taps["v1_up_3"].numpy())
+    errs["feat"] = _rel(nhwc("feat", 32, 224), taps["feat1"].numpy())
+    print("fp32 PSPNet stage errors:", errs)
+    for k, e in errs.items():
+        assert e < RTOL_FP32, (k, errs)
+    # cost volume of the first chunk (all 4 views fit one chunk)
+    _run(net, inputs, stop_after=2)
+
+    def ndhwc(name, C, D, H):
+        x = net.fetch(B, name, V * D * H * H * C).view(V, D, H, H, C)[:B]
+        return x.permute(0, 4, 1, 2, 3).cpu().numpy()
+    errs = {}
+    errs["vol"] = _rel(ndhwc("vol", 32, 24, 224), taps["fused1"].numpy())
+    errs["c0"] = _rel(ndhwc("c0", 8, 24, 224), taps["v1_c0"].numpy())
+    errs["c2"] = _rel(ndhwc("c2", 16, 12, 112), taps["v1_c2"].numpy())
+    errs["c4"] = _rel(ndhwc("c4", 32, 6, 56), taps["v1_c4"].numpy())
+    errs["c6"] = _rel(ndhwc("c6", 64, 3, 28), taps["v1_c6"].numpy())
+    errs["u7"] = _rel(ndhwc("u7", 32, 6, 56), taps["v1_u7"].numpy())
+    errs["u9"] = _rel(ndhwc("u9", 16, 12, 112), taps["v1_u9"].numpy())
+    errs["u11"] = _rel(ndhwc("u11", 8, 24, 224), taps["v1_u11"].numpy())
+    prob = net.fetch(B, "prob", V * 1024 * 24).view(V, 1024, 24)[:B].permute(0, 2, 1).cpu().numpy()
+    errs["prob"] = _rel(prob, taps["v1_prob"].numpy())
+    print("fp32 cost-volume stage errors:", errs)
+    for k, e in errs.items():
+        assert e < RTOL_FP32, (k, errs)
+
+
+def test_fp32_matches_reference_golden(inputs, golden_dir):
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    out = _run(_net("fp32"), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print("fp32 vs reference golden:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+        assert errs[k] < RTOL_FP32, (k, errs)
+
+
+def test_fp32_batch_invariance_and_chunking():
+    """B=3 with a chunked cost volume (4 views per chunk, ragged last chunk) equals per-pose results."""
+    inp3 = synth.adapose_inputs(3, seed=5)
+    out3 = _run(_net("fp32", max_chunk_views=4), inp3)
+    net1 = _net("fp32")
+    for b in range(3):
+        one = {k: v[b:b + 1] for k, v in inp3.items()}
+        o1 = _run(net1, one)
+        for k in OUT_KEYS:
+            assert _rel(out3[k][b:b + 1], o1[k]) < 1e-5, (b, k)
+
+
+def test_bf16_close_to_golden(inputs, golden_dir):
+    """bf16 storage / fp32 accumulate: the throughput mode.  The bound is what 8-bit mantissas allow through a
+    ~60-layer un-normalised network; the measured errors are printed and recorded in DESIGN.md."""
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    out = _run(_net("bf16"), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print("bf16 vs reference golden:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+    assert errs["view1_depth"] < 3e-2 and errs["view1_nocs"] < 1e-1 and errs["view1_r"] < 1.5e-1, errs
+
+
+def test_nan_projection_stays_per_sample(inputs):
+    """A degenerate pair (singular projection) must poison only its own pose."""
+    inp = {k: v.copy() for k, v in inputs.items()}
+    inp["P2"][1] = 0.0
+    inp["P2"][1, 3, 3] = 1.0
+    net = _net("fp32")
+    out = _run(net, inp)
+    ref = _run(net, inputs)
+    assert _rel(out["view1_depth"][0], ref["view1_depth"][0]) < 1e-6
+    assert _rel(out["view1_r"][0], ref["view1_r"][0]) < 1e-6
+
+
+def test_estimate_end_to_end_vs_oracle(inputs, oracle_taps):
+    """network + device post-processing -> world bbox, against oracle network + numpy post-processing."""
+    from oracle import postproc_ref
+    from rgbmanip_amd.adapose import postprocess
+    oout, _ = oracle_taps
+    net = _net("fp32")
+    out = net(inputs["img1"], inputs["choose1"], inputs["img2"], inputs["choose2"], inputs["P1"], inputs["P2"], inputs["depths"])
+    bbox, ts, valid = postprocess(out["view1_nocs"], out["view1_depth"], out["view1_r"], inputs["choose1"], inputs["K1"], inputs["E1"])
+    torch.cuda.synchronize()
+    for b in range(2):
+        exp = postproc_ref.bbox_world(oout["view1_nocs"][b].numpy(), oout["view1_depth"][b].numpy(), oout["view1_r"][b].numpy(),
+                                      inputs["choose1"][b], inputs["K1"][b], inputs["E1"][b])
+        assert _rel(bbox[b].cpu().numpy(), exp) < 1e-3, b

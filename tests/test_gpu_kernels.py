@@ -1,0 +1,241 @@
+"""-m gpu: kernel-level parity of the HIP library against plain PyTorch-CPU fp32 ops / the oracle.
+
+fp32 mode must meet the north-star tolerance (1e-4 relative); bf16 mode is the throughput mode and is
+held to a bf16-appropriate bound (inputs/weights/outputs rounded to 8 mantissa bits, fp32 accumulate).
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from rgbmanip_amd import _lib  # noqa: E402
+
+TOL = {_lib.F32: 2e-5, _lib.BF16: 2.5e-2}
+DTYPES = [_lib.F32, _lib.BF16]
+
+
+def _act(y, act, slope):
+    if act == 1:
+        return F.relu(y)
+    if act == 2:
+        return torch.where(y > 0, y, y * slope)
+    if act == 3:
+        return torch.tanh(y)
+    return y
+
+
+CONV2D_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, pad, dil, bias, act, res_mode
+    ("l1_3x3_res", 2, 64, 14, 14, 64, 3, 1, 1, 1, False, 1, 1),
+    ("l2_3x3_s2", 2, 64, 14, 14, 128, 3, 2, 1, 1, False, 1, 0),
+    ("l3_dil2", 1, 32, 12, 12, 256, 3, 1, 2, 2, False, 1, 1),
+    ("l4_dil4", 1, 64, 12, 12, 128, 3, 1, 4, 4, False, 1, 0),
+    ("ds_1x1_s2", 2, 64, 14, 14, 128, 1, 2, 0, 1, False, 0, 0),
+    ("conv1_7x7", 2, 3, 32, 32, 64, 7, 2, 3, 1, False, 1, 0),
+    ("up_prelu", 1, 256, 10, 10, 64, 3, 1, 1, 1, True, 2, 0),
+    ("final_1x1", 1, 64, 20, 20, 32, 1, 1, 0, 1, True, 0, 0),
+    ("psp_1x1_tinyM", 3, 512, 2, 2, 128, 1, 1, 0, 1, False, 1, 0),
+    ("big_k", 1, 1024, 6, 6, 256, 3, 1, 1, 1, True, 2, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV2D_CASES, ids=[c[0] for c in CONV2D_CASES])
+def test_conv2d(case, dtype):
+    from gpu_util import conv_nd, rel_err
+    name, N, Cin, H, W, Cout, k, stride, pad, dil, has_bias, act, res_mode = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    res = torch.randn(ref.shape, generator=g) if res_mode else None
+    if dtype == _lib.BF16:       # compare against the same rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+        ref = F.conv2d(x, w, b, stride, pad, dil)
+    if res_mode == 1:
+        ref = ref + res
+    ref = _act(ref, act, 0.25)
+    y = conv_nd(dtype, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25)
+    assert y.shape == ref.shape
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < TOL[dtype], name
+
+
+CONV3D_CASES = [
+    # name, Cin, Cout, stride, transposed, (D,H,W)
+    ("c0_32_8", 32, 8, 1, False, (8, 12, 12)),
+    ("c1_8_16_s2", 8, 16, 2, False, (8, 12, 12)),
+    ("c2_16_16", 16, 16, 1, False, (4, 10, 10)),
+    ("c3_16_32_s2", 16, 32, 2, False, (4, 10, 10)),
+    ("c4_32_32", 32, 32, 1, False, (4, 6, 6)),
+    ("c5_32_64_s2", 32, 64, 2, False, (4, 6, 6)),
+    ("c6_64_64", 64, 64, 1, False, (3, 5, 5)),
+    ("d7_64_32", 64, 32, 2, True, (3, 5, 5)),
+    ("d9_32_16", 32, 16, 2, True, (3, 6, 6)),
+    ("d11_16_8", 16, 8, 2, True, (4, 7, 7)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV3D_CASES, ids=[c[0] for c in CONV3D_CASES])
+def test_conv3d_bn_relu(case, dtype):
+    from gpu_util import conv_nd, rel_err
+    name, Cin, Cout, stride, transposed, (D, H, W) = case
+    g = torch.Generator().manual_seed(len(name) * 7 + Cin)
+    N = 2
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    if transposed:
+        w = torch.randn(Cin, Cout, 3, 3, 3, generator=g) / np.sqrt(Cin * 27 / 8)
+    else:
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(Cin * 27)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    if dtype == _lib.BF16:
+        x = x.bfloat16().float()
+    wf = w * (scale.view(1, -1, 1, 1, 1) if transposed else scale.view(-1, 1, 1, 1, 1))
+    if dtype == _lib.BF16:
+        wf = wf.bfloat16().float()
+    if transposed:
+        ref = F.conv_transpose3d(x, wf, None, 2, 1, 1)
+    else:
+        ref = F.conv3d(x, wf, None, stride, 1)
+    ref = F.relu(ref + shift.view(1, -1, 1, 1, 1))
+    res = None
+    if transposed:
+        res = torch.randn(ref.shape, generator=g)
+        if dtype == _lib.BF16:
+            res = res.bfloat16().float()
+        ref = ref + res                      # post-activation skip add (network_v5.py:287-289)
+    y = conv_nd(dtype, x, w, stride=stride, pad=1, transposed=transposed, bn_scale=scale, bn_shift=shift, res=res,
+                res_mode=2 if transposed else 0, act=1)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL[dtype], name
+
+
+LINEAR_CASES = [("inst_32_64", 32, 64, 1), ("pm1_96_128", 96, 128, 1), ("npm_3_32", 3, 32, 1), ("nocs_64_3_tanh", 64, 3, 3),
+                ("pm2_256_256", 256, 256, 1)]
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=[c[0] for c in LINEAR_CASES])
+def test_linear_as_conv_fp32(case):
+    from gpu_util import conv_nd, rel_err
+    name, Cin, Cout, act = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(2, Cin, 1, 700, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = _act(F.conv2d(x, w, b), act, 0.0)
+    y = conv_nd(_lib.F32, x, w, bias=b, act=act)
+    assert rel_err(y, ref) < 2e-5, name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_resize_avgpool(dtype):
+    from gpu_util import to_channels_last, from_channels_last, rel_err, TORCH_DT
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 18, 18, generator=g)
+    if dtype == _lib.BF16:
+        x = x.bfloat16().float()
+    xd = to_channels_last(x, dtype)
+    # max-pool 3x3 s2 p1 (pspnet.py:39)
+    out = torch.empty(2, 9, 9, 64, dtype=TORCH_DT[dtype], device="cuda")
+    _lib.check(lib.rgbm_maxpool3x3s2(dtype, _lib.ptr(xd), _lib.ptr(out), 2, 18, 18, 64, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_channels_last(out), F.max_pool2d(x, 3, 2, 1)) < 1e-6
+    # bilinear x2 align_corners=True (pspnet.py:106)
+    out = torch.empty(2, 36, 36, 64, dtype=TORCH_DT[dtype], device="cuda")
+    _lib.check(lib.rgbm_resize_bilinear_ac(dtype, _lib.ptr(xd), _lib.ptr(out), 2, 18, 18, 64, 36, 36, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    assert rel_err(from_channels_last(out), ref) < (1e-5 if dtype == _lib.F32 else 1e-2)
+    # adaptive avg pool with overlapping windows (28 -> 1,2,3,6)
+    x = torch.randn(2, 64, 28, 28, generator=g)
+    if dtype == _lib.BF16:
+        x = x.bfloat16().float()
+    xd = to_channels_last(x, dtype)
+    for S in (1, 2, 3, 6):
+        out = torch.empty(2, S, S, 64, dtype=TORCH_DT[dtype], device="cuda")
+        _lib.check(lib.rgbm_adaptive_avgpool(dtype, _lib.ptr(xd), _lib.ptr(out), 2, 28, 28, 64, S, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = F.adaptive_avg_pool2d(x, (S, S))
+        assert rel_err(from_channels_last(out), ref) < (1e-5 if dtype == _lib.F32 else 1e-2), S
+        # PSP expand: bilinear align_corners=True from SxS to 28x28 (pspnet.py:93)
+        out2 = torch.empty(2, 28, 28, 64, dtype=TORCH_DT[dtype], device="cuda")
+        _lib.check(lib.rgbm_resize_bilinear_ac(dtype, _lib.ptr(out), _lib.ptr(out2), 2, S, S, 64, 28, 28, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        ref2 = F.interpolate(from_channels_last(out), size=(28, 28), mode="bilinear", align_corners=True)
+        assert rel_err(from_channels_last(out2), ref2) < (1e-5 if dtype == _lib.F32 else 1e-2), S
+
+
+def test_build_volume_matches_reference_warp(golden_dir):
+    """Fused plane-sweep volume vs the golden produced by the reference's homo_warping (fp32)."""
+    from gpu_util import to_channels_last, rel_err
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, "adapose_layers.npz"))
+    fea = torch.from_numpy(g["warp_fea"])                 # [2,32,16,16]: treat as B=1: view0 = ref, view1 = src
+    Psrc, Pref, dv = g["warp_Psrc"], g["warp_Pref"], g["warp_depths"]
+    # golden: warped = homo_warping(fea, Psrc, Pref); build a 2-view problem per sample so that
+    # vol[view0] = fea_ref + warp(fea_src): use B=1 with view0 = sample b (ref proj), view1 = same feature (src proj)
+    for b in range(2):
+        feat = torch.stack([fea[b], fea[b]])              # both views hold the same feature map
+        P = torch.from_numpy(np.stack([Pref[b], Psrc[b]])).float().cuda()
+        fd = to_channels_last(feat, _lib.F32)
+        D = dv.shape[1]
+        vol = torch.empty(2, D, 16, 16, 32, dtype=torch.float32, device="cuda")
+        hom = torch.empty(2 * 12, dtype=torch.float32, device="cuda")
+        dep = torch.from_numpy(dv[b:b + 1]).cuda()
+        _lib.check(lib.rgbm_build_volume(_lib.F32, _lib.ptr(fd), _lib.ptr(P), _lib.ptr(dep), _lib.ptr(hom), _lib.ptr(vol),
+                                         2, 1, D, 16, 16, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got = vol[0].permute(3, 0, 1, 2).cpu()            # [32,D,16,16] = ref + warped
+        ref = fea[b].unsqueeze(1) + torch.from_numpy(g["warp_out"][b])
+        assert rel_err(got, ref) < 1e-4, b
+
+
+def test_gae_matches_golden(golden_dir):
+    from rgbmanip_amd import synth
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, "ppo.npz"))
+    T, N = 16, 32
+    roll = synth.ppo_rollout(T, N, seed=0)
+    dev = {k: torch.from_numpy(v).cuda().contiguous() for k, v in roll.items()}
+    ret = torch.empty(T, N, dtype=torch.float32, device="cuda")
+    adv = torch.empty(T, N, dtype=torch.float32, device="cuda")
+    sums = torch.zeros(2 + 2 * ((N + 255) // 256), dtype=torch.float64, device="cuda")
+    _lib.check(lib.rgbm_gae(T, N, _lib.ptr(dev["rewards"]), _lib.ptr(dev["dones"]), _lib.ptr(dev["values"]),
+                            _lib.ptr(dev["last_values"]), 0.98, 0.98, _lib.ptr(ret), _lib.ptr(adv), _lib.ptr(sums),
+                            _lib.stream_ptr()))
+    _lib.check(lib.rgbm_adv_normalise(T * N, _lib.ptr(adv), _lib.ptr(sums), float(T * N), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(ret.cpu().numpy().reshape(T, N, 1), g["n32_returns"])          # bit-exact recurrence
+    np.testing.assert_allclose(adv.cpu().numpy().reshape(T, N, 1), g["n32_advantages"], rtol=1e-5, atol=1e-6)
+
+
+def test_postprocess_matches_golden(golden_dir):
+    from rgbmanip_amd.adapose import postprocess
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    n = int(g["n_cases"])
+    nocs = torch.from_numpy(np.stack([g[f"c{i}_in_nocs"] for i in range(n)])).cuda()
+    depth = torch.from_numpy(np.stack([g[f"c{i}_in_depth"] for i in range(n)])).cuda()
+    R = torch.from_numpy(np.stack([g[f"c{i}_in_R"] for i in range(n)])).cuda()
+    ch = np.stack([g[f"c{i}_in_choose"] for i in range(n)])
+    K = np.stack([g[f"c{i}_in_K"] for i in range(n)])
+    E = np.stack([g[f"c{i}_in_E"] for i in range(n)])
+    bbox, ts, valid = postprocess(nocs, depth, R, ch, K, E)
+    torch.cuda.synchronize()
+    bbox, ts, valid = bbox.cpu().numpy(), ts.cpu().numpy(), valid.cpu().numpy()
+    for i in range(n):
+        exp = g[f"c{i}_bbox"]
+        is_default = np.allclose(exp, exp.round()) and exp.min() >= 10.0
+        assert bool(valid[i]) == (not is_default), i
+        np.testing.assert_allclose(bbox[i], exp, rtol=1e-6, atol=1e-7, err_msg=f"case {i}")
+        if not is_default:
+            np.testing.assert_allclose(ts[i, 3], float(g[f"c{i}_s"]), rtol=1e-12)        # exact median element
