@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AdaPose poses/sec at batch 256 (BASELINE.json configs[1]) on N MI355X.
+
+One "step" = one pass of the estimator hot path over one batch of 256 synthetic poses per GPU:
+  HIP network forward (2 x 256 views of 224x224, all 10 outputs)  +  device post-processing to world boxes,
+with every input already resident in HBM.  N > 1: one process per GPU (torch.distributed, RCCL); poses are
+independent, so ranks shard the batch with no data-path collective (weak scaling, 256 poses per GPU).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
+dominant kernel (the library's rgbm_prof_* hooks, same stream as the launches); `cpu_baseline` times the CPU
+oracle (PyTorch-CPU restatement of the reference, proven equal to it on golden vectors) on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GFLOP_PER_POSE = 163.68          # hooks on the reference module, 2*MAC, full 10-output forward
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks
+VARIANT_NAMES = {0: "f32,16,256", 1: "f32,32,256", 2: "f32,64,256", 3: "f32,128,128",
+                 4: "bf16,16,256", 5: "bf16,32,256", 6: "bf16,64,256", 7: "bf16,128,128"}
+
+
+def make_inputs(B, device, unique=16):
+    from rgbmanip_amd import synth
+    u = min(unique, B)
+    base = synth.adapose_inputs(u, seed=0)
+    reps = (B + u - 1) // u
+    out = {}
+    for k, v in base.items():
+        t = np.concatenate([v] * reps, axis=0)[:B]
+        out[k] = t
+    dev = {
+        "img1": torch.from_numpy(out["img1"]).to(device), "img2": torch.from_numpy(out["img2"]).to(device),
+        "choose1": torch.from_numpy(out["choose1"]).to(device=device, dtype=torch.int32),
+        "choose2": torch.from_numpy(out["choose2"]).to(device=device, dtype=torch.int32),
+        "P1": torch.from_numpy(out["P1"]).to(device), "P2": torch.from_numpy(out["P2"]).to(device),
+        "depths": torch.from_numpy(out["depths"]).to(device),
+        "K1": torch.from_numpy(out["K1"]).to(device), "E1": torch.from_numpy(out["E1"]).to(device),
+    }
+    return out, dev
+
+
+def cpu_baseline(n_chunks=2, chunk=2):
+    """Oracle (kind "port") on the host cores: network forward + numpy post-processing, bounded sample."""
+    from oracle import adapose_ref, postproc_ref
+    from rgbmanip_amd import synth
+    cores = min(os.cpu_count() or 1, 32)       # oneDNN convs at batch 2 stop scaling (and thrash) far below 256 threads
+    torch.set_num_threads(cores)
+    sd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+    inp = synth.adapose_inputs(chunk, seed=1)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+
+    def one():
+        o = adapose_ref.adapose_forward(sd, t["img1"], t["choose1"], t["img2"], t["choose2"], t["P1"], t["P2"], t["depths"])
+        for b in range(chunk):
+            postproc_ref.bbox_world(o["view1_nocs"][b].numpy(), o["view1_depth"][b].numpy(), o["view1_r"][b].numpy(),
+                                    inp["choose1"][b], inp["K1"][b], inp["E1"][b])
+    one()                                   # warm-up chunk
+    t0 = time.perf_counter()
+    for _ in range(n_chunks):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_chunks * chunk / dt, 4), "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": f"{n_chunks} timed chunks of {chunk} poses (1 warm-up chunk), fp32 PyTorch-CPU oracle forward + numpy "
+                      f"compute_scale/bbox, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="poses per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
+                         f"(WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from rgbmanip_amd import _lib, synth
+    from rgbmanip_amd.adapose import AdaPoseNet, postprocess
+    lib = _lib.load()
+    net = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank,
+                     max_chunk_views=args.chunk or None)
+    B = args.batch
+    host, d = make_inputs(B, device)
+
+    def step():
+        out = net(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
+        bbox, ts, valid = postprocess(out["view1_nocs"], out["view1_depth"], out["view1_r"], d["choose1"], d["K1"], d["E1"])
+        return out, bbox, valid
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.check(lib.rgbm_prof_start(), "rgbm_prof_start")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, bbox, valid = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = (C.c_double * 32)()
+    _lib.check(lib.rgbm_prof_stop(stats), "rgbm_prof_stop")
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_valid = int(valid.sum().item())
+    finite = bool(torch.isfinite(bbox).all().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B / (elapsed / args.steps)
+        st = np.array(list(stats)).reshape(8, 4)
+        kernels = []
+        for v in range(8):
+            n, ms, fl, by = st[v]
+            if n > 0:
+                kernels.append({"kernel": f"conv_igemm_kernel<{VARIANT_NAMES[v]}>", "launches_per_step": n / args.steps,
+                                "avg_launch_ms": ms / n, "total_ms_per_step": ms / args.steps,
+                                "tflops": fl / (ms * 1e-3) / 1e12, "algo_GBps": by / (ms * 1e-3) / 1e9})
+        kernels.sort(key=lambda k: -k["total_ms_per_step"])
+        dom = kernels[0]
+        peak = PEAK_TFLOPS[args.dtype if dom["kernel"].find("bf16") >= 0 else "fp32"]
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                    "avg_launch_ms": round(dom["avg_launch_ms"], 4), "launches_per_step": dom["launches_per_step"],
+                    "flops_per_launch": dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3}
+        res = {
+            "metric": "adapose_poses_per_sec_batch256", "value": round(value, 3), "unit": "poses/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "adapose_cabinet forward + post-processing, batch=256 poses (512 views of 224x224) per GPU, "
+                                   "synthetic RGB, random-init weights of the reference architecture",
+                       "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}"},
+            "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
+            "whole_net_frac_of_mfma_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
+            "valid_poses_last_step": n_valid, "outputs_finite": finite,
+            "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+            res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,13 @@ int rgbm_adapose_forward_ex(rgbm_adapose_t* h, int B, const float* img1, const f
 int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* name, float* out_dev, size_t capacity,
                        size_t* n_elems, void* stream);
 
+/* Live per-kernel timing for bench.py's roofline figure: between start and stop every convolution launch is
+ * bracketed by HIP events recorded on its own stream.  stats: host double[8*4]; row v = dtype*4 + {0:16,1:32,2:64,
+ * 3:128}-channel tile instantiation of conv_igemm_kernel, columns {launches, total ms, algorithmic FLOPs,
+ * algorithmic bytes}.  stop synchronises on the recorded events. */
+int rgbm_prof_start(void);
+int rgbm_prof_stop(double* stats);
+
 #ifdef __cplusplus
 }
 #endif

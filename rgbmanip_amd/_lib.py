@@ -51,6 +51,8 @@ SIGNATURES = {
     "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_build_volume": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbm_prof_start": (_i, []),
+    "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -8,12 +8,15 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
 for f in conv_igemm.hip misc_kernels.hip head_kernels.hip postproc.hip ppo_kernels.hip policy_kernels.hip; do
   [ -f "$f" ] || continue
-  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ]; then
-    hipcc $FLAGS -c "$f" -o build/${f%.hip}.o &
+  EXTRA=""
+  # files that must round like numpy / torch elementwise ops: no mul+add -> fma contraction
+  case "$f" in postproc.hip|ppo_kernels.hip) EXTRA="-ffp-contract=off";; esac
+  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ] || [ build.sh -nt build/${f%.hip}.o ]; then
+    hipcc $FLAGS $EXTRA -c "$f" -o build/${f%.hip}.o &
     pids+=($!)
   fi
 done
-for f in layers.cpp adapose.cpp capi.cpp; do
+for f in layers.cpp adapose.cpp capi.cpp prof.cpp; do
   hipcc $FLAGS -x hip -c "$f" -o build/${f%.cpp}.o &
   pids+=($!)
 done

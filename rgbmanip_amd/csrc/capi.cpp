@@ -173,3 +173,12 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 }
 
 }  // extern "C"
+
+#include "prof.h"
+extern "C" {
+int rgbm_prof_start(void) { return rgbm::prof_start(); }
+int rgbm_prof_stop(double* stats) {
+  RGBM_REQUIRE(stats != nullptr, "prof_stop arguments");
+  return rgbm::prof_stop(stats, rgbm::kProfVariants);
+}
+}

@@ -116,6 +116,7 @@ struct ConvDesc {
   int act; float slope; int res_mode; int bias_stride;  // bias index = n*bias_stride + ch
   long long M;                            // N*Dq*Hq*Wq
   int n_pix_tiles, n_ch_tiles;
+  double algo_flops, algo_bytes;          // algorithmic work of this launch (profiling only)
 };
 
 int launch_conv(const ConvDesc& d, int dtype, hipStream_t s);

@@ -18,6 +18,7 @@
 // ds_read_b128 lane group touches land on 16 distinct 16-B bank slots.
 // bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); f32: v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "common.h"
+#include "prof.h"
 
 namespace rgbm {
 
@@ -249,7 +250,10 @@ static int launch_one(ConvDesc d, hipStream_t s) {
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
+  const int variant = (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
+  prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_kernel<T, BCH, BPIX>), dim3((unsigned)nblk), dim3(256), 0, s, d);
+  prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -272,7 +276,6 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
   RGBM_REQUIRE(d.Cin % E == 0, "conv Cin must be a multiple of the 16-byte chunk");
   if (d.lcin >= 0) {
     RGBM_REQUIRE((1 << d.lcin) == d.Cin, "conv lcin mismatch");
-    RGBM_REQUIRE(d.Kpad / d.Cin <= 64 || d.Cin >= conv_bk(dtype), "conv tap range");
   } else {
     RGBM_REQUIRE(d.ntaps == 1, "linear-K mode needs a single tap");
   }

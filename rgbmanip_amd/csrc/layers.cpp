@@ -170,6 +170,11 @@ int ConvLayer::run(const void* in, void* out, int N, int Di, int Hi, int Wi, int
       d.opd = d.oph = d.opw = 0;
     }
     d.M = (long long)N * d.Dq * d.Hq * d.Wq;
+    // algorithmic work: real (unpadded) channels, every tap counted (zero padding included, as usual)
+    d.algo_flops = 2.0 * (double)d.M * g.Cout * (double)pc.ntaps * g.Cin;
+    d.algo_bytes = ((double)d.M * g.Cout + (cls == 0 ? (double)N * Di * Hi * Wi * g.Cin : 0.0) +
+                    (res ? (double)d.M * g.Cout : 0.0)) * (double)dtype_size(dtype) +
+                   (double)g.Cout * pc.ntaps * g.Cin * (double)dtype_size(dtype);
     if (int rc = launch_conv(d, dtype, s)) return rc;
   }
   return 0;

@@ -22,13 +22,15 @@ constexpr int PP_THREADS = 1024;
 
 __device__ __forceinline__ bool pair_ratio(const double* cx, const double* cy, const double* cz, const float* nx,
                                            const float* ny, const float* nz, int i, int j, double& ratio) {
-  const float dx = __fsub_rn(nx[i], nx[j]), dy = __fsub_rn(ny[i], ny[j]), dz = __fsub_rn(nz[i], nz[j]);
-  const float nd = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  // plain IEEE operators (this file is built with -ffp-contract=off; sqrtf/sqrt/÷ are correctly rounded,
+  // whereas HIP's __fsqrt_rn/__fdiv_rn wrappers lower to the approximate native instructions)
+  const float dx = nx[i] - nx[j], dy = ny[i] - ny[j], dz = nz[i] - nz[j];
+  const float nd = sqrtf((dx * dx + dy * dy) + dz * dz);
   if (!(nd > 0.01f)) return false;
-  const double ex = __dsub_rn(cx[i], cx[j]), ey = __dsub_rn(cy[i], cy[j]), ez = __dsub_rn(cz[i], cz[j]);
-  const double rd = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez)));
+  const double ex = cx[i] - cx[j], ey = cy[i] - cy[j], ez = cz[i] - cz[j];
+  const double rd = sqrt((ex * ex + ey * ey) + ez * ez);
   if (!(rd < 0.3)) return false;
-  ratio = __ddiv_rn(rd, (double)nd);
+  ratio = rd / (double)nd;
   return true;
 }
 
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
     const int ch = choose[(long long)b * P + t];
     const double u = (double)(ch % img), v = (double)(ch / img);
     const double z = (double)depth[(long long)b * P + t];
-    cx[t] = __ddiv_rn(__dmul_rn(__dsub_rn(u, pcx), z), fx);
-    cy[t] = __ddiv_rn(__dmul_rn(__dsub_rn(v, pcy), z), fy);
+    cx[t] = ((u - pcx) * z) / fx;
+    cy[t] = ((v - pcy) * z) / fy;
     cz[t] = z;
     nx[t] = nocs[((long long)b * P + t) * 3 + 0];
     ny[t] = nocs[((long long)b * P + t) * 3 + 1];

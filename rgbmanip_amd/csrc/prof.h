@@ -1,0 +1,11 @@
+#pragma once
+#include <hip/hip_runtime.h>
+namespace rgbm {
+// conv variants: dtype*4 + {0: BCH16, 1: BCH32, 2: BCH64, 3: BCH128}
+constexpr int kProfVariants = 8;
+bool prof_enabled();
+void prof_begin_launch(hipStream_t s, int variant, double flops, double bytes);
+void prof_end_launch(hipStream_t s);
+int prof_start();
+int prof_stop(double* stats, int n_variants);
+}  // namespace rgbm
