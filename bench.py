@@ -25,8 +25,10 @@ import torch
 
 GFLOP_PER_POSE = 163.68          # hooks on the reference module, 2*MAC, full 10-output forward
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks
-VARIANT_NAMES = {0: "f32,16,256", 1: "f32,32,256", 2: "f32,64,256", 3: "f32,128,128",
-                 4: "bf16,16,256", 5: "bf16,32,256", 6: "bf16,64,256", 7: "bf16,128,128"}
+VARIANT_NAMES = {0: "conv_igemm_kernel<f32,16,256>", 1: "conv_igemm_kernel<f32,32,256>", 2: "conv_igemm_kernel<f32,64,256>",
+                 3: "conv_igemm_kernel<f32,128,128>", 4: "conv_igemm_kernel<bf16,16,256>", 5: "conv_igemm_kernel<bf16,32,256>",
+                 6: "conv_igemm_kernel<bf16,64,256>", 7: "conv_igemm_kernel<bf16,128,128>",
+                 8: "conv3d_tile_kernel<f32,*>", 9: "conv3d_tile_kernel<bf16,*>"}
 
 
 def make_inputs(B, device, unique=16):
@@ -83,6 +85,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
+    ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,7 +106,7 @@ def main():
     from rgbmanip_amd.adapose import AdaPoseNet, postprocess
     lib = _lib.load()
     net = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank,
-                     max_chunk_views=args.chunk or None)
+                     max_chunk_views=args.chunk or None, cost_impl=None if args.cost_impl < 0 else args.cost_impl)
     B = args.batch
     host, d = make_inputs(B, device)
 
@@ -126,7 +129,7 @@ def main():
         out, bbox, valid = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    stats = (C.c_double * 32)()
+    stats = (C.c_double * 40)()
     _lib.check(lib.rgbm_prof_stop(stats), "rgbm_prof_stop")
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -138,12 +141,12 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
-        st = np.array(list(stats)).reshape(8, 4)
+        st = np.array(list(stats)).reshape(10, 4)
         kernels = []
-        for v in range(8):
+        for v in range(10):
             n, ms, fl, by = st[v]
             if n > 0:
-                kernels.append({"kernel": f"conv_igemm_kernel<{VARIANT_NAMES[v]}>", "launches_per_step": n / args.steps,
+                kernels.append({"kernel": VARIANT_NAMES[v], "launches_per_step": n / args.steps,
                                 "avg_launch_ms": ms / n, "total_ms_per_step": ms / args.steps,
                                 "tflops": fl / (ms * 1e-3) / 1e12, "algo_GBps": by / (ms * 1e-3) / 1e9})
         kernels.sort(key=lambda k: -k["total_ms_per_step"])

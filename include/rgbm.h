@@ -54,6 +54,10 @@ int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* 
 int rgbm_adapose_destroy(rgbm_adapose_t* h);
 /* views per cost-volume chunk (default 32); bounds the workspace */
 int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
+/* options: "max_chunk" (views per cost-volume chunk), "cost_impl" (2 = halo-tiled 3-D convs with the plane-sweep
+ * volume fused into conv0's loader [default]; 1 = halo-tiled convs on a materialised volume; 0 = generic implicit
+ * GEMM on a materialised volume).  Set before querying the workspace size. */
+int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
 /* img1/img2 [B,3,224,224] fp32 NCHW normalised; choose1/2 [B,1024] int32; P1/P2 [B,4,4] fp32; depths [B,24] fp32.
  * Same argument meaning as network_v5.py:418 (view1_img, view1_choose, view2_img, view2_choose, view1_proj,
@@ -95,6 +99,12 @@ int rgbm_conv_nd(int dtype, const void* in_dev, int N, int D, int H, int W, int 
                  int Cout, int Cout_pad, int KD, int KH, int KW, int stride_d, int stride_hw, int pad_d, int pad_hw,
                  int dil_hw, int transposed, const float* bias_host, const float* bn_scale_host, const float* bn_shift_host,
                  const void* res_dev, int res_mode, int act, float slope, void* out_dev, void* stream);
+/* Halo-tiled 3-D conv of the cost-regularisation stack, one layer: layer 0..6 = conv0..conv6 (k3, pad 1, stride 1/2),
+ * 7..9 = conv7/conv9/conv11 (ConvTranspose3d k3 s2 p1 op1).  Channels are fixed by the layer (network_v5.py:263-278);
+ * in_dev [N][D][H][W][Cin], out_dev [N][Do][Ho][Wo][Cout], folded BN scale/shift on the host, ReLU, optional
+ * post-activation residual res_dev (same layout as out). */
+int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N, int D, int H, int W, const float* w_host,
+                     const float* bn_scale_host, const float* bn_shift_host, const void* res_dev, void* out_dev, void* stream);
 int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream);
 int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
                             void* stream);
@@ -113,8 +123,8 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
                        size_t* n_elems, void* stream);
 
 /* Live per-kernel timing for bench.py's roofline figure: between start and stop every convolution launch is
- * bracketed by HIP events recorded on its own stream.  stats: host double[8*4]; row v = dtype*4 + {0:16,1:32,2:64,
- * 3:128}-channel tile instantiation of conv_igemm_kernel, columns {launches, total ms, algorithmic FLOPs,
+ * bracketed by HIP events recorded on its own stream.  stats: host double[10*4]; rows 0..7 = dtype*4 + {0:16,1:32,2:64,
+ * 3:128}-channel tile instantiation of conv_igemm_kernel, rows 8/9 = conv3d_tile_kernel f32/bf16; columns {launches, total ms, algorithmic FLOPs,
  * algorithmic bytes}.  stop synchronises on the recorded events. */
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);

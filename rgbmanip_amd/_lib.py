@@ -38,6 +38,7 @@ SIGNATURES = {
     "rgbm_adapose_create": (_i, [C.POINTER(_vp), _i, C.POINTER(WeightDesc), _i, _i, _i]),
     "rgbm_adapose_destroy": (_i, [_vp]),
     "rgbm_adapose_set_chunk": (_i, [_vp, _i]),
+    "rgbm_adapose_set_option": (_i, [_vp, C.c_char_p, _i]),
     "rgbm_adapose_workspace_bytes": (_i, [_vp, _i, C.POINTER(_sz)]),
     "rgbm_adapose_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _vp]),
     "rgbm_adapose_forward_ex": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _i, _vp]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "rgbm_adv_normalise": (_i, [_i64, _vp, _vp, _d, _vp]),
     "rgbm_conv_nd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                           _vp, _i, _i, _f, _vp, _vp]),
+    "rgbm_conv3d_tile": (_i, [_i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_maxpool3x3s2": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -116,6 +116,37 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
   if (int rc = init_conv3d_bn(dc[1], dtype, sd, cr + "conv9.", 32, 16, 2, true)) return rc;
   if (int rc = init_conv3d_bn(dc[2], dtype, sd, cr + "conv11.", 16, 8, 2, true)) return rc;
   {
+    // halo-tiled versions of the same ten layers (conv3d_tile.hip)
+    const char* nm[10] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"};
+    const int cin[10] = {32, 8, 16, 16, 32, 32, 64, 64, 32, 16};
+    const int cout[10] = {8, 16, 16, 32, 32, 64, 64, 32, 16, 8};
+    for (int i = 0; i < 10; ++i) {
+      const std::string p = cr + nm[i] + ".";
+      GET(w, p + "conv.weight");
+      std::vector<float> scale, shift, packed;
+      if (int rc = bn_fold(sd, p + "bn.", cout[i], scale, shift)) return rc;
+      const int coutp = cout[i] < 16 ? 16 : cout[i];
+      conv3d_tile_pack(w->data, scale.data(), cin[i], cout[i], coutp, i >= 7, dtype, packed);
+      t3d[i].Cin = cin[i]; t3d[i].Cout = cout[i];
+      if (dtype == BF16) {
+        std::vector<unsigned short> h(packed.size());
+        for (size_t k = 0; k < packed.size(); ++k) {
+          unsigned u; memcpy(&u, &packed[k], 4);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          h[k] = (unsigned short)(u >> 16);
+        }
+        RGBM_CHECK_HIP(hipMalloc(&t3d[i].w, h.size() * 2));
+        RGBM_CHECK_HIP(hipMemcpy(t3d[i].w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      } else {
+        RGBM_CHECK_HIP(hipMalloc(&t3d[i].w, packed.size() * 4));
+        RGBM_CHECK_HIP(hipMemcpy(t3d[i].w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      }
+      std::vector<float> bpad(coutp, 0.f);
+      for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
+      if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
+    }
+  }
+  {
     GET(w, cr + "prob.weight");
     RGBM_REQUIRE(w->numel() == 8 * 27, "prob weight shape");
     std::vector<float> wp(27 * 8);
@@ -169,6 +200,7 @@ void AdaPose::destroy() {
   for (auto& l : npm) l.destroy();
   for (auto& l : pm1) l.destroy();
   for (auto& l : pm2) l.destroy();
+  for (auto& t : t3d) { if (t.w) (void)hipFree(t.w); if (t.bias) (void)hipFree(t.bias); t.w = nullptr; t.bias = nullptr; }
   if (wprob) (void)hipFree(wprob);
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
@@ -229,7 +261,7 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   const int Vc = chunk_views(V);
   const int D = n_depth;
   const size_t vox = (size_t)D * S * S;
-  bf.vol = A.alloc((size_t)Vc * vox * 32 * es);
+  bf.vol = cost_impl == 2 ? nullptr : A.alloc((size_t)Vc * vox * 32 * es);   // fused-warp conv0 never materialises it
   bf.c[0] = A.alloc((size_t)Vc * vox * 8 * es);
   bf.c[1] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
   bf.c[2] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
@@ -299,7 +331,43 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
 int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const {
   const int S = img, D = n_depth, P = n_pts;
   const int Vc0 = chunk_views(V);
-  for (int v0 = 0; v0 < V; v0 += Vc0) {
+  // halo-tiled path (cost_impl >= 1): one launch per layer; conv0 optionally builds its input on the fly
+  auto tile = [&](int layer, const void* in, void* out, const void* res, int Vc, int Di, int Hi, int Wi, int Do, int Ho,
+                  int Wo, bool transposed, int v0) -> int {
+    const int li = layer == 10 ? 0 : layer;
+    Conv3dTileDesc d;
+    memset(&d, 0, sizeof(d));
+    d.in = in; d.wgt = t3d[li].w; d.out = out; d.bias = t3d[li].bias; d.res = res;
+    d.N = Vc; d.Di = Di; d.Hi = Hi; d.Wi = Wi; d.Do = Do; d.Ho = Ho; d.Wo = Wo;
+    d.Dq = transposed ? Di : Do; d.Hq = transposed ? Hi : Ho; d.Wq = transposed ? Wi : Wo;
+    d.Cout = t3d[li].Cout; d.relu = 1;
+    d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
+    d.prof_variant = 8 + (dtype == BF16 ? 1 : 0);
+    d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
+    d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
+                   (double)dtype_size(dtype);
+    return launch_conv3d_tile(layer, dtype, d, s);
+  };
+  for (int v0 = 0; cost_impl >= 1 && v0 < V; v0 += Vc0) {
+    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+    if (cost_impl == 1) {
+      if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
+      if (int rc = tile(0, bf.vol, bf.c[0], nullptr, Vc, D, S, S, D, S, S, false, v0)) return rc;
+    } else {
+      if (int rc = tile(10, nullptr, bf.c[0], nullptr, Vc, D, S, S, D, S, S, false, v0)) return rc;
+    }
+    if (int rc = tile(1, bf.c[0], bf.c[1], nullptr, Vc, D, S, S, D / 2, S / 2, S / 2, false, v0)) return rc;
+    if (int rc = tile(2, bf.c[1], bf.c[2], nullptr, Vc, D / 2, S / 2, S / 2, D / 2, S / 2, S / 2, false, v0)) return rc;
+    if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0)) return rc;
+    if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0)) return rc;
+    if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0)) return rc;
+    if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
+    if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
+    if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
+    if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;
+    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, s)) return rc;
+  }
+  for (int v0 = 0; cost_impl == 0 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
     if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
     if (int rc = c3d[0].run(bf.vol, bf.c[0], Vc, D, S, S, 8, nullptr, 0, nullptr, 0, s)) return rc;

@@ -29,7 +29,10 @@ struct AdaPose {
   Block blocks[16];
   int n_blocks = 0;
   ConvLayer psp[4], up1, up2, up3, fin;
-  ConvLayer c3d[7], dc[3];
+  ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
+  struct Tile3d { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0; };
+  Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11
+  int cost_impl = 2;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp
   float* wprob = nullptr;
   ConvLayer inst, nh[3], npm[2], pm1[2], pm2[2];
   float* pm2_0_wfull = nullptr;

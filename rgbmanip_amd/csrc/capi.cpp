@@ -56,6 +56,15 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views) {
   return 0;
 }
 
+int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
+  RGBM_REQUIRE(h && key, "set_option arguments");
+  const std::string k = key;
+  if (k == "max_chunk") { RGBM_REQUIRE(value > 0, "max_chunk"); h->net.max_chunk = value; }
+  else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 2, "cost_impl"); h->net.cost_impl = value; }
+  else { set_error("unknown option " + k); return -1; }
+  return 0;
+}
+
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes) {
   RGBM_REQUIRE(h && bytes && B > 0, "workspace_bytes arguments");
   *bytes = h->net.workspace_bytes(B);
@@ -181,4 +190,46 @@ int rgbm_prof_stop(double* stats) {
   RGBM_REQUIRE(stats != nullptr, "prof_stop arguments");
   return rgbm::prof_stop(stats, rgbm::kProfVariants);
 }
+}
+
+// Layer-level entry for the halo-tiled 3-D conv (tests): layer 0..6 = conv0..conv6, 7..9 = conv7/9/11 (transposed).
+extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N, int D, int H, int W, const float* w_host,
+                                const float* bn_scale_host, const float* bn_shift_host, const void* res_dev, void* out_dev,
+                                void* stream) {
+  static const int cin[10] = {32, 8, 16, 16, 32, 32, 64, 64, 32, 16};
+  static const int cout[10] = {8, 16, 16, 32, 32, 64, 64, 32, 16, 8};
+  static const int stride[10] = {1, 2, 1, 2, 1, 2, 1, 1, 1, 1};
+  RGBM_REQUIRE(layer >= 0 && layer < 10 && in_dev && w_host && bn_scale_host && bn_shift_host && out_dev, "conv3d_tile arguments");
+  const bool tr = layer >= 7;
+  const int coutp = cout[layer] < 16 ? 16 : cout[layer];
+  std::vector<float> packed;
+  conv3d_tile_pack(w_host, bn_scale_host, cin[layer], cout[layer], coutp, tr, dtype, packed);
+  void* wdev = nullptr; float* bdev = nullptr;
+  if (dtype == BF16) {
+    std::vector<unsigned short> h(packed.size());
+    for (size_t k = 0; k < packed.size(); ++k) { unsigned u; memcpy(&u, &packed[k], 4); u += 0x7fffu + ((u >> 16) & 1u); h[k] = (unsigned short)(u >> 16); }
+    RGBM_CHECK_HIP(hipMalloc(&wdev, h.size() * 2));
+    RGBM_CHECK_HIP(hipMemcpy(wdev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    RGBM_CHECK_HIP(hipMalloc(&wdev, packed.size() * 4));
+    RGBM_CHECK_HIP(hipMemcpy(wdev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<float> bpad(coutp, 0.f);
+  for (int o = 0; o < cout[layer]; ++o) bpad[o] = bn_shift_host[o];
+  if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;
+  Conv3dTileDesc d;
+  memset(&d, 0, sizeof(d));
+  d.in = in_dev; d.wgt = wdev; d.out = out_dev; d.bias = bdev; d.res = res_dev;
+  d.N = N; d.Di = D; d.Hi = H; d.Wi = W;
+  if (tr) { d.Do = 2 * D; d.Ho = 2 * H; d.Wo = 2 * W; d.Dq = D; d.Hq = H; d.Wq = W; }
+  else {
+    const int s = stride[layer];
+    d.Do = (D + 2 - 3) / s + 1; d.Ho = (H + 2 - 3) / s + 1; d.Wo = (W + 2 - 3) / s + 1;
+    d.Dq = d.Do; d.Hq = d.Ho; d.Wq = d.Wo;
+  }
+  d.Cout = cout[layer]; d.relu = 1; d.prof_variant = -1;
+  int rc = launch_conv3d_tile(layer, dtype, d, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  (void)hipFree(wdev); (void)hipFree(bdev);
+  return rc;
 }

@@ -40,8 +40,9 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == ACT_PRELU) return v > 0.f ? v : v * slope;
+  // NaN must propagate like torch.relu / prelu (a degenerate pair ends as default_bbox, never as a finite box)
+  if (act == ACT_RELU) return v < 0.f ? 0.f : v;
+  if (act == ACT_PRELU) return v < 0.f ? v * slope : v;
   if (act == ACT_TANH) return tanhf(v);
   return v;
 }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void view_linear_kernel(const float* __restric
     float acc = bias ? bias[o] : 0.f;
     const float* wr = W + (long long)o * ldw + i0;
     for (int i = 0; i < I; ++i) acc = fmaf(wr[i], xs[i], acc);
-    if (relu) acc = fmaxf(acc, 0.f);
+    if (relu) acc = acc < 0.f ? 0.f : acc;        // NaN propagates, like torch.relu
     out[(long long)v * O + o] = acc;
   }
 }

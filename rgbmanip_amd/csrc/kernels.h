@@ -1,5 +1,7 @@
 // Host-side launchers of the helper kernels (misc_kernels.hip, head_kernels.hip, postproc.hip, ppo_kernels.hip).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace rgbm {
@@ -29,6 +31,21 @@ int launch_view_linear(const float* x, const float* W, const float* bias, float*
                        int relu, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
 int launch_copy_cols(const float* in, float* out, long long rows, int ldi, int ldo, int n, hipStream_t s);
+
+// conv3d_tile.hip — halo-tiled 3-D conv for the cost-regularisation stack
+struct Conv3dTileDesc {
+  const void* in; const void* wgt; void* out; const float* bias; const void* res;
+  int N, Di, Hi, Wi;            // input tensor [N][Di][Hi][Wi][CIN]
+  int Do, Ho, Wo;               // output tensor dims
+  int Dq, Hq, Wq;               // tile-enumeration grid (= output dims; = input dims for transposed)
+  int ntd, nth, ntw;            // filled by the launcher
+  int Cout, relu;
+  const void* feat; const float* homog; const float* depths; int v0, V, B;   // fused-warp mode only
+  int prof_variant; double algo_flops, algo_bytes;
+};
+void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
+                      std::vector<float>& packed);
+int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);
 
 // postproc.hip
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,

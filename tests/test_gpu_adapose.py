@@ -49,10 +49,12 @@ def _run(net, inp, **kw):
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
-def test_fp32_intermediates_vs_oracle(inputs, oracle_taps):
-    """Bisecting aid: PSPNet stages and cost-volume stages of view 1 against the oracle (fp32)."""
+@pytest.mark.parametrize("cost_impl", [2, 1, 0])
+def test_fp32_intermediates_vs_oracle(inputs, oracle_taps, cost_impl):
+    """Bisecting aid: PSPNet stages and cost-volume stages of view 1 against the oracle (fp32), for each
+    cost-volume implementation (2 = halo-tiled + fused warp [default], 1 = halo-tiled, 0 = generic igemm)."""
     _, taps = oracle_taps
-    net = _net("fp32")
+    net = _net("fp32", cost_impl=cost_impl)
     B, V = 2, 4
     _run(net, inputs, stop_after=1)
 
@@ -77,7 +79,8 @@ def test_fp32_intermediates_vs_oracle(inputs, oracle_taps):
         x = net.fetch(B, name, V * D * H * H * C).view(V, D, H, H, C)[:B]
         return x.permute(0, 4, 1, 2, 3).cpu().numpy()
     errs = {}
-    errs["vol"] = _rel(ndhwc("vol", 32, 24, 224), taps["fused1"].numpy())
+    if cost_impl != 2:
+        errs["vol"] = _rel(ndhwc("vol", 32, 24, 224), taps["fused1"].numpy())
     errs["c0"] = _rel(ndhwc("c0", 8, 24, 224), taps["v1_c0"].numpy())
     errs["c2"] = _rel(ndhwc("c2", 16, 12, 112), taps["v1_c2"].numpy())
     errs["c4"] = _rel(ndhwc("c4", 32, 6, 56), taps["v1_c4"].numpy())
@@ -114,13 +117,14 @@ def test_fp32_batch_invariance_and_chunking():
             assert _rel(out3[k][b:b + 1], o1[k]) < 1e-5, (b, k)
 
 
-def test_bf16_close_to_golden(inputs, golden_dir):
+@pytest.mark.parametrize("cost_impl", [2, 0])
+def test_bf16_close_to_golden(inputs, golden_dir, cost_impl):
     """bf16 storage / fp32 accumulate: the throughput mode.  The bound is what 8-bit mantissas allow through a
     ~60-layer un-normalised network; the measured errors are printed and recorded in DESIGN.md."""
     g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
-    out = _run(_net("bf16"), inputs)
+    out = _run(_net("bf16", cost_impl=cost_impl), inputs)
     errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
-    print("bf16 vs reference golden:", errs)
+    print(f"bf16 (cost_impl={cost_impl}) vs reference golden:", errs)
     for k in OUT_KEYS:
         assert np.isfinite(out[k]).all(), k
     assert errs["view1_depth"] < 3e-2 and errs["view1_nocs"] < 1e-1 and errs["view1_r"] < 1.5e-1, errs

@@ -239,3 +239,59 @@ def test_postprocess_matches_golden(golden_dir):
         np.testing.assert_allclose(bbox[i], exp, rtol=1e-6, atol=1e-7, err_msg=f"case {i}")
         if not is_default:
             np.testing.assert_allclose(ts[i, 3], float(g[f"c{i}_s"]), rtol=1e-12)        # exact median element
+
+
+C3T = {0: (32, 8, 1, False), 1: (8, 16, 2, False), 2: (16, 16, 1, False), 3: (16, 32, 2, False), 4: (32, 32, 1, False),
+       5: (32, 64, 2, False), 6: (64, 64, 1, False), 7: (64, 32, 2, True), 8: (32, 16, 2, True), 9: (16, 8, 2, True)}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layer", sorted(C3T))
+def test_conv3d_tile_layers(layer, dtype):
+    """Halo-tiled 3-D conv (every CostRegNet layer shape), ragged tiles, and sample isolation."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, host_f32, TORCH_DT
+    lib = _lib.load()
+    Cin, Cout, stride, tr = C3T[layer]
+    g = torch.Generator().manual_seed(100 + layer)
+    N, D, H, W = 3, 6, 20, 12            # not multiples of the 8x8 tiles; D exercises partial depth tiles
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    x[1] = 0.0                           # a sample whose content must not influence its neighbours
+    w = (torch.randn(Cin, Cout, 3, 3, 3, generator=g) if tr else torch.randn(Cout, Cin, 3, 3, 3, generator=g)) / np.sqrt(Cin * 27)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    if dtype == _lib.BF16:
+        x = x.bfloat16().float()
+    wf = w * (scale.view(1, -1, 1, 1, 1) if tr else scale.view(-1, 1, 1, 1, 1))
+    if dtype == _lib.BF16:
+        wf = wf.bfloat16().float()
+    ref = F.conv_transpose3d(x, wf, None, 2, 1, 1) if tr else F.conv3d(x, wf, None, stride, 1)
+    ref = F.relu(ref + shift.view(1, -1, 1, 1, 1))
+    res = None
+    if tr:
+        res = torch.randn(ref.shape, generator=g)
+        if dtype == _lib.BF16:
+            res = res.bfloat16().float()
+        ref = ref + res
+    xd = to_channels_last(x, dtype)
+    rd = to_channels_last(res, dtype) if res is not None else None
+    out = torch.full(tuple(ref.permute(0, 2, 3, 4, 1).shape), float("nan"), dtype=TORCH_DT[dtype], device="cuda")
+    wa, wp = host_f32(w)
+    sa, sp = host_f32(scale)
+    ha, hp = host_f32(shift)
+    _lib.check(lib.rgbm_conv3d_tile(layer, dtype, _lib.ptr(xd), N, D, H, W, wp, sp, hp, _lib.ptr(rd), _lib.ptr(out),
+                                    _lib.stream_ptr()), "rgbm_conv3d_tile")
+    torch.cuda.synchronize()
+    y = from_channels_last(out)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < TOL[dtype], layer
+    # NaN in one sample stays in that sample (and does propagate there, like torch.relu)
+    x2 = x.clone()
+    x2[1, :, 2, 5, 5] = float("nan")
+    xd2 = to_channels_last(x2, dtype)
+    out2 = torch.zeros_like(out)
+    _lib.check(lib.rgbm_conv3d_tile(layer, dtype, _lib.ptr(xd2), N, D, H, W, wp, sp, hp, _lib.ptr(rd), _lib.ptr(out2),
+                                    _lib.stream_ptr()), "rgbm_conv3d_tile")
+    torch.cuda.synchronize()
+    y2 = from_channels_last(out2)
+    assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
+    assert torch.isnan(y2[1]).any()
