@@ -89,6 +89,38 @@ int rgbm_gae(int T, int N, const float* rewards, const uint8_t* dones, const flo
 int rgbm_adv_normalise(int64_t n_local, float* adv, const double* sums, double count_total, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * PPO policy (actor-critic MLPs obs -> h0 -> h1 -> h2 -> {act, 1}, ELU) on a flat fp32 parameter vector laid out in the
+ * reference's state_dict order (log_std, actor.{0,2,4,6}.{weight,bias}, critic.{0,2,4,6}.{weight,bias}).
+ * Replaces: ActorCritic.act / act_inference / evaluate   algo/ppo/ppo/module.py:73-107
+ *           one minibatch of PPO.update                   algo/ppo/ppo/ppo.py:472-528
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct rgbm_policy_layout {
+  int dims[5];        /* obs, h0, h1, h2, act */
+  int log_std;        /* offsets (in floats) into the flat parameter vector */
+  int w[2][4];        /* [net: 0 actor, 1 critic][layer] weight offsets, row-major [out][in] */
+  int b[2][4];
+  int total;          /* number of parameters */
+} rgbm_policy_layout;
+/* mode 0: act (actions = mu + exp(2*log_std)*noise, log-prob, value, mu); 1: act_inference (mu only);
+ * 2: evaluate (log-prob of the given actions, value, mu).  obs [n,dims[0]], noise/actions/mu [n,dims[4]], logp/value [n]. */
+int rgbm_policy_forward(const float* params, const rgbm_policy_layout* L, int n, int mode, const float* obs, const float* noise,
+                        float* actions, float* logp, float* value, float* mu, void* stream);
+/* scratch floats needed by rgbm_ppo_minibatch_fwd_bwd for n rows */
+int rgbm_ppo_partial_floats(const rgbm_policy_layout* L, int n, size_t* count);
+/* forward + clipped-surrogate / clipped-value / entropy loss + backward for one minibatch of n rows.
+ * grads_flat [total+4]: d loss / d params (mean over the n rows), then {sum surrogate, sum value loss, sum KL, rows}.
+ * With several ranks: all-reduce(sum) grads_flat, then call rgbm_ppo_clip_adam with inv_world = 1/world. */
+int rgbm_ppo_minibatch_fwd_bwd(const float* params, const rgbm_policy_layout* L, int n, const float* obs, const float* actions,
+                               const float* old_logp, const float* adv, const float* returns, const float* old_values,
+                               const float* old_mu, const float* old_log_std, float clip, float vcoef, float ecoef,
+                               float* partial_scratch, float* grads_flat, void* stream);
+/* clip_grad_norm_(max_norm) + KL-adaptive learning rate (ppo.py:486-495) + Adam(0.9,0.999,1e-8) in one launch.
+ * opt_state: 48-byte device record {int t, n_updates; float lr, last_kl, last_norm, pad; double sum_surr, sum_vloss}. */
+int rgbm_ppo_clip_adam(float* params, const float* grads_flat, float* exp_avg, float* exp_avg_sq, void* opt_state,
+                       const rgbm_policy_layout* L, float inv_world, float max_norm, float desired_kl, float lr_min,
+                       float lr_max, int adaptive, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Layer-level entry points (used by the parity tests and by the Python host for pieces it drives itself).
  * ---------------------------------------------------------------------------------------------------------- */
 /* Generic N-D convolution on channels-last tensors, weights given in PyTorch layout on the host
@@ -126,6 +158,8 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * bracketed by HIP events recorded on its own stream.  stats: host double[10*4]; rows 0..7 = dtype*4 + {0:16,1:32,2:64,
  * 3:128}-channel tile instantiation of conv_igemm_kernel, rows 8/9 = conv3d_tile_kernel f32/bf16; columns {launches, total ms, algorithmic FLOPs,
  * algorithmic bytes}.  stop synchronises on the recorded events. */
+/* ablation switches for kernel benchmarking only (0 = normal operation) */
+int rgbm_debug_flags(int flags);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);
 

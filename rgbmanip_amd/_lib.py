@@ -24,6 +24,10 @@ class WeightDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.POINTER(C.c_int64))]
 
 
+class PolicyLayout(C.Structure):
+    _fields_ = [("dims", C.c_int * 5), ("log_std", C.c_int), ("w", (C.c_int * 4) * 2), ("b", (C.c_int * 4) * 2), ("total", C.c_int)]
+
+
 class AdaposeOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("view1_nocs", "view2_nocs", "view1_depth", "view2_depth", "view1_r", "view2_r",
                                            "view1_t", "view2_t", "view1_s", "view2_s")]
@@ -46,6 +50,10 @@ SIGNATURES = {
     "rgbm_adapose_postprocess": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_gae": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "rgbm_adv_normalise": (_i, [_i64, _vp, _vp, _d, _vp]),
+    "rgbm_policy_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_ppo_partial_floats": (_i, [_vp, _i, C.POINTER(_sz)]),
+    "rgbm_ppo_minibatch_fwd_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "rgbm_ppo_clip_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp]),
     "rgbm_conv_nd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                           _vp, _i, _i, _f, _vp, _vp]),
     "rgbm_conv3d_tile": (_i, [_i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -53,6 +61,7 @@ SIGNATURES = {
     "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_build_volume": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbm_debug_flags": (_i, [_i]),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),
 }

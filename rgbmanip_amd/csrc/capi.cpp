@@ -233,3 +233,40 @@ extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N,
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;
 }
+
+extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; return 0; }
+
+// ---- PPO policy -------------------------------------------------------------------------------------------------
+static_assert(sizeof(rgbm_policy_layout) == sizeof(rgbm::PolicyLayout), "policy layout ABI mismatch");
+static_assert(sizeof(rgbm::PolicyOptState) == 40 || sizeof(rgbm::PolicyOptState) == 48, "opt state size");
+extern "C" {
+int rgbm_policy_forward(const float* params, const rgbm_policy_layout* L, int n, int mode, const float* obs, const float* noise,
+                        float* actions, float* logp, float* value, float* mu, void* stream) {
+  RGBM_REQUIRE(params && L && obs && mu, "policy_forward arguments");
+  RGBM_REQUIRE(mode == 1 || (logp && value && actions), "policy_forward outputs");
+  RGBM_REQUIRE(mode != 0 || noise, "policy_forward: act needs noise");
+  return launch_policy_forward(params, *reinterpret_cast<const PolicyLayout*>(L), n, mode, obs, noise, actions, logp, value, mu,
+                               (hipStream_t)stream);
+}
+int rgbm_ppo_partial_floats(const rgbm_policy_layout* L, int n, size_t* count) {
+  RGBM_REQUIRE(L && count && n > 0, "ppo_partial_floats arguments");
+  *count = (size_t)policy_partial_floats(*reinterpret_cast<const PolicyLayout*>(L), n);
+  return 0;
+}
+int rgbm_ppo_minibatch_fwd_bwd(const float* params, const rgbm_policy_layout* L, int n, const float* obs, const float* actions,
+                               const float* old_logp, const float* adv, const float* returns, const float* old_values,
+                               const float* old_mu, const float* old_log_std, float clip, float vcoef, float ecoef,
+                               float* partial_scratch, float* grads_flat, void* stream) {
+  RGBM_REQUIRE(params && L && obs && actions && old_logp && adv && returns && old_values && old_mu && old_log_std &&
+               partial_scratch && grads_flat, "ppo_minibatch arguments");
+  return launch_ppo_minibatch(params, *reinterpret_cast<const PolicyLayout*>(L), n, obs, actions, old_logp, adv, returns,
+                              old_values, old_mu, old_log_std, clip, vcoef, ecoef, partial_scratch, grads_flat, (hipStream_t)stream);
+}
+int rgbm_ppo_clip_adam(float* params, const float* grads_flat, float* exp_avg, float* exp_avg_sq, void* opt_state,
+                       const rgbm_policy_layout* L, float inv_world, float max_norm, float desired_kl, float lr_min,
+                       float lr_max, int adaptive, void* stream) {
+  RGBM_REQUIRE(params && grads_flat && exp_avg && exp_avg_sq && opt_state && L, "ppo_clip_adam arguments");
+  return launch_ppo_adam(params, grads_flat, exp_avg, exp_avg_sq, reinterpret_cast<PolicyOptState*>(opt_state), L->total,
+                         inv_world, max_norm, desired_kl, lr_min, lr_max, adaptive, (hipStream_t)stream);
+}
+}

@@ -49,6 +49,14 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return (unsigned short)(u >> 16);
 }
 
+// two floats -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN kept)
+typedef float rgbm_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rgbm_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  rgbm_f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rgbm_b2));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kPerChunk = 4;  // elements per 16 bytes
@@ -76,8 +84,8 @@ __device__ __forceinline__ void store4(float* p, const float v[4]) {
 }
 __device__ __forceinline__ void store4(unsigned short* p, const float v[4]) {
   uint2 t;
-  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  t.x = pack2_bf16(v[0], v[1]);
+  t.y = pack2_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 // unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
@@ -95,10 +103,10 @@ __device__ __forceinline__ uint4 pack_chunk(const float* v, float /*tag*/) {
 }
 __device__ __forceinline__ uint4 pack_chunk(const float* v, unsigned short /*tag*/) {
   uint4 c;
-  c.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-  c.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-  c.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-  c.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+  c.x = pack2_bf16(v[0], v[1]);
+  c.y = pack2_bf16(v[2], v[3]);
+  c.z = pack2_bf16(v[4], v[5]);
+  c.w = pack2_bf16(v[6], v[7]);
   return c;
 }
 

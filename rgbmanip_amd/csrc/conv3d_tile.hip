@@ -9,9 +9,10 @@
 // Why not the generic implicit GEMM: with 8..64 channels an im2col-style gather re-reads every input voxel
 // 27 times from L2 for a handful of MFMAs (measured 62 TFLOP/s).  Here a workgroup stages the input halo of
 // its output tile ONCE into LDS (one 16-byte-padded row per voxel, conflict-free for ds_read_b128), then each
-// wave walks the taps: B operand (16 voxels x 32 k) straight out of the halo with a per-tap offset, A operand
-// (16 output channels x 32 k, BN folded, pre-swizzled per lane on the host) from L1/L2, MFMA 16x16x32 bf16
-// (or 16x16x4 f32) accumulating in registers.  Transposed convs run their 8 sub-pixel classes off one halo.
+// wave walks the taps fully unrolled: B operand (16 voxels x 32 k) straight out of the halo at a compile-time
+// offset, A operand (16 output channels x 32 k, BN folded, pre-swizzled per lane on the host) from L1/L2,
+// MFMA 16x16x32 bf16 (or 16x16x4 f32) accumulating in registers.  Transposed convs run their 8 sub-pixel
+// classes off one halo.  All loads of the staging phase are issued in batches so that many are in flight.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -48,8 +49,16 @@ struct C3Cfg {
   static constexpr int FM = COUTP / 16;
   static constexpr int SPT = BPT >= 64 ? BPT / 64 : 1; // MFMA steps per tap
   static constexpr int TPS = BPT >= 64 ? 1 : 64 / BPT; // taps per MFMA step
+  static constexpr int GPT = 4 / TPS;                  // lane groups per tap inside one step
   static_assert(NV % 64 == 0, "tile must hold a multiple of 64 voxels");
   static_assert(BPT % 16 == 0, "voxel must be a multiple of 16 bytes");
+  // pass p of a transposed conv = sub-pixel class (pd,ph,pw) with (1+pd)(1+ph)(1+pw) taps; a plain conv has one 27-tap pass
+  static constexpr int kd_of(int p) { return TR ? 1 + ((p >> 2) & 1) : 3; }
+  static constexpr int kh_of(int p) { return TR ? 1 + ((p >> 1) & 1) : 3; }
+  static constexpr int kw_of(int p) { return TR ? 1 + (p & 1) : 3; }
+  static constexpr int taps_of(int p) { return kd_of(p) * kh_of(p) * kw_of(p); }
+  static constexpr int steps_of(int p) { return (taps_of(p) + TPS - 1) / TPS * SPT; }
+  static constexpr int step0_of(int p) { int s = 0; for (int q = 0; q < p; ++q) s += steps_of(q); return s; }
 };
 
 __device__ __forceinline__ void warp_ixy(const float* __restrict__ hm, float x, float y, float depth, int H, int W, float& ix,
@@ -65,16 +74,17 @@ __device__ __forceinline__ void warp_ixy(const float* __restrict__ hm, float x, 
   iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
 }
 
+int g_debug_flags = 0;
+
+template <int N> struct IC { static constexpr int value = N; };
+
 template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP>
-__global__ __launch_bounds__(256) void conv3d_tile_kernel(const Conv3dTileDesc d) {
+__global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDesc d) {
   using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR>;
-  constexpr int VS = Cfg::VS, CPV = Cfg::CPV, HD = Cfg::HD, HH = Cfg::HH, HW = Cfg::HW, NVH = Cfg::NVH;
-  constexpr int NF = Cfg::NF, FM = Cfg::FM, SPT = Cfg::SPT, TPS = Cfg::TPS, E = Cfg::E;
-  constexpr int NPASS = TR ? 8 : 1;
-  constexpr int MAXSTEPS = TR ? (27 * SPT + 8) : ((27 + TPS - 1) / TPS * SPT);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* stepoff = reinterpret_cast<int*>(smem);                       // [MAXSTEPS][4] byte offsets into the halo
-  unsigned char* halo = smem + ((MAXSTEPS * 16 + 15) / 16) * 16;
+  constexpr int VS = Cfg::VS, CPV = Cfg::CPV, HH = Cfg::HH, HW = Cfg::HW, NVH = Cfg::NVH;
+  constexpr int NF = Cfg::NF, FM = Cfg::FM, SPT = Cfg::SPT, TPS = Cfg::TPS, GPT = Cfg::GPT, E = Cfg::E;
+  constexpr int ZERO_OFF = NVH * VS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char halo[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -88,150 +98,167 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(const Conv3dTileDesc d
   const int q0d = td * TD, q0h = th * TH, q0w = tw * TW;
   const int i0d = TR ? q0d : q0d * STRIDE - 1, i0h = TR ? q0h : q0h * STRIDE - 1, i0w = TR ? q0w : q0w * STRIDE - 1;
 
-  // ---- per-(step, lane-group) halo byte offsets; padded taps point at the zero voxel ----
-  for (int i = tid; i < MAXSTEPS * 4; i += 256) {
-    const int s = i >> 2, g = i & 3;
-    int off = -1;                                                    // padded tap: read the zero voxel (absolute)
-    if (!TR) {
-      const int tap = SPT > 1 ? s / SPT : s * TPS + g / (4 / TPS);
-      const int chunk = SPT > 1 ? (s % SPT) * 4 + g : g % (4 / TPS);
-      if (tap < 27) { const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3; off = ((kd * HH + kh) * HW + kw) * VS + chunk * 16; }
-    } else {
-      // passes (classes) are concatenated; class c = (pd,ph,pw) has (1+pd)(1+ph)(1+pw) taps
-      int rem = s, cls = 0, nst = 0;
-      for (cls = 0; cls < 8; ++cls) {
-        const int nt = (1 + ((cls >> 2) & 1)) * (1 + ((cls >> 1) & 1)) * (1 + (cls & 1));
-        nst = (nt + TPS - 1) / TPS * SPT;
-        if (rem < nst) break;
-        rem -= nst;
-      }
-      if (cls < 8) {
-        const int KH = 1 + ((cls >> 1) & 1), KW = 1 + (cls & 1);
-        const int nt = (1 + ((cls >> 2) & 1)) * KH * KW;
-        const int tap = SPT > 1 ? rem / SPT : rem * TPS + g / (4 / TPS);
-        const int chunk = SPT > 1 ? (rem % SPT) * 4 + g : g % (4 / TPS);
-        if (tap < nt) { const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW; off = ((kd * HH + kh) * HW + kw) * VS + chunk * 16; }
-      }
-    }
-    stepoff[i] = off;
-  }
-  if (tid < VS / 16) reinterpret_cast<uint4*>(halo + NVH * VS)[tid] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < VS / 16) reinterpret_cast<uint4*>(halo + ZERO_OFF)[tid] = make_uint4(0u, 0u, 0u, 0u);
 
-  // ---- stage the input halo ----
-  {
+  // ---- stage the input halo (all global loads of a batch are issued before the first LDS write) ----
+  if (d.dbg & 1) {
+    for (int i = tid; i < NVH * CPV; i += 256) reinterpret_cast<uint4*>(halo)[i] = make_uint4(0u, 0u, 0u, 0u);
+  } else if constexpr (!WARP) {
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
     constexpr int TOTAL = NVH * CPV;
-    for (int idx = tid; idx < TOTAL; idx += 256) {
-      const int vox = idx / CPV, chunk = idx - vox * CPV;
-      const int hw = vox % HW, hh = (vox / HW) % HH, hd = vox / (HW * HH);
-      const int gd = i0d + hd, gh = i0h + hh, gw = i0w + hw;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)gd < (unsigned)d.Di && (unsigned)gh < (unsigned)d.Hi && (unsigned)gw < (unsigned)d.Wi) {
-        if (!WARP) {
-          v = *reinterpret_cast<const uint4*>(in + ((((long long)n * d.Di + gd) * d.Hi + gh) * d.Wi + gw) * CIN + chunk * E);
-        } else {
-          // fused plane-sweep volume: feat[v] + bilinear(feat[partner], homography(v, depth gd, pixel (gw, gh)))
-          const int vv = d.v0 + n, partner = (vv + d.B) % d.V, b = vv % d.B;
-          const T* __restrict__ feat = reinterpret_cast<const T*>(d.feat);
-          float ix, iy;
-          warp_ixy(d.homog + (long long)vv * 12, (float)gw, (float)gh, d.depths[b * d.Di + gd], d.Hi, d.Wi, ix, iy);
-          float r[E], acc[E], s[E];
-          unpack_chunk(*reinterpret_cast<const uint4*>(feat + (((long long)vv * d.Hi + gh) * d.Wi + gw) * CIN + chunk * E), r, T());
-          if (!(isfinite(ix) && isfinite(iy))) {
+    constexpr int ITERS = (TOTAL + 255) / 256;
+    constexpr int BATCH = 8;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      uint4 v[BATCH];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = __builtin_nanf("");
-          } else {
-            ix = fminf(fmaxf(ix, -4.f), 1.0e6f);
-            iy = fminf(fmaxf(iy, -4.f), 1.0e6f);
-            const float fx = floorf(ix), fy = floorf(iy);
-            const int x0 = (int)fx, y0 = (int)fy;
-            const float tx = ix - fx, ty = iy - fy;
-            const T* src = feat + (long long)partner * d.Hi * d.Wi * CIN + chunk * E;
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = 0.f;
-            const bool xin0 = (unsigned)x0 < (unsigned)d.Wi, xin1 = (unsigned)(x0 + 1) < (unsigned)d.Wi;
-            const bool yin0 = (unsigned)y0 < (unsigned)d.Hi, yin1 = (unsigned)(y0 + 1) < (unsigned)d.Hi;
-            if (xin0 && yin0) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)y0 * d.Wi + x0) * CIN), s, T());
-              const float w = (1.f - tx) * (1.f - ty);
-#pragma unroll
-              for (int e = 0; e < E; ++e) acc[e] += s[e] * w; }
-            if (xin1 && yin0) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)y0 * d.Wi + x0 + 1) * CIN), s, T());
-              const float w = tx * (1.f - ty);
-#pragma unroll
-              for (int e = 0; e < E; ++e) acc[e] += s[e] * w; }
-            if (xin0 && yin1) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)(y0 + 1) * d.Wi + x0) * CIN), s, T());
-              const float w = (1.f - tx) * ty;
-#pragma unroll
-              for (int e = 0; e < E; ++e) acc[e] += s[e] * w; }
-            if (xin1 && yin1) { unpack_chunk(*reinterpret_cast<const uint4*>(src + ((long long)(y0 + 1) * d.Wi + x0 + 1) * CIN), s, T());
-              const float w = tx * ty;
-#pragma unroll
-              for (int e = 0; e < E; ++e) acc[e] += s[e] * w; }
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = r[e] + acc[e];
-          }
-          v = pack_chunk(acc, T());
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = tid + (it0 + u) * 256;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int vox = idx / CPV, chunk = idx - vox * CPV;
+          const int hw = vox % HW, hh = (vox / HW) % HH, hd = vox / (HW * HH);
+          const int gd = i0d + hd, gh = i0h + hh, gw = i0w + hw;
+          if ((unsigned)gd < (unsigned)d.Di && (unsigned)gh < (unsigned)d.Hi && (unsigned)gw < (unsigned)d.Wi)
+            v[u] = *reinterpret_cast<const uint4*>(in + ((((long long)n * d.Di + gd) * d.Hi + gh) * d.Wi + gw) * CIN + chunk * E);
         }
       }
-      *reinterpret_cast<uint4*>(halo + vox * VS + chunk * 16) = v;
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = tid + (it0 + u) * 256;
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int vox = idx / CPV, chunk = idx - vox * CPV;
+          *reinterpret_cast<uint4*>(halo + vox * VS + chunk * 16) = v[u];
+        }
+      }
+    }
+  } else {
+    // fused plane-sweep volume: voxel = feat[v] + bilinear(feat[partner], homography(v, depth, pixel)); one task per
+    // halo voxel, 4 chunks at a time: 4 reference + 16 corner loads in flight per lane.
+    const T* __restrict__ feat = reinterpret_cast<const T*>(d.feat);
+    const int vv = d.v0 + n, partner = (vv + d.B) % d.V, bb = vv % d.B;
+    const float* hm = d.homog + (long long)vv * 12;
+    const T* refb = feat + (long long)vv * d.Hi * d.Wi * CIN;
+    const T* srcb = feat + (long long)partner * d.Hi * d.Wi * CIN;
+    constexpr int ITERS = (NVH + 255) / 256;
+    constexpr int CG = CPV < 4 ? CPV : 4;
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+      const int vox = tid + it * 256;
+      if (vox >= NVH) break;
+      const int hw = vox % HW, hh = (vox / HW) % HH, hd = vox / (HW * HH);
+      const int gd = i0d + hd, gh = i0h + hh, gw = i0w + hw;
+      const bool inb = (unsigned)gd < (unsigned)d.Di && (unsigned)gh < (unsigned)d.Hi && (unsigned)gw < (unsigned)d.Wi;
+      unsigned char* dst = halo + vox * VS;
+      if (!inb) {
+#pragma unroll
+        for (int c = 0; c < CPV; ++c) *reinterpret_cast<uint4*>(dst + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      float ix, iy;
+      warp_ixy(hm, (float)gw, (float)gh, d.depths[bb * d.Di + gd], d.Hi, d.Wi, ix, iy);
+      const bool fin = isfinite(ix) && isfinite(iy);
+      ix = fin ? fminf(fmaxf(ix, -4.f), 1.0e6f) : 0.f;
+      iy = fin ? fminf(fmaxf(iy, -4.f), 1.0e6f) : 0.f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = (unsigned)x0 < (unsigned)d.Wi, xin1 = (unsigned)(x0 + 1) < (unsigned)d.Wi;
+      const bool yin0 = (unsigned)y0 < (unsigned)d.Hi, yin1 = (unsigned)(y0 + 1) < (unsigned)d.Hi;
+      const int xc0 = min(max(x0, 0), d.Wi - 1), xc1 = min(max(x0 + 1, 0), d.Wi - 1);
+      const int yc0 = min(max(y0, 0), d.Hi - 1), yc1 = min(max(y0 + 1, 0), d.Hi - 1);
+      const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+      const bool m00 = xin0 && yin0, m01 = xin1 && yin0, m10 = xin0 && yin1, m11 = xin1 && yin1;
+      const T* p00 = srcb + ((long long)yc0 * d.Wi + xc0) * CIN;
+      const T* p01 = srcb + ((long long)yc0 * d.Wi + xc1) * CIN;
+      const T* p10 = srcb + ((long long)yc1 * d.Wi + xc0) * CIN;
+      const T* p11 = srcb + ((long long)yc1 * d.Wi + xc1) * CIN;
+      const T* pr = refb + ((long long)gh * d.Wi + gw) * CIN;
+#pragma unroll
+      for (int c0 = 0; c0 < CPV; c0 += CG) {
+        uint4 r[CG], a[CG], b[CG], c[CG], e[CG];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+          r[k] = *reinterpret_cast<const uint4*>(pr + (c0 + k) * E);
+          a[k] = *reinterpret_cast<const uint4*>(p00 + (c0 + k) * E);
+          b[k] = *reinterpret_cast<const uint4*>(p01 + (c0 + k) * E);
+          c[k] = *reinterpret_cast<const uint4*>(p10 + (c0 + k) * E);
+          e[k] = *reinterpret_cast<const uint4*>(p11 + (c0 + k) * E);
+        }
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          float fr[E], fa[E], fb[E], fc[E], fe[E], o[E];
+          unpack_chunk(r[k], fr, T());
+          unpack_chunk(m00 ? a[k] : z, fa, T());       // zeros padding: an outside corner contributes exactly 0
+          unpack_chunk(m01 ? b[k] : z, fb, T());
+          unpack_chunk(m10 ? c[k] : z, fc, T());
+          unpack_chunk(m11 ? e[k] : z, fe, T());
+#pragma unroll
+          for (int q = 0; q < E; ++q) {
+            const float wsum = ((fa[q] * w00 + fb[q] * w01) + fc[q] * w10) + fe[q] * w11;
+            o[q] = fin ? fr[q] + wsum : __builtin_nanf("");
+          }
+          *reinterpret_cast<uint4*>(dst + (c0 + k) * 16) = pack_chunk(o, T());
+        }
+      }
     }
   }
   __syncthreads();
 
-  // ---- per-lane fragment bases: voxel (lane&15) of fragment f, tap (0,0,0) ----
+  // ---- per-lane fragment bases: voxel (lane&15) of fragment f at tap (0,0,0) ----
   int base[NF];
   int qd_[NF], qh_[NF], qw_[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int vt = (wave * NF + f) * 16 + lr;          // voxel index inside the tile, w fastest
     const int w_ = vt % TW, h_ = (vt / TW) % TH, d_ = vt / (TW * TH);
-    base[f] = ((d_ * STRIDE * HH + h_ * STRIDE) * HW + w_ * STRIDE) * VS;
+    base[f] = ((d_ * STRIDE * HH + h_ * STRIDE) * HW + w_ * STRIDE) * VS + (TPS == 1 ? lg * 16 : 0);
     qd_[f] = q0d + d_; qh_[f] = q0h + h_; qw_[f] = q0w + w_;
   }
 
-  const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(d.wgt);
+  const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(d.wgt) + lr * 64 + lg * 16;
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
-  int step0 = 0;
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-    int nsteps;
-    if (!TR) nsteps = (27 + TPS - 1) / TPS * SPT;
-    else nsteps = ((1 + ((pass >> 2) & 1)) * (1 + ((pass >> 1) & 1)) * (1 + (pass & 1)) + TPS - 1) / TPS * SPT;
+
+  auto run_pass = [&](auto pc) {
+    constexpr int PASS = decltype(pc)::value;
+    constexpr int KH = Cfg::kh_of(PASS), KW = Cfg::kw_of(PASS);
+    constexpr int NT = Cfg::taps_of(PASS), NS = Cfg::steps_of(PASS), S0 = Cfg::step0_of(PASS);
     f32x4 acc[FM][NF];
 #pragma unroll
     for (int a = 0; a < FM; ++a)
 #pragma unroll
       for (int f = 0; f < NF; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // A fragments: [step][COUTP rows][64 bytes]; lane reads row (fm*16+lr), 16-byte chunk lg
-    const unsigned char* wp = wg + ((long long)step0 * COUTP + lr) * 64 + lg * 16;
-    uint4 an[FM];
+    if (!(d.dbg & 2))
 #pragma unroll
-    for (int a = 0; a < FM; ++a) an[a] = *reinterpret_cast<const uint4*>(wp + a * 16 * 64);
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-      uint4 ac[FM];
-#pragma unroll
-      for (int a = 0; a < FM; ++a) ac[a] = an[a];
-      if (s + 1 < nsteps) {
-        const unsigned char* wq = wp + (long long)(s + 1) * COUTP * 64;
-#pragma unroll
-        for (int a = 0; a < FM; ++a) an[a] = *reinterpret_cast<const uint4*>(wq + a * 16 * 64);
+    for (int s = 0; s < NS; ++s) {
+      // halo byte offset of this step's tap for this lane; compile-time when one tap spans the whole step
+      int so;
+      bool pad = false;
+      if constexpr (TPS == 1) {
+        const int tap = s / SPT;
+        so = (((tap / (KH * KW)) * HH + (tap / KW) % KH) * HW + tap % KW) * VS + (s % SPT) * 64;
+      } else {
+        const int tap = s * TPS + lg / GPT;
+        pad = tap >= NT;
+        so = (((tap / (KH * KW)) * HH + (tap / KW) % KH) * HW + tap % KW) * VS + (lg % GPT) * 16;
       }
-      const int so = stepoff[(step0 + s) * 4 + lg];
+      uint4 af[FM];
+#pragma unroll
+      for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        // padded taps (so < 0) must hit the zero voxel itself, not zero-voxel + pixel offset: their weights are 0,
-        // but 0 * (stale NaN bytes beyond the halo) would still poison the accumulator
-        const uint4 b = *reinterpret_cast<const uint4*>(halo + (so < 0 ? NVH * VS : base[f] + so));
+        // a padded tap must read the zero voxel itself: its weights are 0, but 0 * stale NaN bytes would poison acc
+        const bool maybe_pad = (TPS > 1) && ((s + 1) * TPS > NT);
+        const int addr = (maybe_pad && pad) ? ZERO_OFF : base[f] + so;
+        const uint4 b = *reinterpret_cast<const uint4*>(halo + addr);
 #pragma unroll
-        for (int a = 0; a < FM; ++a) Mma3<T>::run(ac[a], b, acc[a][f]);
+        for (int a = 0; a < FM; ++a) Mma3<T>::run(af[a], b, acc[a][f]);
       }
     }
-    step0 += nsteps;
-
     // ---- epilogue: bias (folded BN), ReLU, post-activation skip add, 4-channel vector store ----
-    const int pd = TR ? (pass >> 2) & 1 : 0, ph = TR ? (pass >> 1) & 1 : 0, pw = TR ? pass & 1 : 0;
+    constexpr int pd = TR ? (PASS >> 2) & 1 : 0, ph = TR ? (PASS >> 1) & 1 : 0, pw = TR ? PASS & 1 : 0;
     constexpr int OS = TR ? 2 : 1;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(const Conv3dTileDesc d
           if (d.relu) v[e] = v[e] < 0.f ? 0.f : v[e];      // NaN propagates, like torch.relu
         }
         const long long o = opix * d.Cout + ch;
-        if (d.res) {
+        if (res) {
           float rv[4];
           load4(res + o, rv);
 #pragma unroll
@@ -257,6 +284,11 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(const Conv3dTileDesc d
         store4(out + o, v);
       }
     }
+  };
+  run_pass(IC<0>{});
+  if constexpr (TR) {
+    run_pass(IC<1>{}); run_pass(IC<2>{}); run_pass(IC<3>{});
+    run_pass(IC<4>{}); run_pass(IC<5>{}); run_pass(IC<6>{}); run_pass(IC<7>{});
   }
 }
 
@@ -313,8 +345,7 @@ void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int
 template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP>
 static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
   using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR>;
-  constexpr int NPASSSTEPS = TR ? (27 * Cfg::SPT + 8) : ((27 + Cfg::TPS - 1) / Cfg::TPS * Cfg::SPT);
-  constexpr size_t LDS = ((NPASSSTEPS * 16 + 15) / 16) * 16 + Cfg::LDS_BYTES;
+  constexpr size_t LDS = Cfg::LDS_BYTES;
   static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
   d.ntd = (d.Dq + TD - 1) / TD; d.nth = (d.Hq + TH - 1) / TH; d.ntw = (d.Wq + TW - 1) / TW;
   const long long nblk = (long long)d.N * d.ntd * d.nth * d.ntw;
@@ -325,6 +356,7 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
     RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_done = true;
   }
+  d.dbg = g_debug_flags;
   prof_begin_launch(s, d.prof_variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, s, d);
   prof_end_launch(s);
@@ -341,7 +373,7 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
   switch (layer) {
     //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp
     C3_CASE(0, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, false)
-    C3_CASE(10, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, true)
+    C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true)
     C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false)
     C3_CASE(2, 16, 16, 4, 8, 8, 4, 8, 8, 1, false, false)
     C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false)

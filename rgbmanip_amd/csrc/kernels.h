@@ -42,7 +42,9 @@ struct Conv3dTileDesc {
   int Cout, relu;
   const void* feat; const float* homog; const float* depths; int v0, V, B;   // fused-warp mode only
   int prof_variant; double algo_flops, algo_bytes;
+  int dbg;                      // ablation bits (benchmark only): 1 = skip halo staging work, 2 = skip the MFMA phase
 };
+extern int g_debug_flags;
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed);
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);
@@ -55,5 +57,18 @@ int launch_postprocess(const float* nocs, const float* depth, const float* rot, 
 int launch_gae(int T, int N, const float* rewards, const unsigned char* dones, const float* values, const float* last_values,
                float gamma, float lam, float* returns, float* adv, double* sums, hipStream_t s);
 int launch_adv_normalise(long long n_local, float* adv, const double* sums, double count_total, hipStream_t s);
+
+// policy_kernels.hip — PPO actor-critic (flat fp32 parameter vector in the reference's state_dict order)
+struct PolicyLayout { int dims[5]; int log_std; int w[2][4]; int b[2][4]; int total; };   // net 0 = actor, 1 = critic
+struct PolicyOptState { int t; int n_updates; float lr; float last_kl; float last_norm; float pad_; double sum_surr; double sum_vloss; };
+int launch_policy_forward(const float* params, const PolicyLayout& L, int n, int mode, const float* obs, const float* noise,
+                          float* actions, float* logp, float* value, float* mu, hipStream_t s);
+int policy_partial_floats(const PolicyLayout& L, int n);
+int launch_ppo_minibatch(const float* params, const PolicyLayout& L, int n, const float* obs, const float* actions,
+                         const float* old_logp, const float* adv, const float* returns, const float* old_values,
+                         const float* old_mu, const float* old_sigma, float clip, float vcoef, float ecoef, float* partial,
+                         float* grads, hipStream_t s);
+int launch_ppo_adam(float* params, const float* grads, float* m, float* v, PolicyOptState* st, int total, float inv_world,
+                    float max_norm, float desired_kl, float lr_min, float lr_max, int adaptive, hipStream_t s);
 
 }  // namespace rgbm

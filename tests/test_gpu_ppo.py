@@ -1,0 +1,137 @@
+"""-m gpu: PPO policy kernels and classes against the oracle / the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rgbmanip_amd import synth  # noqa: E402
+from rgbmanip_amd.spaces import Box  # noqa: E402
+
+CFG = {"learn": dict(exp_name="PPO", reset=True, num_transitions_per_env=16, num_transitions_eval=512, num_learning_epochs=8,
+                     num_mini_batches=4, clip_range=0.2, gamma=0.98, lam=0.98, init_noise_std=0.6, value_loss_coef=1.0,
+                     entropy_coef=0.0, learning_rate=0.00001, max_grad_norm=1.0, use_clipped_value_loss=True,
+                     schedule="adaptive", desired_kl=0.016, max_lr=0.005, min_lr=0.0002, device="cuda", sampler="sequential",
+                     log_dir="/tmp/rgbm_logs", save_dir="/tmp/rgbm_saves", testing=False, eval_interval=64, eval_round=16,
+                     eval=False, print_log=False, contrastive=False, contrastive_m=0.99, asymmetric=False),
+       "policy": dict(actor_critic_class="ActorCritic", pi_hid_sizes=[96, 96, 32], vf_hid_sizes=[96, 96, 32], activation="elu"),
+       "load": ""}
+
+
+class FakeEnv:
+    def __init__(self, n):
+        self.num_envs = n
+        self.observation_space = Box(-1.5, 1.5, (60,))
+        self.state_space = Box(-1.5, 1.5, (75,))
+        self.action_space = Box(-1.5, 1.5, (12,))
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def _ppo(N):
+    from rgbmanip_amd.ppo import PPO
+    ppo = PPO(FakeEnv(N), CFG)
+    ppo.actor_critic.load_state_dict({k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()})
+    return ppo
+
+
+def test_act_evaluate_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ppo.npz"))
+    ppo = _ppo(32)
+    roll = synth.ppo_rollout(16, 32, seed=0)
+    obs = torch.from_numpy(roll["observations"][0]).cuda()
+    a, logp, v, mu, sig = ppo.actor_critic.act(obs, None, noise=torch.from_numpy(g["n32_act_eps"]))
+    torch.cuda.synchronize()
+    assert _rel(a.cpu(), g["n32_act_a"]) < 1e-5 and _rel(logp.cpu(), g["n32_act_logp"]) < 1e-5
+    assert _rel(v.cpu(), g["n32_act_v"]) < 1e-5 and _rel(mu.cpu(), g["n32_act_mu"]) < 1e-5
+    assert sig.shape == (32, 12)
+    lp, ent, vv, _, _, _ = ppo.actor_critic.evaluate(obs, None, torch.from_numpy(roll["actions"][0]).cuda())
+    assert _rel(lp.cpu(), g["n32_eval_logp"]) < 1e-5 and _rel(ent.cpu(), g["n32_eval_ent"]) < 1e-5
+    assert _rel(vv.cpu(), g["n32_eval_v"]) < 1e-5
+    # the "next-view" slice of the mean action: argmax must be identical (north_star's bit-exact gate)
+    inf = ppo.actor_critic.act_inference(obs).cpu().numpy()
+    assert np.array_equal(inf[:, 6:11].argmax(1), g["n32_act_mu"][:, 6:11].argmax(1))
+
+
+@pytest.mark.parametrize("N", [32, 512])
+def test_update_matches_reference_golden(golden_dir, N):
+    """Recorded rollout -> compute_returns -> 32 optimiser steps: losses, LR trajectory end point, parameters."""
+    g = np.load(os.path.join(golden_dir, "ppo.npz"))
+    T = 16
+    ppo = _ppo(N)
+    roll = synth.ppo_rollout(T, N, seed=0)
+    tr = {k: torch.from_numpy(v).cuda() for k, v in roll.items()}
+    ac = ppo.actor_critic
+    for t in range(T):      # same storage fill as tools/make_goldens.py::gen_ppo
+        lp, _, _, mm, ss, _ = ac.evaluate(tr["observations"][t], None, tr["actions"][t])
+        mm = mm + 0.02 * torch.sin(torch.arange(12.0)).cuda()[None]
+        ppo.storage.add_transitions(tr["observations"][t], tr["states"][t], tr["actions"][t], tr["rewards"][t].view(-1),
+                                    tr["dones"][t].view(-1), tr["values"][t], lp - 0.01, mm, ss - 0.005)
+    ppo.storage.compute_returns(tr["last_values"], 0.98, 0.98)
+    tag = f"n{N}_"
+    if N == 32:
+        assert np.array_equal(ppo.storage.returns.cpu().numpy(), g[tag + "returns"])
+        assert _rel(ppo.storage.advantages.cpu().numpy(), g[tag + "advantages"]) < 1e-5
+    else:
+        assert abs(float(ppo.storage.returns.double().sum()) - float(g[tag + "returns_sum"])) < 1e-2
+    mvl, msl = ppo.update(0)
+    flat = ac.flat.cpu().numpy()
+    print(f"N={N}: value loss {mvl} vs {float(g[tag + 'mvl'])}; surrogate {msl} vs {float(g[tag + 'msl'])}; lr {ppo.step_size} vs {float(g[tag + 'lr_after'])}")
+    assert abs(mvl - float(g[tag + "mvl"])) < 1e-3 * abs(float(g[tag + "mvl"]))
+    assert abs(msl - float(g[tag + "msl"])) < 2e-3 * abs(float(g[tag + "msl"])) + 1e-5
+    assert abs(ppo.step_size - float(g[tag + "lr_after"])) < 1e-9 + 1e-6 * float(g[tag + "lr_after"])
+    if N == 32:
+        assert _rel(flat, g[tag + "params_after"]) < 2e-3
+    else:
+        step = max(1, flat.size // 256)
+        assert _rel(flat[::step][:256], g[tag + "params_after_slice"]) < 2e-3
+
+
+def test_gradients_match_autograd():
+    """One minibatch: HIP analytic gradients vs torch autograd on the oracle's loss."""
+    import ctypes as C
+    from oracle import ppo_ref
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    ppo = _ppo(64)
+    ac = ppo.actor_critic
+    gen = torch.Generator().manual_seed(5)
+    n = 200                                             # not a multiple of 64: ragged last workgroup
+    obs = torch.rand(n, 60, generator=gen) * 2 - 1
+    act = torch.randn(n, 12, generator=gen) * 0.5
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.policy_state_dict(seed=0).items()}
+    with torch.no_grad():
+        lp0, _, v0, mu0, ls0 = ppo_ref.evaluate(sd, obs, act)
+    old_logp = lp0 + 0.3 * torch.randn(n, generator=gen)          # large enough to hit both clip branches
+    adv = torch.randn(n, generator=gen)
+    ret = v0.squeeze(1) + torch.randn(n, generator=gen)
+    old_v = v0.squeeze(1) + 0.3 * torch.randn(n, generator=gen)
+    old_mu = mu0 + 0.05 * torch.randn(n, 12, generator=gen)
+    old_ls = ls0 - 0.01
+    lp, ent, v, mu, ls = ppo_ref.evaluate(sd, obs, act)
+    ratio = torch.exp(lp - old_logp)
+    surr = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 0.8, 1.2)).mean()
+    vc = old_v + (v.squeeze(1) - old_v).clamp(-0.2, 0.2)
+    vl = torch.max((v.squeeze(1) - ret) ** 2, (vc - ret) ** 2).mean()
+    loss = surr + 1.0 * vl - 0.01 * ent.mean()
+    grads = torch.autograd.grad(loss, list(sd.values()))
+    gref = torch.cat([x.reshape(-1) for x in grads]).numpy()
+    need = C.c_size_t()
+    lib.rgbm_ppo_partial_floats(C.byref(ac.layout), n, C.byref(need))
+    partial = torch.empty(need.value, device="cuda")
+    gout = torch.zeros(ac.total + 4, device="cuda")
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    args = [d(obs), d(act), d(old_logp), d(adv), d(ret), d(old_v), d(old_mu), d(old_ls)]
+    _lib.check(lib.rgbm_ppo_minibatch_fwd_bwd(_lib.ptr(ac.flat), C.byref(ac.layout), n, *[_lib.ptr(a) for a in args], 0.2, 1.0, 0.01,
+                                              _lib.ptr(partial), _lib.ptr(gout), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = gout.cpu().numpy()
+    assert _rel(got[:ac.total], gref) < 1e-4
+    assert abs(got[ac.total] / n - surr.item()) < 1e-5 and abs(got[ac.total + 1] / n - vl.item()) < 1e-4 * vl.item()
+    assert got[ac.total + 3] == n
