@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
+    ap.add_argument("--ppo-envs", type=int, default=512, help="envs per GPU for the PPO leg (0 = skip it)")
+    ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()
 
@@ -138,6 +140,21 @@ def main():
     n_valid = int(valid.sum().item())
     finite = bool(torch.isfinite(bbox).all().item())
 
+    # ---- PPO leg: AdaPose-in-the-loop rollout (synthetic vec-env stand-in) + HIP learn phase, cfg/controller/rl.yaml ----
+    ppo_res = None
+    if args.ppo_envs > 0:
+        from rgbmanip_amd.config import rl_cfg
+        from rgbmanip_amd.ppo import PPO
+        from rgbmanip_amd.synthetic_env import SyntheticPoseVecEnv
+        env = SyntheticPoseVecEnv(args.ppo_envs, net, device, seed=0, rank=rank)
+        ppo = PPO(env, rl_cfg(device=str(device), print_log=False, log_dir="/tmp/rgbm_bench_logs", save_dir="/tmp/rgbm_bench_saves"))
+        ppo.run(args.ppo_iters, log_interval=1, save_interval=10 ** 9)
+        barrier()
+        ppo_res = {"env_steps_per_sec": round(ppo.last_fps, 1), "num_envs_per_gpu": args.ppo_envs, "transitions_per_env": 16,
+                   "collection_s": round(ppo.last_collection_time, 3), "learn_s": round(ppo.last_learn_time, 4),
+                   "optimizer_steps": 32, "env": "SyntheticPoseVecEnv (one batched AdaPose estimate per env step)",
+                   "lr_after": ppo.step_size}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
@@ -168,6 +185,8 @@ def main():
             "valid_poses_last_step": n_valid, "outputs_finite": finite,
             "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
+        if ppo_res is not None:
+            res["ppo"] = ppo_res
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the sharding and the two PPO exchanges reproduce the single-process arithmetic.
+(The compute inside uses the oracle — these tests cover the distributed host logic, not the kernels.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rgbmanip_amd import synth
+from rgbmanip_amd.dist_utils import average_flat_gradient, global_adv_stats, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ppo_ref
+    T, N = 16, 64
+    roll = {k: torch.from_numpy(v) for k, v in synth.ppo_rollout(T, N, seed=3).items()}
+    lo, hi = shard_range(N, rank, world)
+    # GAE is per env -> run it on the local env slice; advantage normalisation needs the global statistics
+    ret, _ = ppo_ref.compute_returns(roll["rewards"][:, lo:hi], roll["dones"][:, lo:hi], roll["values"][:, lo:hi],
+                                     roll["last_values"][lo:hi], 0.98, 0.98)
+    adv_raw = (ret - roll["values"][:, lo:hi]).double()
+    sums = torch.stack([adv_raw.sum(), (adv_raw * adv_raw).sum()])
+    mean, std, n = global_adv_stats(sums, adv_raw.numel())
+    adv_local = ((adv_raw - mean) / (std + 1e-8)).float()
+    # gradient exchange: each rank contributes the gradient of its local minibatch mean
+    g_local = torch.full((10 + 4,), float(rank + 1))
+    g_local[10:] = torch.tensor([1.0 * (rank + 1), 2.0, 3.0, float(hi - lo)])
+    scale = average_flat_gradient(g_local)
+    q.put((rank, lo, hi, adv_local.numpy(), n, g_local.numpy(), scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchanges_match_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import ppo_ref
+    T, N = 16, 64
+    roll = {k: torch.from_numpy(v) for k, v in synth.ppo_rollout(T, N, seed=3).items()}
+    _, adv_ref = ppo_ref.compute_returns(roll["rewards"], roll["dones"], roll["values"], roll["last_values"], 0.98, 0.98)
+    got = np.concatenate([r[3] for r in res], axis=1)
+    assert [(r[1], r[2]) for r in res] == [(0, 32), (32, 64)]
+    np.testing.assert_allclose(got, adv_ref.numpy(), rtol=2e-5, atol=2e-6)
+    assert all(r[4] == T * N for r in res)
+    for r in res:
+        assert r[6] == 0.5
+        np.testing.assert_allclose(r[5][:10] * r[6], 1.5)           # mean of the two ranks' gradients
+        np.testing.assert_allclose(r[5][10:], [3.0, 4.0, 6.0, 64.0])  # statistics are summed
+
+
+def test_shard_range_covers_everything():
+    for total in (1, 7, 512, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

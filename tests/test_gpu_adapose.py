@@ -155,3 +155,45 @@ def test_estimate_end_to_end_vs_oracle(inputs, oracle_taps):
         exp = postproc_ref.bbox_world(oout["view1_nocs"][b].numpy(), oout["view1_depth"][b].numpy(), oout["view1_r"][b].numpy(),
                                       inputs["choose1"][b], inputs["K1"][b], inputs["E1"][b])
         assert _rel(bbox[b].cpu().numpy(), exp) < 1e-3, b
+
+
+def test_estimator_plugin_estimate_vs_oracle_pipeline():
+    """`AdaPoseEstimator_v5.estimate` (crop/resize/sample on the host, batched HIP net + post-processing) against the
+    oracle pipeline; an empty mask must yield the +10 default cube without disturbing its neighbours."""
+    from oracle import adapose_ref, postproc_ref
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5, DEFAULT_BBOX
+    g = np.random.default_rng(3)
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False)
+    sd = synth.adapose_state_dict(seed=0)
+    est = AdaPoseEstimator_v5(None, cfg, None, state_dict=sd, dtype="fp32")
+    n = 3
+    yy, xx = np.mgrid[0:480, 0:640]
+    K = np.tile(np.array([[439.31, 0, 320.0], [0, 439.31, 240.0], [0, 0, 1.0]])[None], (n, 1, 1))
+    base = synth.adapose_inputs(n, seed=9)
+    rgb1 = np.clip(0.5 + 0.25 * np.cos(xx / 37.0)[None, :, :, None] + 0.2 * g.random((n, 480, 640, 3)), 0, 1)
+    rgb2 = np.clip(0.5 + 0.25 * np.sin(yy / 29.0)[None, :, :, None] + 0.2 * g.random((n, 480, 640, 3)), 0, 1)
+    m1 = np.stack([((yy - 240) / 60.0) ** 2 + ((xx - 300 - 10 * i) / 90.0) ** 2 <= 1 for i in range(n)])
+    m2 = np.stack([((yy - 250) / 70.0) ** 2 + ((xx - 340 + 10 * i) / 80.0) ** 2 <= 1 for i in range(n)])
+    m2[1] = False                                            # sample 1: empty second mask -> default bbox
+    E1, E2 = base["E1"], base["E2"]
+    est.rng = np.random.default_rng(11)
+    out = est.estimate(K, rgb1, m1, E1, rgb2, m2, E2)
+    assert out.shape == (n, 8, 3) and np.allclose(out[1], DEFAULT_BBOX)
+    # oracle pipeline with the same sampling stream
+    rng = np.random.default_rng(11)
+    tsd = adapose_ref.to_torch_sd(sd)
+    for i in range(n):
+        a = postproc_ref.prepare_model_input(rgb1[i], m1[i], K[i], 224, rng=rng)     # same RNG consumption as estimate()
+        b = postproc_ref.prepare_model_input(rgb2[i], m2[i], K[i], 224, rng=rng)
+        if a[0] is None or b[0] is None:
+            continue
+        P1, P2 = np.eye(4), np.eye(4)
+        P1[:3] = a[3] @ E1[i][:3]
+        P2[:3] = b[3] @ E2[i][:3]
+        dep = torch.arange(24, dtype=torch.float32)[None] * 0.1 + 0.1
+        o = adapose_ref.adapose_forward(tsd, torch.from_numpy(a[0]).float()[None], torch.from_numpy(a[1])[None],
+                                        torch.from_numpy(b[0]).float()[None], torch.from_numpy(b[1])[None],
+                                        torch.from_numpy(P1).float()[None], torch.from_numpy(P2).float()[None], dep)
+        exp = postproc_ref.bbox_world(o["view1_nocs"][0].numpy(), o["view1_depth"][0].numpy(), o["view1_r"][0].numpy(), a[1], a[3], E1[i])
+        assert _rel(out[i], exp) < 1e-3, i

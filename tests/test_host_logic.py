@@ -1,0 +1,85 @@
+"""CPU: host-side logic of the plugin layer (no GPU, no HIP calls)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import postproc_ref
+from rgbmanip_amd import config, estimator, spaces, synth
+from rgbmanip_amd.ppo.module import ActorCritic
+from rgbmanip_amd.ppo.storage import RolloutStorage
+
+
+def test_get_bbox_and_resize_match_oracle():
+    g = np.random.default_rng(0)
+    for _ in range(50):
+        y1, x1 = int(g.integers(0, 470)), int(g.integers(0, 630))
+        y2, x2 = int(g.integers(y1, 480)), int(g.integers(x1, 640))
+        assert estimator.get_bbox([y1, x1, y2, x2]) == postproc_ref.get_bbox([y1, x1, y2, x2])
+    img = g.random((200, 200, 3))
+    np.testing.assert_allclose(estimator._resize_linear(img, 224), postproc_ref.resize_linear(img, 224), rtol=1e-6, atol=1e-7)
+    m = (g.random((240, 240)) > 0.5).astype(np.float32)
+    assert np.array_equal(estimator._resize_nearest(m, 224), postproc_ref.resize_nearest(m, 224))
+
+
+def test_prepare_model_input_matches_oracle():
+    g = np.random.default_rng(1)
+    rgb = g.random((480, 640, 3))
+    mask = np.zeros((480, 640), dtype=bool)
+    mask[200:300, 250:420] = True
+    K = np.array([[439.3, 0, 320.0], [0, 439.3, 240.0], [0, 0, 1.0]])
+    est = estimator.AdaPoseEstimator_v5.__new__(estimator.AdaPoseEstimator_v5)      # host logic only: no device net
+    est.cfg = config.ADAPOSE_CFGS["adapose_cabinet"]
+    est.rng = np.random.default_rng(7)
+    view, choose, pts2d, Kn = est.prepare_model_input(rgb, mask, K, 224)
+    v2, c2, p2, K2 = postproc_ref.prepare_model_input(rgb, mask, K, 224, rng=np.random.default_rng(7))
+    assert np.array_equal(choose, c2) and choose.shape == (1024,)
+    np.testing.assert_allclose(view.numpy(), v2, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Kn, K2)
+    np.testing.assert_allclose(pts2d, p2, rtol=1e-6)
+    assert est.prepare_model_input(rgb, np.zeros_like(mask), K, 224) == (None, None, None, None)
+
+
+def test_actor_critic_layout_and_state_dict_roundtrip():
+    ac = ActorCritic((60,), (75,), (12,), 0.6, config.RL_CONTROLLER_CFG["policy"])
+    sd = ac.state_dict()
+    assert list(sd.keys()) == list(synth.policy_state_dict().keys())
+    assert ac.total == 36985 and sum(v.numel() for v in sd.values()) == 36985
+    assert torch.allclose(sd["log_std"], torch.full((12,), float(np.log(0.6))))
+    w = sd["actor.0.weight"]
+    assert torch.allclose(w.T @ w, 2.0 * torch.eye(60), atol=1e-4)            # orthogonal init, gain sqrt(2)
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()})
+    assert torch.equal(ac.state_dict()["critic.6.weight"], torch.from_numpy(synth.policy_state_dict(seed=0)["critic.6.weight"]))
+    with pytest.raises(RuntimeError):
+        ac.load_state_dict({"log_std": torch.zeros(12)})
+    from rgbmanip_amd import _lib
+    with pytest.raises(_lib.RgbmError):                                         # product path never falls back to the CPU
+        ac.act(torch.zeros(4, 60), None)
+
+
+def test_rollout_storage_bookkeeping():
+    st = RolloutStorage(4, 3, (60,), (75,), (12,), "cpu", "sequential")
+    for t in range(3):
+        st.add_transitions(torch.zeros(4, 60), torch.zeros(4, 75), torch.zeros(4, 12), torch.ones(4), torch.tensor([0, 1, 0, 0]),
+                           torch.zeros(4, 1), torch.zeros(4), torch.zeros(4, 12), torch.zeros(4, 12))
+    with pytest.raises(AssertionError, match="Rollout buffer overflow"):
+        st.add_transitions(torch.zeros(4, 60), torch.zeros(4, 75), torch.zeros(4, 12), torch.ones(4), torch.zeros(4),
+                           torch.zeros(4, 1), torch.zeros(4), torch.zeros(4, 12), torch.zeros(4, 12))
+    length, rew = st.get_statistics()
+    # env 1 is done every step (3 trajectories of 1), envs 0,2,3 are cut once at the end (3 trajectories of 3): 12 steps / 6
+    assert abs(float(length) - 2.0) < 1e-6 and float(rew) == 1.0
+    assert [list(b) for b in st.mini_batch_generator(4)] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]]
+    from rgbmanip_amd import _lib
+    with pytest.raises(_lib.RgbmError):
+        st.compute_returns(torch.zeros(4, 1), 0.98, 0.98)
+
+
+def test_ppo_rejects_non_spaces():
+    from rgbmanip_amd.ppo import PPO
+
+    class Bad:
+        num_envs = 2
+        observation_space = "nope"
+        state_space = spaces.Box(-1, 1, (75,))
+        action_space = spaces.Box(-1, 1, (12,))
+    with pytest.raises(TypeError, match="observation_space must be a gym Space"):
+        PPO(Bad(), config.rl_cfg(device="cpu"))
