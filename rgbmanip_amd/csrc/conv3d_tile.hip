@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   const int lr = lane & 15, lg = lane >> 4;
 
   // ---- tile coordinates (q-grid = output grid for conv, input grid for transposed) ----
-  int t = blockIdx.x;
+  // XCD-aware order: hardware block b runs on XCD b%8; give every XCD a contiguous run of tiles (whole views) so the
+  // feature maps / halos its 32 CUs gather from stay in that XCD's 4 MB L2 (bijective for any grid size)
+  const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  int t = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
   const int tw = t % d.ntw; t /= d.ntw;
   const int th = t % d.nth; t /= d.nth;
   const int td = t % d.ntd; t /= d.ntd;

@@ -1,40 +1,28 @@
-// Generic implicit-GEMM convolution for gfx950 (CDNA4): 1-D/2-D/3-D, stride, dilation,
-// sub-pixel (transposed-conv) output mapping, fused bias / residual / activation epilogue.
-//
-// Replaces the cuDNN conv calls behind the reference's nn.Conv2d / nn.Conv3d /
-// nn.ConvTranspose3d / nn.Conv1d(k=1) / nn.Linear layers
-// (/root/reference/models/pose_estimator/AdaPose/lib/pspnet.py:11-30,97-107,
-//  lib/network_v5.py:8-28,217-291,317-376).
-//
-// GEMM view (per workgroup):   D[ch][pix] = sum_k W[ch][k] * X[k][pix]
-//   A operand = weights  [BCH rows ][BK]  (K contiguous; pre-packed, BN folded, zero padded)
-//   B operand = gathered [BPIX rows][BK]  input patch (NDHWC, k = tap*Cin + c)
-// so every lane ends up with 4 consecutive output channels of one pixel (MFMA 16x16 C layout:
-// col = lane&15 -> pixel, row = (lane>>4)*4+r -> channel) and stores them as one 8/16-byte write.
-//
-// 256 threads = 4 wave64; wave tile = min(BCH,64) channels x 64 pixels; K tile = 128 bytes per row
-// (64 bf16 / 32 f32), register-staged global->LDS double buffering, one barrier per K tile.
-// LDS rows are 128 B with a 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7) so that the 16 rows a
-// ds_read_b128 lane group touches land on 16 distinct 16-B bank slots.
-// bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); f32: v_mfma_f32_16x16x4_f32 (exact fp32).
+// Implicit-GEMM convolution, LDS-DMA variant (gfx950): same GEMM view, tiles, fragment maps and epilogue as
+// conv_igemm.hip, but both operand tiles travel global -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no
+// ds_write pass), so the loads of K tile t+1 are in flight while the MFMAs of tile t run and only one barrier per K tile
+// is needed.  The LDS image of a tile is lane-linear (wave-uniform base + lane*16 bytes), therefore the bank-conflict
+// swizzle is applied on the SOURCE side: the lane that fills LDS slot (row, j) fetches global chunk j ^ ((row>>1)&7),
+// and readers XOR the same value (an involution).  Out-of-image / padded-K lanes fetch from a 16-byte zero page.
 #include "common.h"
 #include "prof.h"
 
 namespace rgbm {
 
 extern int g_debug_flags;
-int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s);
+__device__ uint4 g_zero_page[4];     // zero-initialised device memory: the source of every padded chunk
 
-template <typename T> struct Mma;
-template <> struct Mma<unsigned short> {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <typename T> struct MmaG;
+template <> struct MmaG<unsigned short> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
-template <> struct Mma<float> {
+template <> struct MmaG<float> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-    // lane-group g, element e of the 16-byte chunk is k = g*4+e; the same map is used for A and B,
-    // so the four MFMAs together contract the 16 k values this chunk quad holds.
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
@@ -42,19 +30,18 @@ template <> struct Mma<float> {
   }
 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  // NaN must propagate like torch.relu / prelu (a degenerate pair ends as default_bbox, never as a finite box)
-  if (act == ACT_RELU) return v < 0.f ? 0.f : v;
+__device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
+  if (act == ACT_RELU) return v < 0.f ? 0.f : v;          // NaN propagates like torch
   if (act == ACT_PRELU) return v < 0.f ? v * slope : v;
   if (act == ACT_TANH) return tanhf(v);
   return v;
 }
 
 template <typename T, int BCH, int BPIX>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
-  constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk
-  constexpr int BK = 8 * E;              // K tile (128 bytes per row)
-  constexpr int XR = BPIX / 32;          // gathered rows per thread
+__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc d) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr int BK = 8 * E;
+  constexpr int XR = BPIX / 32;
   constexpr int WL = BCH >= 32 ? BCH / 32 : 1;
   constexpr int WCH = BCH < 64 ? BCH : 64;
   constexpr int FM = WCH / 16;
@@ -66,9 +53,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  // XCD-aware tile order: the hardware dispatches block b to XCD b%8; give each XCD a contiguous
-  // run of logical tiles (bijective for any grid size) so channel tiles of one pixel tile and
-  // neighbouring pixel tiles (shared halos) hit the same L2.
   const int nblk = gridDim.x;
   const int bq = nblk >> 3, br = nblk & 7;
   const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
@@ -79,9 +63,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
 
-  // ---- per-thread gather rows ----------------------------------------------------------
-  const int j = tid & 7;        // 16-byte chunk within the 128-byte K tile row
-  const int r0 = tid >> 3;      // 0..31
+  // LDS slot (row, j) is filled by thread (r0 = row & 31 [+32*i], j); it fetches source chunk js = j ^ swizzle(row).
+  const int j = tid & 7;
+  const int r0 = tid >> 3;
+  const int js = j ^ ((r0 >> 1) & 7);       // ((r0 + 32*i) >> 1) & 7 == (r0 >> 1) & 7
   int xn[XR], xd0[XR], xh0[XR], xw0[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
@@ -102,12 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   const float rcp_khw = 1.0f / (float)(d.KH * d.KW);
   const float rcp_kw = 1.0f / (float)d.KW;
   const int khw = d.KH * d.KW;
+  const bool wload = (BCH >= 32) || (wave < BCH / 8);      // wave-uniform
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
 
-  uint4 xr[XR], wr[WL];
-  const bool wload = (BCH >= 32) || (tid < BCH * 8);
-
-  auto gload = [&](int kt) {
-    const int k = kt * BK + j * E;
+  auto issue = [&](int kt, int stage) {
+    const int k = kt * BK + js * E;
     int tap, c;
     bool tapok;
     if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
@@ -117,42 +101,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
     const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
     const int kw = rem - kh * d.KW;
     const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
+    uint4* W = lds + stage * STAGE;
+    uint4* X = W + BCH * 8;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
-      const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi &&
-                      (unsigned)ww < (unsigned)d.Wi;
+      const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
       const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(in + pix * d.Cin + c);
-      xr[i] = v;
+      const T* src = ok ? in + pix * d.Cin + c : zero;
+      // wave-uniform LDS base of this wave's 64 consecutive slots; the hardware adds lane*16 bytes
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(X + (i * 32 + wave * 8) * 8), 16, 0, 0);
     }
     if (wload) {
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
         const int row = ch_tile * BCH + r0 + 32 * i;
-        wr[i] = *reinterpret_cast<const uint4*>(wgt + (long long)row * d.Kpad + k);
-      }
-    }
-  };
-  auto lstore = [&](int stage) {
-    uint4* W = lds + stage * STAGE;
-    uint4* X = W + BCH * 8;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const int row = r0 + 32 * i;
-      X[row * 8 + (j ^ ((row >> 1) & 7))] = xr[i];
-    }
-    if (wload) {
-#pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int row = r0 + 32 * i;
-        W[row * 8 + (j ^ ((row >> 1) & 7))] = wr[i];
+        const T* src = wgt + (long long)row * d.Kpad + kt * BK + js * E;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(W + (i * 32 + wave * 8) * 8), 16, 0, 0);
       }
     }
   };
 
-  // ---- wave tile -------------------------------------------------------------------------
   const int wch = (BCH == 128) ? (wave >> 1) * 64 : 0;
   const int wpix = (BCH == 128) ? (wave & 1) * 64 : wave * 64;
   f32x4 acc[FM][FN];
@@ -160,16 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   for (int a = 0; a < FM; ++a)
 #pragma unroll
     for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int lr = lane & 15, lg = lane >> 4;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  issue(0, 0);
   int cur = 0;
   for (int kt = 0; kt < d.KT; ++kt) {
-    const bool more = kt + 1 < d.KT;
-    if (more) gload(kt + 1);
+    // tile kt has landed for every wave (vmcnt(0) + barrier); every wave has also finished reading the other stage
+    __syncthreads();
+    if (kt + 1 < d.KT) issue(kt + 1, cur ^ 1);
     const uint4* W = lds + cur * STAGE;
     const uint4* X = W + BCH * 8;
 #pragma unroll
@@ -189,14 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
-        for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+        for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
     cur ^= 1;
   }
 
-  // ---- epilogue: bias, residual, activation, 4-channel vector store ---------------------------
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
 #pragma unroll
@@ -228,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
         for (int e = 0; e < 4; ++e) v[e] += rv[e];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act, d.slope);
+      for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
       if (d.res_mode == RES_POST_ACT) {
         float rv[4];
         load4(res + o, rv);
@@ -240,51 +204,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   }
 }
 
-int conv_ch_tile(int Cout) {
-  if (Cout <= 16) return 16;
-  if (Cout <= 32) return 32;
-  if (Cout <= 64) return 64;
-  return 128;
-}
-int conv_bk(int dtype) { return dtype == BF16 ? 64 : 32; }
-
 template <typename T, int BCH, int BPIX>
-static int launch_one(ConvDesc d, hipStream_t s) {
+static int launch_one_g(ConvDesc d, hipStream_t s) {
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const int variant = (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
   prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BCH, BPIX>), dim3((unsigned)nblk), dim3(256), 0, s, d);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<T, BCH, BPIX>), dim3((unsigned)nblk), dim3(256), 0, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T>
-static int launch_t(const ConvDesc& d, hipStream_t s) {
+static int launch_t_g(const ConvDesc& d, hipStream_t s) {
   switch (conv_ch_tile(d.Cout)) {
-    case 16: return launch_one<T, 16, 256>(d, s);
-    case 32: return launch_one<T, 32, 256>(d, s);
-    case 64: return launch_one<T, 64, 256>(d, s);
-    default: return launch_one<T, 128, 128>(d, s);
+    case 16: return launch_one_g<T, 16, 256>(d, s);
+    case 32: return launch_one_g<T, 32, 256>(d, s);
+    case 64: return launch_one_g<T, 64, 256>(d, s);
+    default: return launch_one_g<T, 128, 128>(d, s);
   }
 }
 
-int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
-  RGBM_REQUIRE(d.M > 0 && d.M < (1ll << 31), "conv M out of range");
-  RGBM_REQUIRE(d.Cout % 4 == 0 && d.ldo % 4 == 0, "conv Cout/ldo must be multiples of 4");
-  RGBM_REQUIRE(d.KT > 0 && d.Kpad == d.KT * conv_bk(dtype), "conv K padding mismatch");
-  const int E = dtype == BF16 ? 8 : 4;
-  RGBM_REQUIRE(d.Cin % E == 0, "conv Cin must be a multiple of the 16-byte chunk");
-  if (d.lcin >= 0) {
-    RGBM_REQUIRE((1 << d.lcin) == d.Cin, "conv lcin mismatch");
-  } else {
-    RGBM_REQUIRE(d.ntaps == 1, "linear-K mode needs a single tap");
-  }
-  if (!(g_debug_flags & 4)) return launch_conv_glds(d, dtype, s);      // default: LDS-DMA variant (conv_igemm_glds.hip)
-  return dtype == BF16 ? launch_t<unsigned short>(d, s) : launch_t<float>(d, s);
+int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
+  return dtype == BF16 ? launch_t_g<unsigned short>(d, s) : launch_t_g<float>(d, s);
 }
 
 }  // namespace rgbm
