@@ -28,7 +28,9 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md dense MF
 VARIANT_NAMES = {0: "conv_igemm_kernel<f32,16,256>", 1: "conv_igemm_kernel<f32,32,256>", 2: "conv_igemm_kernel<f32,64,256>",
                  3: "conv_igemm_kernel<f32,128,128>", 4: "conv_igemm_kernel<bf16,16,256>", 5: "conv_igemm_kernel<bf16,32,256>",
                  6: "conv_igemm_kernel<bf16,64,256>", 7: "conv_igemm_kernel<bf16,128,128>",
-                 8: "conv3d_tile_kernel<f32,*>", 9: "conv3d_tile_kernel<bf16,*>"}
+                 8: "conv3d_tile_kernel<f32,*> (conv1..conv11)", 9: "conv3d_tile_kernel<bf16,*> (conv1..conv11)",
+                 10: "conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)",
+                 11: "conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)"}
 
 
 def make_inputs(B, device, unique=16):
@@ -131,7 +133,7 @@ def main():
         out, bbox, valid = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    stats = (C.c_double * 40)()
+    stats = (C.c_double * 48)()
     _lib.check(lib.rgbm_prof_stop(stats), "rgbm_prof_stop")
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -158,9 +160,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
-        st = np.array(list(stats)).reshape(10, 4)
+        st = np.array(list(stats)).reshape(12, 4)
         kernels = []
-        for v in range(10):
+        for v in range(12):
             n, ms, fl, by = st[v]
             if n > 0:
                 kernels.append({"kernel": VARIANT_NAMES[v], "launches_per_step": n / args.steps,

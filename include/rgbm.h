@@ -155,7 +155,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
                        size_t* n_elems, void* stream);
 
 /* Live per-kernel timing for bench.py's roofline figure: between start and stop every convolution launch is
- * bracketed by HIP events recorded on its own stream.  stats: host double[10*4]; rows 0..7 = dtype*4 + {0:16,1:32,2:64,
+ * bracketed by HIP events recorded on its own stream.  stats: host double[12*4]; rows 10/11 = conv3d_tile_kernel of conv0 alone (f32/bf16); rows 0..7 = dtype*4 + {0:16,1:32,2:64,
  * 3:128}-channel tile instantiation of conv_igemm_kernel, rows 8/9 = conv3d_tile_kernel f32/bf16; columns {launches, total ms, algorithmic FLOPs,
  * algorithmic bytes}.  stop synchronises on the recorded events. */
 /* ablation switches for kernel benchmarking only (0 = normal operation) */

@@ -342,7 +342,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.Dq = transposed ? Di : Do; d.Hq = transposed ? Hi : Ho; d.Wq = transposed ? Wi : Wo;
     d.Cout = t3d[li].Cout; d.relu = 1;
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
-    d.prof_variant = 8 + (dtype == BF16 ? 1 : 0);
+    d.prof_variant = (layer == 10 || layer == 0) ? 10 + (dtype == BF16 ? 1 : 0) : 8 + (dtype == BF16 ? 1 : 0);   // conv0 counted on its own
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);

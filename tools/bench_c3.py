@@ -18,7 +18,7 @@ for flags in (0, 1, 2, 3):
     lib.rgbm_prof_start()
     for _ in range(3): run()
     torch.cuda.synchronize()
-    st = (C.c_double * 40)(); lib.rgbm_prof_stop(st)
-    st = np.array(list(st)).reshape(10, 4)
+    st = (C.c_double * 48)(); lib.rgbm_prof_stop(st)
+    st = np.array(list(st)).reshape(12, 4); st[9] += st[11]
     print(f"flags {flags}: conv3d_tile bf16: launches {st[9,0]:.0f} total ms/forward {st[9,1]/3:.3f}  (B={B}: 1 chunk of {2*B} views)")
 lib.rgbm_debug_flags(0)
