@@ -342,6 +342,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.Dq = transposed ? Di : Do; d.Hq = transposed ? Hi : Ho; d.Wq = transposed ? Wi : Wo;
     d.Cout = t3d[li].Cout; d.relu = 1;
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
+    d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
     d.prof_variant = (layer == 10 || layer == 0) ? 10 + (dtype == BF16 ? 1 : 0) : 8 + (dtype == BF16 ? 1 : 0);   // conv0 counted on its own
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
@@ -365,7 +366,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
     if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
     if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;
-    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, s)) return rc;
+    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 1, s)) return rc;
   }
   for (int v0 = 0; cost_impl == 0 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
@@ -381,7 +382,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = dc[0].run(bf.c[6], bf.u7, Vc, D / 8, S / 8, S / 8, 32, bf.c[4], RES_POST_ACT, nullptr, 0, s)) return rc;
     if (int rc = dc[1].run(bf.u7, bf.u9, Vc, D / 4, S / 4, S / 4, 16, bf.c[2], RES_POST_ACT, nullptr, 0, s)) return rc;
     if (int rc = dc[2].run(bf.u9, bf.u11, Vc, D / 2, S / 2, S / 2, 8, bf.c[0], RES_POST_ACT, nullptr, 0, s)) return rc;
-    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, s)) return rc;
+    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 0, s)) return rc;
   }
   return 0;
 }

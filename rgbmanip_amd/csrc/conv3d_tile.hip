@@ -266,7 +266,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       if (qd_[f] >= d.Dq || qh_[f] >= d.Hq || qw_[f] >= d.Wq) continue;
-      const long long opix = (((long long)n * d.Do + (qd_[f] * OS + pd)) * d.Ho + (qh_[f] * OS + ph)) * d.Wo + (qw_[f] * OS + pw);
+      // class-major output (transposed convs whose consumer gathers sparsely): the 8 sub-pixel classes become 8 dense
+      // volumes, so a fragment row is one full 128-byte line instead of eight 16-byte pieces of eight lines
+      const long long opix = (TR && d.out_classmajor)
+          ? ((((long long)PASS * d.N + n) * d.Dq + qd_[f]) * d.Hq + qh_[f]) * d.Wq + qw_[f]
+          : (((long long)n * d.Do + (qd_[f] * OS + pd)) * d.Ho + (qh_[f] * OS + ph)) * d.Wo + (qw_[f] * OS + pw);
+      const long long rpix = (((long long)n * d.Do + (qd_[f] * OS + pd)) * d.Ho + (qh_[f] * OS + ph)) * d.Wo + (qw_[f] * OS + pw);
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
         const int ch = a * 16 + lg * 4;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
         const long long o = opix * d.Cout + ch;
         if (res) {
           float rv[4];
-          load4(res + o, rv);
+          load4(res + rpix * d.Cout + ch, rv);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void prob_softmax_depth_kernel(const T* __rest
                                                                  const int* __restrict__ choose,
                                                                  const float* __restrict__ depths, float* __restrict__ prob,
                                                                  float* __restrict__ depth_out, int v0, int Vc, int B, int P,
-                                                                 int D, int H, int W) {
+                                                                 int D, int H, int W, int classmajor) {
   constexpr int C = 8;
   __shared__ float w[27 * C];
   __shared__ float logit[64][25];
@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void prob_softmax_depth_kernel(const T* __rest
           for (int kw = 0; kw < 3; ++kw) {
             const int xx = x + kw - 1;
             if ((unsigned)xx >= (unsigned)W) continue;
-            const T* p = u11 + ((((long long)vl * D + zz) * H + yy) * W + xx) * C;
+            // class-major u11 (written by the halo-tiled conv11): class = parity bits (d,y,x), dense [8][Vc][D/2][H/2][W/2][C]
+            const long long vidx = classmajor
+                ? (((((long long)(((zz & 1) << 2) | ((yy & 1) << 1) | (xx & 1)) * Vc + vl) * (D >> 1) + (zz >> 1)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1))
+                : ((((long long)vl * D + zz) * H + yy) * W + xx);
+            const T* p = u11 + vidx * C;
             float a[4], b[4];
             load4(p, a);
             load4(p + 4, b);
@@ -110,15 +114,15 @@ __global__ __launch_bounds__(256) void prob_softmax_depth_kernel(const T* __rest
 
 int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, const int* choose, const float* depths,
                               float* prob, float* depth_out, int v0, int Vc, int B, int P, int D, int H, int W,
-                              hipStream_t s) {
+                              int classmajor, hipStream_t s) {
   RGBM_REQUIRE(D <= 24, "prob kernel supports up to 24 depth planes");
   const unsigned g = (unsigned)(((long long)Vc * P + 63) / 64);
   if (dtype == BF16)
     hipLaunchKernelGGL(prob_softmax_depth_kernel<unsigned short>, dim3(g), dim3(256), 0, s, (const unsigned short*)u11, wprob,
-                       choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W);
+                       choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
   else
     hipLaunchKernelGGL(prob_softmax_depth_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)u11, wprob, choose, depths,
-                       prob, depth_out, v0, Vc, B, P, D, H, W);
+                       prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -22,7 +22,8 @@ int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_
 // head_kernels.hip
 int launch_gather_points(int dtype, const void* feat, const int* choose, float* out, int V, int P, int HW, int C, hipStream_t s);
 int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, const int* choose, const float* depths,
-                              float* prob, float* depth_out, int v0, int Vc, int B, int P, int D, int H, int W, hipStream_t s);
+                              float* prob, float* depth_out, int v0, int Vc, int B, int P, int D, int H, int W, int classmajor,
+                              hipStream_t s);
 int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
                        const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
                        hipStream_t s);
@@ -42,6 +43,7 @@ struct Conv3dTileDesc {
   int Cout, relu;
   const void* feat; const float* homog; const float* depths; int v0, V, B;   // fused-warp mode only
   int prof_variant; double algo_flops, algo_bytes;
+  int out_classmajor;           // transposed only: write each sub-pixel class as its own dense [N][Dq][Hq][Wq][C] volume
   int dbg;                      // ablation bits (benchmark only): 1 = skip halo staging work, 2 = skip the MFMA phase
 };
 extern int g_debug_flags;

@@ -87,7 +87,13 @@ def test_fp32_intermediates_vs_oracle(inputs, oracle_taps, cost_impl):
     errs["c6"] = _rel(ndhwc("c6", 64, 3, 28), taps["v1_c6"].numpy())
     errs["u7"] = _rel(ndhwc("u7", 32, 6, 56), taps["v1_u7"].numpy())
     errs["u9"] = _rel(ndhwc("u9", 16, 12, 112), taps["v1_u9"].numpy())
-    errs["u11"] = _rel(ndhwc("u11", 8, 24, 224), taps["v1_u11"].numpy())
+    if cost_impl == 0:
+        errs["u11"] = _rel(ndhwc("u11", 8, 24, 224), taps["v1_u11"].numpy())
+    else:
+        # the halo-tiled conv11 writes its 8 sub-pixel classes as 8 dense volumes [cls][view][12][112][112][8]
+        cm = net.fetch(B, "u11", V * 24 * 224 * 224 * 8).view(2, 2, 2, V, 12, 112, 112, 8)[:, :, :, :B]
+        full = cm.permute(3, 7, 4, 0, 5, 1, 6, 2).reshape(B, 8, 24, 224, 224)      # [v, c, (qd,pd), (qh,ph), (qw,pw)]
+        errs["u11"] = _rel(full.cpu().numpy(), taps["v1_u11"].numpy())
     prob = net.fetch(B, "prob", V * 1024 * 24).view(V, 1024, 24)[:B].permute(0, 2, 1).cpu().numpy()
     errs["prob"] = _rel(prob, taps["v1_prob"].numpy())
     print("fp32 cost-volume stage errors:", errs)
