@@ -15,6 +15,20 @@ __device__ uint4 g_zero_page[4];     // zero-initialised device memory: the sour
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// LDS-DMA issued from inline asm ON PURPOSE: for the builtin, hipcc (ROCm 7.2) conservatively places `s_waitcnt vmcnt(0)`
+// in front of the first ds_read that follows, which drains the loads of the NEXT K tile before the current one is
+// multiplied (seen in the ISA: issue -> vmcnt(0) -> ds_read -> mfma, i.e. no load/compute overlap inside a workgroup).
+// An asm DMA is invisible to that bookkeeping; completion is enforced by our own counted `s_waitcnt vmcnt(N)` + barrier.
+// lds_off: wave-uniform LDS byte address of this wave's 1 KiB slot (hardware adds lane*16); M0 is saved and restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <typename T> struct MmaG;
 template <> struct MmaG<unsigned short> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
@@ -110,14 +124,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
       const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
       const T* src = ok ? in + pix * d.Cin + c : zero;
       // wave-uniform LDS base of this wave's 64 consecutive slots; the hardware adds lane*16 bytes
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(X + (i * 32 + wave * 8) * 8), 16, 0, 0);
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
     }
     if (wload) {
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
         const int row = ch_tile * BCH + r0 + 32 * i;
         const T* src = wgt + (long long)row * d.Kpad + kt * BK + js * E;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(W + (i * 32 + wave * 8) * 8), 16, 0, 0);
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
       }
     }
   };
@@ -135,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
   int cur = 0;
   for (int kt = 0; kt < d.KT; ++kt) {
     // tile kt has landed for every wave (vmcnt(0) + barrier); every wave has also finished reading the other stage
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (kt + 1 < d.KT) issue(kt + 1, cur ^ 1);
     const uint4* W = lds + cur * STAGE;
     const uint4* X = W + BCH * 8;
@@ -204,6 +219,196 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 128 tile, 8 waves, 3-stage LDS ring with counted vmcnt (layers with >= 128 output channels).
+// Two K tiles are in flight while a third is multiplied: tile kt+2 is issued right after the single barrier of
+// iteration kt, the wait in front of that barrier is `vmcnt(6)` (the 6 LDS-DMA instructions of tile kt+1 may stay
+// outstanding), never 0 inside the loop.  Raw s_barrier + inline waits: __syncthreads() would drain the DMA queue.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d) {
+  constexpr int BCH = 128, BPIX = 256;
+  constexpr int E = 16 / sizeof(T);
+  constexpr int BK = 8 * E;
+  constexpr int XR = BPIX / 64;              // 4 gathered rows per thread
+  constexpr int WL = BCH / 64;               // 2 weight rows per thread
+  constexpr int FM = 4, FN = 4;
+  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (48 KB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;                 // 0..7
+
+  const int nblk = gridDim.x;
+  const int bq = nblk >> 3, br = nblk & 7;
+  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int lid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+  const int pix_tile = lid / d.n_ch_tiles;
+  const int ch_tile = lid - pix_tile * d.n_ch_tiles;
+
+  const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+  const int j = tid & 7;
+  const int r0 = tid >> 3;                   // 0..63
+  const int js = j ^ ((r0 >> 1) & 7);
+  int xn[XR], xd0[XR], xh0[XR], xw0[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const long long m = (long long)pix_tile * BPIX + r0 + 64 * i;
+    if (m < d.M) {
+      unsigned t = (unsigned)m;
+      const unsigned qw = t % (unsigned)d.Wq; t /= (unsigned)d.Wq;
+      const unsigned qh = t % (unsigned)d.Hq; t /= (unsigned)d.Hq;
+      const unsigned qd = t % (unsigned)d.Dq; t /= (unsigned)d.Dq;
+      xn[i] = (int)t * d.Di;
+      xd0[i] = (int)qd * d.sd - d.pd;
+      xh0[i] = (int)qh * d.sh - d.ph;
+      xw0[i] = (int)qw * d.sw - d.pw;
+    } else {
+      xn[i] = 0; xd0[i] = -(1 << 20); xh0[i] = 0; xw0[i] = 0;
+    }
+  }
+  const float rcp_khw = 1.0f / (float)(d.KH * d.KW);
+  const float rcp_kw = 1.0f / (float)d.KW;
+  const int khw = d.KH * d.KW;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  auto issue = [&](int kt, int stage) {
+    const int k = kt * BK + js * E;
+    int tap, c;
+    bool tapok;
+    if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
+    else { tap = 0; c = k; tapok = k < d.Cin; }
+    const int kd = (int)(((float)tap + 0.5f) * rcp_khw);
+    const int rem = tap - kd * khw;
+    const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
+    const int kw = rem - kh * d.KW;
+    const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
+    uint4* W = lds3 + stage * STAGE;
+    uint4* X = W + BCH * 8;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
+      const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
+      const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
+      const T* src = ok ? in + pix * d.Cin + c : zero;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int row = ch_tile * BCH + r0 + 64 * i;
+      const T* src = wgt + (long long)row * d.Kpad + kt * BK + js * E;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
+    }
+  };
+
+  const int wch = (wave >> 2) * 64;
+  const int wpix = (wave & 3) * 64;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lg = lane >> 4;
+
+  issue(0, 0);
+  if (d.KT > 1) issue(1, 1);
+  int st = 0;                                  // stage of tile kt
+  for (int kt = 0; kt < d.KT; ++kt) {
+    if (kt + 1 < d.KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // tile kt landed; tile kt+1 may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave's share of tile kt is in LDS; stage of tile kt-1 is free
+    if (kt + 2 < d.KT) issue(kt + 2, st == 0 ? 2 : st - 1);
+    const uint4* W = lds3 + st * STAGE;
+    const uint4* X = W + BCH * 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cidx = s * 4 + lg;
+      uint4 af[FM], bf[FN];
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        const int row = wch + a * 16 + lr;
+        af[a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int b = 0; b < FN; ++b) {
+        const int row = wpix + b * 16 + lr;
+        bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
+#pragma unroll
+  for (int b = 0; b < FN; ++b) {
+    const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
+    if (m >= d.M) continue;
+    unsigned t = (unsigned)m;
+    const unsigned qw = t % (unsigned)d.Wq; t /= (unsigned)d.Wq;
+    const unsigned qh = t % (unsigned)d.Hq; t /= (unsigned)d.Hq;
+    const unsigned qd = t % (unsigned)d.Dq; t /= (unsigned)d.Dq;
+    const int n = (int)t;
+    const long long opix = (((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo +
+                           (qw * d.osw + d.opw);
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+      const int ch = ch_tile * BCH + wch + a * 16 + lg * 4;
+      if (ch >= d.Cout) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (d.bias) {
+        const float* bp = d.bias + (long long)n * d.bias_stride + ch;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bp[e];
+      }
+      const long long o = opix * d.ldo + ch;
+      if (d.res_mode == RES_PRE_ACT) {
+        float rv[4];
+        load4(res + o, rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
+      if (d.res_mode == RES_POST_ACT) {
+        float rv[4];
+        load4(res + o, rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+      store4(out + o, v);
+    }
+  }
+}
+
+template <typename T>
+static int launch_v3(ConvDesc d, hipStream_t s) {
+  constexpr int BCH = 128, BPIX = 256;
+  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4);
+  d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
+  d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
+  const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
+  RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_done = true;
+  }
+  const int variant = (sizeof(T) == 2 ? 4 : 0) + 3;
+  prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL(conv_igemm_v3_kernel<T>, dim3((unsigned)nblk), dim3(512), LDS, s, d);
+  prof_end_launch(s);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int BCH, int BPIX>
 static int launch_one_g(ConvDesc d, hipStream_t s) {
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
@@ -229,6 +434,9 @@ static int launch_t_g(const ConvDesc& d, hipStream_t s) {
 }
 
 int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
+  // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
+  if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256)
+    return dtype == BF16 ? launch_v3<unsigned short>(d, s) : launch_v3<float>(d, s);
   return dtype == BF16 ? launch_t_g<unsigned short>(d, s) : launch_t_g<float>(d, s);
 }
 
