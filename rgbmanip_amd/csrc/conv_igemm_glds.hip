@@ -51,7 +51,12 @@ __device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
   return v;
 }
 
-template <typename T, int BCH, int BPIX>
+// UNI: every K tile lies inside ONE filter tap (Cin is a multiple of BK, or the conv is 1x1), so the tap walk is
+// wave-uniform scalar work and a gathered row costs ~6 VALU per K tile: per-row source pointer of tap (0,0,0) and a
+// (kd | kh<<8 | kw<<16) validity bit mask are built once in the prologue; per tile the lane adds a scalar byte
+// offset and tests the mask.  (The general path recomputes tap -> (kd,kh,kw) -> 64-bit address per lane per tile,
+// ~35 VALU with quarter-rate integer multiplies per row: measured, it cost more issue time than the MFMAs.)
+template <typename T, int BCH, int BPIX, bool UNI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc d) {
   constexpr int E = 16 / sizeof(T);
   constexpr int BK = 8 * E;
@@ -82,6 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
   const int r0 = tid >> 3;
   const int js = j ^ ((r0 >> 1) & 7);       // ((r0 + 32*i) >> 1) & 7 == (r0 >> 1) & 7
   int xn[XR], xd0[XR], xh0[XR], xw0[XR];
+  const char* rowp[XR];
+  unsigned rmask[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     const long long m = (long long)pix_tile * BPIX + r0 + 32 * i;
@@ -97,42 +104,72 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
     } else {
       xn[i] = 0; xd0[i] = -(1 << 20); xh0[i] = 0; xw0[i] = 0;
     }
+    if (UNI) {
+      unsigned mk = 0;
+      for (int k = 0; k < d.KD; ++k) mk |= (unsigned)((unsigned)(xd0[i] + k * d.dild) < (unsigned)d.Di) << k;
+      for (int k = 0; k < d.KH; ++k) mk |= (unsigned)((unsigned)(xh0[i] + k * d.dilh) < (unsigned)d.Hi) << (8 + k);
+      for (int k = 0; k < d.KW; ++k) mk |= (unsigned)((unsigned)(xw0[i] + k * d.dilw) < (unsigned)d.Wi) << (16 + k);
+      rmask[i] = mk;
+      const long long pix0 = ((long long)(xn[i] + xd0[i]) * d.Hi + xh0[i]) * d.Wi + xw0[i];
+      rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+    }
   }
   const float rcp_khw = 1.0f / (float)(d.KH * d.KW);
   const float rcp_kw = 1.0f / (float)d.KW;
   const int khw = d.KH * d.KW;
   const bool wload = (BCH >= 32) || (wave < BCH / 8);      // wave-uniform
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
+  const char* wrow[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i)
+    wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + r0 + 32 * i) * d.Kpad + js * E);
+  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // UNI: wave-uniform tap walker (issue() is called with kt = 0,1,2,...)
 
   auto issue = [&](int kt, int stage) {
-    const int k = kt * BK + js * E;
-    int tap, c;
-    bool tapok;
-    if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
-    else { tap = 0; c = k; tapok = k < d.Cin; }
-    const int kd = (int)(((float)tap + 0.5f) * rcp_khw);
-    const int rem = tap - kd * khw;
-    const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
-    const int kw = rem - kh * d.KW;
-    const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
     uint4* W = lds + stage * STAGE;
     uint4* X = W + BCH * 8;
+    if (UNI) {
+      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+      const long long soff =
+          ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * (long long)sizeof(T);
+      const bool cok = tkd < d.KD && tc + js * E < d.Cin;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
-      const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
-      const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
-      const T* src = ok ? in + pix * d.Cin + c : zero;
-      // wave-uniform LDS base of this wave's 64 consecutive slots; the hardware adds lane*16 bytes
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
+      for (int i = 0; i < XR; ++i) {
+        const bool ok = cok && (rmask[i] & sel) == sel;
+        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
+      }
+      tc += BK;
+      if (d.lcin >= 0 && tc >= d.Cin) {
+        tc = 0;
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      }
+    } else {
+      const int k = kt * BK + js * E;
+      int tap, c;
+      bool tapok;
+      if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
+      else { tap = 0; c = k; tapok = k < d.Cin; }
+      const int kd = (int)(((float)tap + 0.5f) * rcp_khw);
+      const int rem = tap - kd * khw;
+      const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
+      const int kw = rem - kh * d.KW;
+      const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
+        const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
+        const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
+        const T* src = ok ? in + pix * d.Cin + c : zero;
+        // wave-uniform LDS base of this wave's 64 consecutive slots; the hardware adds lane*16 bytes
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
+      }
     }
+    const long long wk = (long long)kt * BK * (long long)sizeof(T);
     if (wload) {
 #pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int row = ch_tile * BCH + r0 + 32 * i;
-        const T* src = wgt + (long long)row * d.Kpad + kt * BK + js * E;
-        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
-      }
+      for (int i = 0; i < WL; ++i)
+        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
     }
   };
 
@@ -226,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
 // iteration kt, the wait in front of that barrier is `vmcnt(6)` (the 6 LDS-DMA instructions of tile kt+1 may stay
 // outstanding), never 0 inside the loop.  Raw s_barrier + inline waits: __syncthreads() would drain the DMA queue.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool UNI>
 __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d) {
   constexpr int BCH = 128, BPIX = 256;
   constexpr int E = 16 / sizeof(T);
@@ -254,6 +291,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
   const int r0 = tid >> 3;                   // 0..63
   const int js = j ^ ((r0 >> 1) & 7);
   int xn[XR], xd0[XR], xh0[XR], xw0[XR];
+  const char* rowp[XR];
+  unsigned rmask[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     const long long m = (long long)pix_tile * BPIX + r0 + 64 * i;
@@ -269,38 +308,71 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
     } else {
       xn[i] = 0; xd0[i] = -(1 << 20); xh0[i] = 0; xw0[i] = 0;
     }
+    if (UNI) {
+      unsigned mk = 0;
+      for (int k = 0; k < d.KD; ++k) mk |= (unsigned)((unsigned)(xd0[i] + k * d.dild) < (unsigned)d.Di) << k;
+      for (int k = 0; k < d.KH; ++k) mk |= (unsigned)((unsigned)(xh0[i] + k * d.dilh) < (unsigned)d.Hi) << (8 + k);
+      for (int k = 0; k < d.KW; ++k) mk |= (unsigned)((unsigned)(xw0[i] + k * d.dilw) < (unsigned)d.Wi) << (16 + k);
+      rmask[i] = mk;
+      const long long pix0 = ((long long)(xn[i] + xd0[i]) * d.Hi + xh0[i]) * d.Wi + xw0[i];
+      rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+    }
   }
   const float rcp_khw = 1.0f / (float)(d.KH * d.KW);
   const float rcp_kw = 1.0f / (float)d.KW;
   const int khw = d.KH * d.KW;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
+  const char* wrow[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i)
+    wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + r0 + 64 * i) * d.Kpad + js * E);
+  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // UNI: wave-uniform tap walker (issue() is called with kt = 0,1,2,...)
 
   auto issue = [&](int kt, int stage) {
-    const int k = kt * BK + js * E;
-    int tap, c;
-    bool tapok;
-    if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
-    else { tap = 0; c = k; tapok = k < d.Cin; }
-    const int kd = (int)(((float)tap + 0.5f) * rcp_khw);
-    const int rem = tap - kd * khw;
-    const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
-    const int kw = rem - kh * d.KW;
-    const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
     uint4* W = lds3 + stage * STAGE;
     uint4* X = W + BCH * 8;
+    if (UNI) {
+      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+      const long long soff =
+          ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * (long long)sizeof(T);
+      const bool cok = tkd < d.KD && tc + js * E < d.Cin;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
-      const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
-      const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
-      const T* src = ok ? in + pix * d.Cin + c : zero;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
+      for (int i = 0; i < XR; ++i) {
+        const bool ok = cok && (rmask[i] & sel) == sel;
+        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
+      }
+      tc += BK;
+      if (d.lcin >= 0 && tc >= d.Cin) {
+        tc = 0;
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      }
+    } else {
+      const int k = kt * BK + js * E;
+      int tap, c;
+      bool tapok;
+      if (d.lcin >= 0) { tap = k >> d.lcin; c = k & (d.Cin - 1); tapok = tap < d.ntaps; }
+      else { tap = 0; c = k; tapok = k < d.Cin; }
+      const int kd = (int)(((float)tap + 0.5f) * rcp_khw);
+      const int rem = tap - kd * khw;
+      const int kh = (int)(((float)rem + 0.5f) * rcp_kw);
+      const int kw = rem - kh * d.KW;
+      const int od = kd * d.dild, oh = kh * d.dilh, ow = kw * d.dilw;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const int dd = xd0[i] + od, hh = xh0[i] + oh, ww = xw0[i] + ow;
+        const bool ok = tapok && (unsigned)dd < (unsigned)d.Di && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
+        const long long pix = ((long long)(xn[i] + dd) * d.Hi + hh) * d.Wi + ww;
+        const T* src = ok ? in + pix * d.Cin + c : zero;
+        // wave-uniform LDS base of this wave's 64 consecutive slots; the hardware adds lane*16 bytes
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
+      }
     }
+    const long long wk = (long long)kt * BK * (long long)sizeof(T);
+    if (true) {
 #pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int row = ch_tile * BCH + r0 + 64 * i;
-      const T* src = wgt + (long long)row * d.Kpad + kt * BK + js * E;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
+      for (int i = 0; i < WL; ++i)
+        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
     }
   };
 
@@ -388,7 +460,14 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
   }
 }
 
-template <typename T>
+// every K tile inside one tap (see the UNI comment at the 2-stage kernel)
+static bool conv_uniform_taps(const ConvDesc& d, int bk) {
+  if (d.KD > 8 || d.KH > 8 || d.KW > 8) return false;
+  if (d.lcin < 0) return d.ntaps == 1;
+  return d.Cin % bk == 0;
+}
+
+template <typename T, bool UNI>
 static int launch_v3(ConvDesc d, hipStream_t s) {
   constexpr int BCH = 128, BPIX = 256;
   constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4);
@@ -398,18 +477,18 @@ static int launch_v3(ConvDesc d, hipStream_t s) {
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   static bool attr_done = false;
   if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T, UNI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_done = true;
   }
   const int variant = (sizeof(T) == 2 ? 4 : 0) + 3;
   prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL(conv_igemm_v3_kernel<T>, dim3((unsigned)nblk), dim3(512), LDS, s, d);
+  hipLaunchKernelGGL((conv_igemm_v3_kernel<T, UNI>), dim3((unsigned)nblk), dim3(512), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-template <typename T, int BCH, int BPIX>
+template <typename T, int BCH, int BPIX, bool UNI>
 static int launch_one_g(ConvDesc d, hipStream_t s) {
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
@@ -417,27 +496,33 @@ static int launch_one_g(ConvDesc d, hipStream_t s) {
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const int variant = (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
   prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<T, BCH, BPIX>), dim3((unsigned)nblk), dim3(256), 0, s, d);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<T, BCH, BPIX, UNI>), dim3((unsigned)nblk), dim3(256), 0, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-template <typename T>
+template <typename T, bool UNI>
 static int launch_t_g(const ConvDesc& d, hipStream_t s) {
   switch (conv_ch_tile(d.Cout)) {
-    case 16: return launch_one_g<T, 16, 256>(d, s);
-    case 32: return launch_one_g<T, 32, 256>(d, s);
-    case 64: return launch_one_g<T, 64, 256>(d, s);
-    default: return launch_one_g<T, 128, 128>(d, s);
+    case 16: return launch_one_g<T, 16, 256, UNI>(d, s);
+    case 32: return launch_one_g<T, 32, 256, UNI>(d, s);
+    case 64: return launch_one_g<T, 64, 256, UNI>(d, s);
+    default: return launch_one_g<T, 128, 128, UNI>(d, s);
   }
 }
 
-int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
+template <typename T>
+static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
+  const bool uni = conv_uniform_taps(d, 8 * (16 / (int)sizeof(T))) && !(g_debug_flags & 16);
   // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256)
-    return dtype == BF16 ? launch_v3<unsigned short>(d, s) : launch_v3<float>(d, s);
-  return dtype == BF16 ? launch_t_g<unsigned short>(d, s) : launch_t_g<float>(d, s);
+    return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
+  return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
+}
+
+int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
+  return dtype == BF16 ? launch_dtype_g<unsigned short>(d, s) : launch_dtype_g<float>(d, s);
 }
 
 }  // namespace rgbm
