@@ -54,8 +54,8 @@ int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* 
 int rgbm_adapose_destroy(rgbm_adapose_t* h);
 /* views per cost-volume chunk (default 32); bounds the workspace */
 int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
-/* options: "max_chunk" (views per cost-volume chunk), "cost_impl" (2 = halo-tiled 3-D convs with the plane-sweep
- * volume fused into conv0's loader [default]; 1 = halo-tiled convs on a materialised volume; 0 = generic implicit
+/* options: "max_chunk" (views per cost-volume chunk), "cost_impl" (3 = 2 with the depth-sweeping conv0 kernel [default for bf16;
+ * fp32 nets run 2]; 2 = halo-tiled 3-D convs with the plane-sweep volume fused into conv0's loader; 1 = halo-tiled convs on a materialised volume; 0 = generic implicit
  * GEMM on a materialised volume).  Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
@@ -145,6 +145,13 @@ int rgbm_adaptive_avgpool(int dtype, const void* in_dev, void* out_dev, int V, i
  * depths [B][D] f32 -> vol [V][D][H][W][32]; homog_scratch: V*12 floats */
 int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
                       void* vol_dev, int V, int B, int D, int H, int W, void* stream);
+/* conv0 of the cost-regularisation net with the plane sweep fused in, depth-sweeping kernel (bf16 only; what
+ * cost_impl = 3 runs): feat [V][H][W][32] bf16 (views 0..B-1 = view 1, B..2B-1 = view 2), P_views [V][4][4], depths [B][D],
+ * homog_scratch [V*12] floats, w_host [8][32][3][3][3] + folded BatchNorm scale/shift [8] on the host ->
+ * out [V][D][H][W][8] bf16 = ReLU(BN(conv3d(feat[v] + homo_warping(feat[partner(v)])))) (network_v5.py:262,378-430). */
+int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                     const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
+                     int V, int B, int D, int H, int W, void* stream);
 /* debugging access to a named intermediate of the last rgbm_adapose_forward on (h, B, workspace):
  * converts it to fp32 into out_dev (elems = capacity in floats); *n_elems returns its size.  Intermediates of the
  * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first. */

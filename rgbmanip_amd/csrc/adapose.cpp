@@ -144,6 +144,18 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
+      if (i == 0 && dtype == BF16) {
+        // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip)
+        conv0_sweep_pack(w->data, scale.data(), packed);
+        std::vector<unsigned short> h(packed.size());
+        for (size_t k = 0; k < packed.size(); ++k) {
+          unsigned u; memcpy(&u, &packed[k], 4);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          h[k] = (unsigned short)(u >> 16);
+        }
+        RGBM_CHECK_HIP(hipMalloc(&sweep_w, h.size() * 2));
+        RGBM_CHECK_HIP(hipMemcpy(sweep_w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      }
     }
   }
   {
@@ -201,6 +213,8 @@ void AdaPose::destroy() {
   for (auto& l : pm1) l.destroy();
   for (auto& l : pm2) l.destroy();
   for (auto& t : t3d) { if (t.w) (void)hipFree(t.w); if (t.bias) (void)hipFree(t.bias); t.w = nullptr; t.bias = nullptr; }
+  if (sweep_w) (void)hipFree(sweep_w);
+  sweep_w = nullptr;
   if (wprob) (void)hipFree(wprob);
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
@@ -261,7 +275,7 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   const int Vc = chunk_views(V);
   const int D = n_depth;
   const size_t vox = (size_t)D * S * S;
-  bf.vol = cost_impl == 2 ? nullptr : A.alloc((size_t)Vc * vox * 32 * es);   // fused-warp conv0 never materialises it
+  bf.vol = cost_impl >= 2 ? nullptr : A.alloc((size_t)Vc * vox * 32 * es);   // fused-warp conv0 never materialises it
   bf.c[0] = A.alloc((size_t)Vc * vox * 8 * es);
   bf.c[1] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
   bf.c[2] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
@@ -347,6 +361,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);
+    if (layer == 10 && cost_impl == 3 && dtype == BF16 && sweep_w) { d.wgt = sweep_w; return launch_conv0_sweep(d, s); }
     return launch_conv3d_tile(layer, dtype, d, s);
   };
   for (int v0 = 0; cost_impl >= 1 && v0 < V; v0 += Vc0) {

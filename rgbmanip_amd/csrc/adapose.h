@@ -32,7 +32,9 @@ struct AdaPose {
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
   struct Tile3d { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0; };
   Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11
-  int cost_impl = 2;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp
+  void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (bf16 nets only)
+  int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,
+                                // 3 = 2 with the depth-sweeping conv0 kernel (bf16; fp32 nets run 2)
   float* wprob = nullptr;
   ConvLayer inst, nh[3], npm[2], pm1[2], pm2[2];
   float* pm2_0_wfull = nullptr;

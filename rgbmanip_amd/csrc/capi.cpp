@@ -60,7 +60,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   RGBM_REQUIRE(h && key, "set_option arguments");
   const std::string k = key;
   if (k == "max_chunk") { RGBM_REQUIRE(value > 0, "max_chunk"); h->net.max_chunk = value; }
-  else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 2, "cost_impl"); h->net.cost_impl = value; }
+  else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   return 0;
 }
@@ -229,6 +229,35 @@ extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N,
   }
   d.Cout = cout[layer]; d.relu = 1; d.prof_variant = -1;
   int rc = launch_conv3d_tile(layer, dtype, d, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  (void)hipFree(wdev); (void)hipFree(bdev);
+  return rc;
+}
+
+// Kernel-level entry for the depth-sweeping conv0 + fused plane sweep (tests): bf16 features [V][H][W][32] -> [V][D][H][W][8].
+extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                                const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
+                                int V, int B, int D, int H, int W, void* stream) {
+  RGBM_REQUIRE(feat_dev && P_views_dev && depths_dev && homog_scratch && w_host && bn_scale_host && bn_shift_host && out_dev,
+               "conv0_sweep arguments");
+  if (int rc = launch_homography(P_views_dev, homog_scratch, V, B, (hipStream_t)stream)) return rc;
+  std::vector<float> packed;
+  conv0_sweep_pack(w_host, bn_scale_host, packed);
+  std::vector<unsigned short> h(packed.size());
+  for (size_t k = 0; k < packed.size(); ++k) { unsigned u; memcpy(&u, &packed[k], 4); u += 0x7fffu + ((u >> 16) & 1u); h[k] = (unsigned short)(u >> 16); }
+  void* wdev = nullptr; float* bdev = nullptr;
+  RGBM_CHECK_HIP(hipMalloc(&wdev, h.size() * 2));
+  RGBM_CHECK_HIP(hipMemcpy(wdev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  std::vector<float> bpad(16, 0.f);
+  for (int o = 0; o < 8; ++o) bpad[o] = bn_shift_host[o];
+  if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;
+  Conv3dTileDesc d;
+  memset(&d, 0, sizeof(d));
+  d.wgt = wdev; d.out = out_dev; d.bias = bdev;
+  d.N = V; d.Di = D; d.Hi = H; d.Wi = W; d.Do = D; d.Ho = H; d.Wo = W; d.Dq = D; d.Hq = H; d.Wq = W;
+  d.Cout = 8; d.relu = 1; d.prof_variant = -1;
+  d.feat = feat_dev; d.homog = homog_scratch; d.depths = depths_dev; d.v0 = 0; d.V = V; d.B = B;
+  int rc = launch_conv0_sweep(d, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;

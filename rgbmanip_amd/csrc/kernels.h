@@ -51,6 +51,10 @@ void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int
                       std::vector<float>& packed);
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);
 
+// conv0_sweep.hip — conv0 + fused plane sweep, depth-sweeping producer/consumer kernel (bf16 only)
+void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& packed);
+int launch_conv0_sweep(const Conv3dTileDesc& d, hipStream_t s);
+
 // postproc.hip
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
                        const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s);

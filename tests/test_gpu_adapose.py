@@ -123,7 +123,7 @@ def test_fp32_batch_invariance_and_chunking():
             assert _rel(out3[k][b:b + 1], o1[k]) < 1e-5, (b, k)
 
 
-@pytest.mark.parametrize("cost_impl", [2, 0])
+@pytest.mark.parametrize("cost_impl", [3, 2, 0])
 def test_bf16_close_to_golden(inputs, golden_dir, cost_impl):
     """bf16 storage / fp32 accumulate: the throughput mode.  The bound is what 8-bit mantissas allow through a
     ~60-layer un-normalised network; the measured errors are printed and recorded in DESIGN.md."""
@@ -134,6 +134,24 @@ def test_bf16_close_to_golden(inputs, golden_dir, cost_impl):
     for k in OUT_KEYS:
         assert np.isfinite(out[k]).all(), k
     assert errs["view1_depth"] < 3e-2 and errs["view1_nocs"] < 1e-1 and errs["view1_r"] < 1.5e-1, errs
+
+
+def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
+    """cost_impl 3 (depth-sweeping conv0, conv0_sweep.hip) vs 2 (halo-tile conv0): same bf16 features and weights, fp32
+    accumulation in a different order, so c0 may differ by one bf16 rounding at most; both stay close to the oracle."""
+    _, taps = oracle_taps
+    c0 = {}
+    for ci in (2, 3):
+        net = _net("bf16", cost_impl=ci)
+        _run(net, inputs, stop_after=2)
+        c0[ci] = net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).view(4, 24, 224, 224, 8).cpu().numpy()
+    scale = np.abs(c0[2]).max()
+    assert np.abs(c0[3] - c0[2]).max() / scale < 8e-3
+    assert np.abs(c0[3] - c0[2]).mean() / np.abs(c0[2]).mean() < 1e-3
+    ref = taps["v1_c0"].numpy()                                   # [2,8,24,224,224]
+    for ci in (2, 3):
+        got = np.transpose(c0[ci][:2], (0, 4, 1, 2, 3))
+        assert _rel(got, ref) < 2e-2, ci
 
 
 def test_nan_projection_stays_per_sample(inputs):

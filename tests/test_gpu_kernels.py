@@ -295,3 +295,70 @@ def test_conv3d_tile_layers(layer, dtype):
     y2 = from_channels_last(out2)
     assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
     assert torch.isnan(y2[1]).any()
+
+
+def _sweep_case(B, D, H, W, seed, singular_pose=None):
+    """Random bf16 features + a two-view rig scaled to an HxW image: returns (feat NCHW float, P [V,4,4], depths [B,D])."""
+    g = torch.Generator().manual_seed(seed)
+    V = 2 * B
+    feat = torch.randn(V, 32, H, W, generator=g).bfloat16().float()
+    K = np.array([[0.9 * W, 0, W / 2.0, 0], [0, 0.9 * W, H / 2.0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    P = np.zeros((V, 4, 4), dtype=np.float32)
+    for b in range(B):
+        a = 0.08 * (b + 1)
+        E2 = np.eye(4)
+        E2[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        E2[:3, 3] = [0.12 * (b + 1), -0.05, 0.02]
+        P[b] = K @ np.eye(4)
+        P[B + b] = K @ E2
+    if singular_pose is not None:
+        P[B + singular_pose] = 0.0
+        P[B + singular_pose, 3, 3] = 1.0
+    depths = np.stack([np.linspace(0.6 + 0.1 * b, 1.6 + 0.1 * b, D) for b in range(B)]).astype(np.float32)
+    return feat, torch.from_numpy(P), torch.from_numpy(depths)
+
+
+@pytest.mark.parametrize("shape", [(5, 20, 37), (1, 16, 16), (24, 33, 16), (3, 48, 50)])
+def test_conv0_sweep_matches_volume_then_conv(shape):
+    """Depth-sweeping conv0 (plane sweep fused, paired depth taps, producer/consumer waves) against the two kernels it
+    replaces run one after the other: build_volume (pinned to the reference's homo_warping golden above) followed by a
+    plain fp32 conv3d + folded BN + ReLU on that bf16 volume.  Ragged tiles in H and W, D = 1, and NaN isolation."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, host_f32
+    lib = _lib.load()
+    D, H, W = shape
+    B, V = 2, 4
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) / np.sqrt(32 * 27)
+    scale = torch.rand(8, generator=g) + 0.5
+    shift = torch.randn(8, generator=g) * 0.1
+    wf = (w * scale.view(-1, 1, 1, 1, 1)).bfloat16().float()
+    wa, wp = host_f32(w)
+    sa, sp = host_f32(scale)
+    ha, hp = host_f32(shift)
+
+    def run(singular_pose):
+        feat, P, dep = _sweep_case(B, D, H, W, seed=11, singular_pose=singular_pose)
+        fd = to_channels_last(feat, _lib.BF16)
+        Pd, dd = P.cuda(), dep.cuda()
+        hom = torch.empty(V * 12, dtype=torch.float32, device="cuda")
+        vol = torch.empty(V, D, H, W, 32, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.rgbm_build_volume(_lib.BF16, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), _lib.ptr(vol),
+                                         V, B, D, H, W, _lib.stream_ptr()), "rgbm_build_volume")
+        out = torch.full((V, D, H, W, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.rgbm_conv0_sweep(_lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out),
+                                        V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep")
+        torch.cuda.synchronize()
+        x = vol.float().cpu().permute(0, 4, 1, 2, 3)
+        ref = F.relu(F.conv3d(x, wf, None, 1, 1) + shift.view(1, -1, 1, 1, 1))
+        return from_channels_last(out), ref, x
+
+    y, ref, x = run(None)
+    assert torch.isfinite(y).all()
+    # some projections must land inside and some outside the partner image, or the case tests nothing
+    assert rel_err(y, ref) < 1e-2, shape                       # one bf16 rounding of the output
+    assert float((y - ref).abs().mean() / ref.abs().mean()) < 2e-3
+    y2, ref2, _ = run(1)                                       # pose 1 = views 1 and 3 gets a singular view-2 projection
+    assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
+    assert torch.isnan(y2[1]).any() and torch.isnan(y2[3]).any()
+    nan_ref = torch.isnan(ref2)
+    assert torch.equal(torch.isnan(y2), nan_ref)
