@@ -3,14 +3,14 @@
 // bf16 kernel for gfx950.  Replaces the halo-tile kernel (conv3d_tile.hip, layer 10) whose staging, MFMA and store
 // phases ran back to back: all blocks of a launch march through identical phases in lock step, so nothing overlaps.
 //
-// One workgroup owns a 16x16 (H x W) column of one view and sweeps it through all D depth planes:
-//   * producer waves (6): one thread per voxel of the 18x18 input plane incl. halo.  The thread keeps the reference
+// One workgroup owns a 12x16 (H x W) column of one view and sweeps it through all D depth planes:
+//   * producer waves (4, one per SIMD): one thread per voxel of the 14x18 input plane incl. halo.  The thread keeps the reference
 //     feature of its pixel in registers for the whole sweep; per plane it projects the pixel with that plane's depth,
-//     gathers the 4 bilinear corners of the partner view's feature map (corners outside the image are pointed at a zero
-//     page: grid_sample padding_mode="zeros"), blends in fp32, rounds to bf16 and writes the 64-byte voxel into one of
-//     two LDS plane slots.  The corner loads of plane z+1 are issued before plane z is blended (two half-voxel register
-//     sets), so gather latency is covered by VALU work.  Halo redundancy is 324/256 = 1.27x (the 4x8x8 tile: 2.34x).
-//   * consumer waves (4): MFMA 16x16x32 bf16, input-plane stationary.  Cout = 8 fills only half of the 16 MFMA rows,
+//     gathers the 4 bilinear corners of the partner view's feature map (corners outside the image get weight 0:
+//     grid_sample padding_mode="zeros"), blends in fp32, rounds to bf16 and writes the 64-byte voxel into one of
+//     two LDS plane slots.  The corner loads of plane z+1 are issued before plane z is blended (two register sets), so
+//     gather latency is covered by VALU work.  Halo redundancy is 252/192 = 1.31x (the 4x8x8 tile: 2.34x).
+//   * consumer waves (3): MFMA 16x16x32 bf16, input-plane stationary.  Cout = 8 fills only half of the 16 MFMA rows,
 //     so two depth taps share one instruction: A01[t] = rows 0-7 W(kd=0,t), rows 8-15 W(kd=1,t); A2[t] = rows 8-15
 //     W(kd=2,t).  For input plane p and in-plane tap t:  X[p] += A01[t]*B,  X[p-1] += A2[t]*B  (same B register), hence
 //     out[o] = rows 8-15 of X[o] (kd=1 from plane o, kd=2 from plane o+1)  +  rows 0-7 of X[o-1] (kd=0 from plane o-1).
@@ -26,16 +26,20 @@ namespace rgbm {
 
 namespace {
 
-constexpr int SW_TH = 16, SW_TW = 16;
+// Tile: SW_TH x 16 output voxels per plane.  TH = 12 makes the input plane incl. halo 14 x 18 = 252 voxels = four
+// producer waves with 98 % of their lanes busy, ONE per SIMD: the producers are VALU-issue bound (a wave64 VALU
+// instruction holds a SIMD's issue port for 4 cycles; measured, the first 16x16 version put two producer waves on two
+// of the SIMDs and ran at their pace), so lanes per instruction and waves per SIMD are what set the speed.
+constexpr int SW_TH = 12, SW_TW = 16;
 constexpr int SW_HH = SW_TH + 2, SW_HW = SW_TW + 2;
-constexpr int SW_NV = SW_HH * SW_HW;             // 324 voxels per input plane
+constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
 constexpr int SW_VS = 80;                        // LDS bytes per voxel: 64 data + 16 pad (conflict-free b128 rows)
-constexpr int SW_SLOT = SW_NV * SW_VS;           // 25920
-constexpr int SW_NPW = 6, SW_NCW = 4;            // producer / consumer waves
+constexpr int SW_SLOT = SW_NV * SW_VS;           // 20160
+constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
+constexpr int SW_NCW = SW_TH / 4;                // 3 consumer waves, 4 fragments (rows) each
 constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
 constexpr int SW_LDS = 2 * SW_SLOT;
-
-__device__ uint4 g_sweep_zero[4];                // 64 zero bytes: the "feature" of every out-of-image corner
+static_assert(SW_TH % 4 == 0, "a consumer wave owns 4 rows");
 
 struct SweepDesc {
   const unsigned short* feat;     // [V][H][W][32] bf16
@@ -47,37 +51,30 @@ struct SweepDesc {
   int N, D, H, W, v0, V, B, nth, ntw, relu, dbg;
 };
 
-__device__ __forceinline__ void sweep_ixy(const float* __restrict__ hm, float x, float y, float depth, int H, int W, float& ix,
-                                          float& iy) {
-  // same arithmetic as warp_ixy (conv3d_tile.hip) / build_volume: homography, perspective divide, the reference's
-  // align_corners=True normalisation followed by grid_sample's align_corners=False un-normalisation
-  const float rx = hm[0] * x + hm[1] * y + hm[2];
-  const float ry = hm[3] * x + hm[4] * y + hm[5];
-  const float rz = hm[6] * x + hm[7] * y + hm[8];
-  const float px = rx * depth + hm[9], py = ry * depth + hm[10], pz = rz * depth + hm[11];
-  const float u = px / pz, vv = py / pz;
-  const float gx = u / ((float)(W - 1) / 2.f) - 1.f;
-  const float gy = vv / ((float)(H - 1) / 2.f) - 1.f;
-  ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
-  iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
-}
-
 struct Corner {                     // everything the blend of one plane needs besides the gathered data
-  const unsigned short* p[4];       // 4 corner pointers (zero page when outside)
-  float w[4];                       // bilinear weights (NaN when the projection is not finite, like the reference)
+  unsigned off[4];                  // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
+  float w[4];                       // bilinear weights: 0 for a corner outside the image, NaN for a non-finite projection
 };
 
-__device__ __forceinline__ uint4 blend_chunk(const uint4& r, const uint4& a, const uint4& b, const uint4& c, const uint4& e,
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;     // native vector: usable as a tied inline-asm operand
+
+__device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
                                              const float* w) {
-  float fr[8], fa[8], fb[8], fc[8], fe[8], o[8];
-  unpack_chunk(r, fr, (unsigned short)0);
-  unpack_chunk(a, fa, (unsigned short)0);
-  unpack_chunk(b, fb, (unsigned short)0);
-  unpack_chunk(c, fc, (unsigned short)0);
-  unpack_chunk(e, fe, (unsigned short)0);
+  const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
+  const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
+  unsigned o[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) o[q] = fr[q] + (((fa[q] * w[0] + fb[q] * w[1]) + fc[q] * w[2]) + fe[q] * w[3]);
-  return pack_chunk(o, (unsigned short)0);
+  for (int q = 0; q < 4; ++q) {       // one dword = two bf16 channels -> one packed-f32 lane pair
+    const f32x2 fr = {__uint_as_float(rr[q] << 16), __uint_as_float(rr[q] & 0xffff0000u)};
+    const f32x2 fa = {__uint_as_float(aa[q] << 16), __uint_as_float(aa[q] & 0xffff0000u)};
+    const f32x2 fb = {__uint_as_float(bb[q] << 16), __uint_as_float(bb[q] & 0xffff0000u)};
+    const f32x2 fc = {__uint_as_float(cc[q] << 16), __uint_as_float(cc[q] & 0xffff0000u)};
+    const f32x2 fe = {__uint_as_float(ee[q] << 16), __uint_as_float(ee[q] & 0xffff0000u)};
+    const f32x2 v = fr + (((fa * w[0] + fb * w[1]) + fc * w[2]) + fe * w[3]);
+    o[q] = pack2_bf16(v.x, v.y);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 __device__ __forceinline__ f32x4 mma_bf16(const uint4& a, const uint4& b, const f32x4& c) {
@@ -103,7 +100,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 
   if (wave < SW_NPW) {
     // ------------------------------------------------------------------ producers
-    const int pv = tid;                                  // voxel of the 18x18 plane
+    const int pv = tid;                                  // voxel of the (TH+2) x 18 plane
     const bool act = pv < SW_NV;
     const int hh = pv / SW_HW, hw = pv - hh * SW_HW;
     const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
@@ -111,89 +108,105 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
     const int partner = (vv + d.B) % d.V, bb = vv % d.B;
     const float* __restrict__ hm = d.homog + (long long)vv * 12;
     const float* __restrict__ dep = d.depths + (long long)bb * D;
-    const unsigned short* __restrict__ srcb = d.feat + (long long)partner * H * W * 32;
-    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_sweep_zero);
+    const unsigned char* __restrict__ srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
     unsigned char* dst0 = planes + pv * SW_VS;
 
     uint4 ref[4];
-    {
-      const unsigned short* pr = inb ? d.feat + (((long long)vv * H + gh) * W + gw) * 32 : zero;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ref[k] = make_uint4(0u, 0u, 0u, 0u);    // outside the image: conv zero padding
+    if (inb) {
+      const unsigned short* pr = d.feat + (((long long)vv * H + gh) * W + gw) * 32;
 #pragma unroll
       for (int k = 0; k < 4; ++k) ref[k] = *reinterpret_cast<const uint4*>(pr + k * 8);
     }
 
+    // Projection of this pixel: (rx,ry,rz) = rot * (x,y,1) once; per plane p = r*depth + t, one reciprocal, and the
+    // reference's align_corners=True normalisation + grid_sample's align_corners=False un-normalisation folded into
+    // ix = u*W/(W-1) - 0.5.  Algebraically network_v5.py:378-430; rounding differs from the fp32 kernels in the last
+    // ulps of the coordinate (1e-5 pixel), far below one bf16 step of the blended value.
+    const float x = (float)gw, y = (float)gh;
+    const float rx = hm[0] * x + hm[1] * y + hm[2];
+    const float ry = hm[3] * x + hm[4] * y + hm[5];
+    const float rz = hm[6] * x + hm[7] * y + hm[8];
+    const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
+    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+
+    // the D depths of this pose live in one VGPR (lane z holds depth z): a per-plane scalar read instead of a memory load
+    const int dbits = __float_as_int(lane < D ? dep[lane] : 1.f);
+
     auto corners = [&](int z, Corner& c) {
-      float ix, iy;
-      sweep_ixy(hm, (float)gw, (float)gh, dep[z], H, W, ix, iy);
+      const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
+      const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
+      const float rinv = __builtin_amdgcn_rcpf(pz);
+      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
       const bool fin = isfinite(ix) && isfinite(iy);
-      ix = fin ? fminf(fmaxf(ix, -4.f), 1.0e6f) : 0.f;
-      iy = fin ? fminf(fmaxf(iy, -4.f), 1.0e6f) : 0.f;
       const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fx, y0 = (int)fy;
+      const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
       const float tx = ix - fx, ty = iy - fy;
       const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
       const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
-      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-      const float nanv = __builtin_nanf("");
-      // a voxel outside the image is conv zero padding: exact 0 whatever the projection says
-      const bool usew = fin || !inb;
-      c.w[0] = usew ? (1.f - tx) * (1.f - ty) : nanv;
-      c.w[1] = usew ? tx * (1.f - ty) : nanv;
-      c.w[2] = usew ? (1.f - tx) * ty : nanv;
-      c.w[3] = usew ? tx * ty : nanv;
-      c.p[0] = (inb && xin0 && yin0) ? srcb + ((long long)yc0 * W + xc0) * 32 : zero;
-      c.p[1] = (inb && xin1 && yin0) ? srcb + ((long long)yc0 * W + xc1) * 32 : zero;
-      c.p[2] = (inb && xin0 && yin1) ? srcb + ((long long)yc1 * W + xc0) * 32 : zero;
-      c.p[3] = (inb && xin1 && yin1) ? srcb + ((long long)yc1 * W + xc1) * 32 : zero;
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+      // grid_sample padding_mode="zeros": a corner outside the image contributes 0 (its clamped address is read, times 0);
+      // a voxel outside the image is conv zero padding; a non-finite projection makes the voxel NaN like the reference
+      const float ux = 1.f - tx, uy = 1.f - ty;
+      c.w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
+      c.w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
+      c.w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
+      c.w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
+      if (inb && !fin) c.w[0] = __builtin_nanf("");
+      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+      c.off[0] = (r0 + (unsigned)xc0) * 64u;
+      c.off[1] = (r0 + (unsigned)xc1) * 64u;
+      c.off[2] = (r1 + (unsigned)xc0) * 64u;
+      c.off[3] = (r1 + (unsigned)xc1) * 64u;
     };
 
+    // One register set of 16 x 16 B: chunk k (its 4 corners) of plane z+1 is requested right after chunk k of plane z
+    // has been blended out of the same registers, so every gather has a whole step to land and each blend waits for
+    // exactly its 4 oldest loads (12 stay in flight).  The gathers are issued from inline asm with tied ("+v") operands
+    // and counted by hand: left to hipcc, its wait-count merging at the loop header plus a back-edge register copy
+    // ended every step in `s_waitcnt vmcnt(0)` (seen in the ISA), i.e. no prefetch at all.  The asm results must not be
+    // touched before gather_wait(): the empty-bodied asm there names them as in/out so every use is ordered after it.
     Corner cur, nxt;
-    uint4 ga[2][4], gb[2][4];                            // [chunk][corner] for chunks 0-1 (ga) and 2-3 (gb)
+    u32x4 g[4][4];                                       // [chunk][corner]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
+#define SW_GATHER(K, Q, OFF)                                                                                       \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
+#define SW_GATHER4(K, C) do { SW_GATHER(K, 0, (C).off[0]); SW_GATHER(K, 1, (C).off[1]); SW_GATHER(K, 2, (C).off[2]); SW_GATHER(K, 3, (C).off[3]); } while (0)
+#define SW_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     if (act) {
       corners(0, cur);
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ga[k][q] = *reinterpret_cast<const uint4*>(cur.p[q] + k * 8);
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gb[k][q] = *reinterpret_cast<const uint4*>(cur.p[q] + (2 + k) * 8);
+      SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
     }
     for (int z = 0; z <= D; ++z) {
       if (act && z < D) {
+        corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
         unsigned char* dst = dst0 + (z & 1) * SW_SLOT;
-        const bool more = z + 1 < D;
-        if (more) corners(z + 1, nxt);
-        if (!(d.dbg & 1)) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            *reinterpret_cast<uint4*>(dst + k * 16) = blend_chunk(ref[k], ga[k][0], ga[k][1], ga[k][2], ga[k][3], cur.w);
-        }
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ga[k][q] = *reinterpret_cast<const uint4*>(nxt.p[q] + k * 8);
-        }
-        if (!(d.dbg & 1)) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            *reinterpret_cast<uint4*>(dst + (2 + k) * 16) = blend_chunk(ref[2 + k], gb[k][0], gb[k][1], gb[k][2], gb[k][3], cur.w);
-        }
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gb[k][q] = *reinterpret_cast<const uint4*>(nxt.p[q] + (2 + k) * 8);
-          cur = nxt;
-        }
+        SW_WAIT12(0);
+        *reinterpret_cast<uint4*>(dst) = blend_chunk(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
+        SW_GATHER4(0, nxt);
+        SW_WAIT12(1);
+        *reinterpret_cast<uint4*>(dst + 16) = blend_chunk(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur.w);
+        SW_GATHER4(1, nxt);
+        SW_WAIT12(2);
+        *reinterpret_cast<uint4*>(dst + 32) = blend_chunk(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur.w);
+        SW_GATHER4(2, nxt);
+        SW_WAIT12(3);
+        *reinterpret_cast<uint4*>(dst + 48) = blend_chunk(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur.w);
+        SW_GATHER4(3, nxt);
+        cur = nxt;
       }
       // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+#undef SW_GATHER
+#undef SW_GATHER4
+#undef SW_WAIT12
   } else {
     // ------------------------------------------------------------------ consumers
     const int cw = wave - SW_NPW;
@@ -257,15 +270,13 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
         f32x4 Xn[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(d.dbg & 2)) {
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-              const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
-              Xn[f] = mma_bf16(A01[tp], b, Xn[f]);
-              Xp[f] = mma_bf16(A2[tp], b, Xp[f]);
-            }
+          for (int f = 0; f < 4; ++f) {
+            const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
+            Xn[f] = mma_bf16(A01[tp], b, Xn[f]);
+            Xp[f] = mma_bf16(A2[tp], b, Xp[f]);
           }
         }
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
@@ -306,7 +317,7 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, hipStream_t s) {
   d.N = t.N; d.D = t.Di; d.H = t.Hi; d.W = t.Wi; d.v0 = t.v0; d.V = t.V; d.B = t.B; d.relu = t.relu;
   d.nth = (d.H + SW_TH - 1) / SW_TH; d.ntw = (d.W + SW_TW - 1) / SW_TW;
   d.dbg = g_debug_flags;
-  RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && t.Cout == 8, "conv0 sweep arguments");
+  RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep arguments");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
   static bool attr_done = false;
