@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgbm_hip.so")
+# RGBM_HIP_LIB selects another build of the same library (kernel ablation builds made by tools/abl_sweep.sh)
+LIB_PATH = os.environ.get("RGBM_HIP_LIB") or os.path.join(_HERE, "librgbm_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3

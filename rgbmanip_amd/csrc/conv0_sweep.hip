@@ -22,6 +22,10 @@
 #include "kernels.h"
 #include "prof.h"
 
+#ifndef SW_ABL
+#define SW_ABL 0      // ablation builds only (tools/abl_sweep.sh): 1 no blend, 2 no MFMA, 4 no gathers
+#endif
+
 namespace rgbm {
 
 namespace {
@@ -176,6 +180,10 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
       for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
 #define SW_GATHER(K, Q, OFF)                                                                                       \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
+#if SW_ABL & 4
+#undef SW_GATHER
+#define SW_GATHER(K, Q, OFF) do { (void)(OFF); } while (0)
+#endif
 #define SW_GATHER4(K, C) do { SW_GATHER(K, 0, (C).off[0]); SW_GATHER(K, 1, (C).off[1]); SW_GATHER(K, 2, (C).off[2]); SW_GATHER(K, 3, (C).off[3]); } while (0)
 #define SW_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     if (act) {
@@ -187,16 +195,24 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
         corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
         unsigned char* dst = dst0 + (z & 1) * SW_SLOT;
         SW_WAIT12(0);
+#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst) = blend_chunk(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
         SW_GATHER4(0, nxt);
         SW_WAIT12(1);
+#endif
+#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 16) = blend_chunk(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur.w);
+#endif
         SW_GATHER4(1, nxt);
         SW_WAIT12(2);
+#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 32) = blend_chunk(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur.w);
+#endif
         SW_GATHER4(2, nxt);
         SW_WAIT12(3);
+#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 48) = blend_chunk(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur.w);
+#endif
         SW_GATHER4(3, nxt);
         cur = nxt;
       }
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < ((SW_ABL & 2) ? 0 : 9); ++tp) {
 #pragma unroll
           for (int f = 0; f < 4; ++f) {
             const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);

@@ -7,6 +7,10 @@
 #include "common.h"
 #include "prof.h"
 
+#ifndef IG_ABL
+#define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too, 8 = no DMA
+#endif
+
 namespace rgbm {
 
 extern int g_debug_flags;
@@ -19,11 +23,14 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // in front of the first ds_read that follows, which drains the loads of the NEXT K tile before the current one is
 // multiplied (seen in the ISA: issue -> vmcnt(0) -> ds_read -> mfma, i.e. no load/compute overlap inside a workgroup).
 // An asm DMA is invisible to that bookkeeping; completion is enforced by our own counted `s_waitcnt vmcnt(N)` + barrier.
-// lds_off: wave-uniform LDS byte address of this wave's 1 KiB slot (hardware adds lane*16); M0 is saved and restored.
+// lds_off: wave-uniform LDS byte address of this wave's 1 KiB slot (hardware adds lane*16).  M0 is left modified: nothing
+// else in these kernels reads it (gfx9+ DS instructions do not), and saving/restoring it cost 2 SALU per piece.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+#if IG_ABL & 8
+  asm volatile("" :: "v"(gsrc), "s"(lds_off) : "memory");
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_off) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: keeps the per-wave bookkeeping scalar
 
   const int nblk = gridDim.x;
   const int bq = nblk >> 3, br = nblk & 7;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
       }
       tc += BK;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
     if (wload) {
 #pragma unroll
       for (int i = 0; i < WL; ++i)
-        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
+        glds16((IG_ABL & 4) ? reinterpret_cast<const char*>(zero) : wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
     }
   };
 
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;                 // 0..7
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7, SGPR
 
   const int nblk = gridDim.x;
   const int bq = nblk >> 3, br = nblk & 7;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
       }
       tc += BK;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
     if (true) {
 #pragma unroll
       for (int i = 0; i < WL; ++i)
-        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
+        glds16((IG_ABL & 4) ? reinterpret_cast<const char*>(zero) : wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
     }
   };
 
@@ -385,14 +392,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
     for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lg = lane >> 4;
 
-  issue(0, 0);
-  if (d.KT > 1) issue(1, 1);
-  int st = 0;                                  // stage of tile kt
-  for (int kt = 0; kt < d.KT; ++kt) {
-    if (kt + 1 < d.KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // tile kt landed; tile kt+1 may still fly
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();              // every wave's share of tile kt is in LDS; stage of tile kt-1 is free
-    if (kt + 2 < d.KT) issue(kt + 2, st == 0 ? 2 : st - 1);
+  auto compute = [&](int st) {
     const uint4* W = lds3 + st * STAGE;
     const uint4* X = W + BCH * 8;
 #pragma unroll
@@ -412,8 +412,30 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
-        for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+        for (int b = 0; b < FN; ++b) {
+          if (!(IG_ABL & 2)) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+          else acc[a][b][0] += __uint_as_float(af[a].x ^ bf[b].x);
+        }
     }
+  };
+
+  issue(0, 0);
+  if (d.KT > 1) issue(1, 1);
+  int st = 0;                                  // stage of tile kt
+  // The two waves of a SIMD run the halves of an iteration in opposite order: waves 0-3 request tile kt+2 (address
+  // VALU/SALU + DMA issue) and then multiply tile kt, waves 4-7 multiply first and request afterwards, so one wave's
+  // request phase runs under the other's MFMAs instead of both idling the matrix pipe at the same time.  Legal in either
+  // order: the stage being refilled was last read in iteration kt-1, i.e. before this iteration's barrier.
+  const bool issue_first = wave < 4;            // wave is an SGPR: a scalar branch
+  for (int kt = 0; kt < d.KT; ++kt) {
+    if (kt + 1 < d.KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // tile kt landed; tile kt+1 may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave's share of tile kt is in LDS; stage of tile kt-1 is free
+    const int nst = st == 0 ? 2 : st - 1;
+    const bool more = kt + 2 < d.KT;
+    if (issue_first && more) issue(kt + 2, nst);       // one copy of compute(): two copies made hipcc shuffle the
+    compute(st);                                       // accumulators between differently allocated paths
+    if (!issue_first && more) issue(kt + 2, nst);
     st = st == 2 ? 0 : st + 1;
   }
 
