@@ -25,12 +25,7 @@ import torch
 
 GFLOP_PER_POSE = 163.68          # hooks on the reference module, 2*MAC, full 10-output forward
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks
-VARIANT_NAMES = {0: "conv_igemm_kernel<f32,16,256>", 1: "conv_igemm_kernel<f32,32,256>", 2: "conv_igemm_kernel<f32,64,256>",
-                 3: "conv_igemm_kernel<f32,128,128>", 4: "conv_igemm_kernel<bf16,16,256>", 5: "conv_igemm_kernel<bf16,32,256>",
-                 6: "conv_igemm_kernel<bf16,64,256>", 7: "conv_igemm_kernel<bf16,128,128>",
-                 8: "conv3d_tile_kernel<f32,*> (conv1..conv11)", 9: "conv3d_tile_kernel<bf16,*> (conv1..conv11)",
-                 10: "conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)",
-                 11: "conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)"}
+
 
 
 def make_inputs(B, device, unique=16):
@@ -133,7 +128,7 @@ def main():
         out, bbox, valid = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    stats = (C.c_double * 48)()
+    stats = (C.c_double * (4 * _lib.PROF_ROWS))()
     _lib.check(lib.rgbm_prof_stop(stats), "rgbm_prof_stop")
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -160,19 +155,29 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
-        st = np.array(list(stats)).reshape(12, 4)
+        st = np.array(list(stats)).reshape(_lib.PROF_ROWS, 4)
         kernels = []
-        for v in range(12):
+        for v in range(_lib.PROF_ROWS):
             n, ms, fl, by = st[v]
             if n > 0:
-                kernels.append({"kernel": VARIANT_NAMES[v], "launches_per_step": n / args.steps,
+                kernels.append({"kernel": _lib.PROF_KERNELS[v][0], "dtype": _lib.PROF_KERNELS[v][1], "launches_per_step": n / args.steps,
                                 "avg_launch_ms": ms / n, "total_ms_per_step": ms / args.steps,
                                 "tflops": fl / (ms * 1e-3) / 1e12, "algo_GBps": by / (ms * 1e-3) / 1e9})
         kernels.sort(key=lambda k: -k["total_ms_per_step"])
         dom = kernels[0]
-        peak = PEAK_TFLOPS[args.dtype if dom["kernel"].find("bf16") >= 0 else "fp32"]
+        peak = PEAK_TFLOPS[dom["dtype"]]
+        # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure is read
+        # from the committed rocprofv3 --pmc measurement of this same command (tools/pmc_traffic.py -> profiles/)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and B == 256 and args.dtype == "bf16":
+            key = dom["kernel"].split(" (")[0].split("<")[0]
+            for kname, nbytes in json.load(open(tpath)).items():
+                if key in kname and (dom["kernel"].split(">")[0].split("<")[-1].split(",")[0] in kname):
+                    traffic, traffic_src = float(nbytes), "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
+                    break
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom["avg_launch_ms"], 4), "launches_per_step": dom["launches_per_step"],
                     "flops_per_launch": dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3}
         res = {

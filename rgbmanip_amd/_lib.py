@@ -17,6 +17,21 @@ ACT_NONE, ACT_RELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
 
+# rows of rgbm_prof_stop (include/rgbm.h): (kernel name as rocprofv3 prints it, arithmetic dtype)
+PROF_ROWS = 16
+PROF_KERNELS = [
+    ("conv_igemm_glds_kernel<float, 16, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 32, 256>", "fp32"),
+    ("conv_igemm_glds_kernel<float, 64, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 128, 128>", "fp32"),
+    ("conv_igemm_glds_kernel<unsigned short, 16, 256>", "bf16"), ("conv_igemm_glds_kernel<unsigned short, 32, 256>", "bf16"),
+    ("conv_igemm_glds_kernel<unsigned short, 64, 256>", "bf16"), ("conv_igemm_glds_kernel<unsigned short, 128, 128>", "bf16"),
+    ("conv3d_tile_kernel<float, ...> (conv1..conv11)", "fp32"), ("conv3d_tile_kernel<unsigned short, ...> (conv1..conv11)", "bf16"),
+    ("conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "fp32"),
+    ("conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "bf16"),
+    ("conv_igemm_v3_kernel<float>", "fp32"), ("conv_igemm_v3_kernel<unsigned short>", "bf16"),
+    ("conv0_sweep_kernel (conv0 + fused plane sweep)", "bf16"), ("unused", "bf16"),
+]
+
+
 class RgbmError(RuntimeError):
     pass
 

@@ -341,7 +341,7 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, hipStream_t s) {
     RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
     attr_done = true;
   }
-  prof_begin_launch(s, t.prof_variant, t.algo_flops, t.algo_bytes);
+  prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
   hipLaunchKernelGGL(conv0_sweep_kernel, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());

@@ -502,7 +502,7 @@ static int launch_v3(ConvDesc d, hipStream_t s) {
     RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T, UNI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_done = true;
   }
-  const int variant = (sizeof(T) == 2 ? 4 : 0) + 3;
+  const int variant = sizeof(T) == 2 ? 13 : 12;
   prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_v3_kernel<T, UNI>), dim3((unsigned)nblk), dim3(512), LDS, s, d);
   prof_end_launch(s);

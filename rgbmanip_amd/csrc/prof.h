@@ -1,8 +1,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 namespace rgbm {
-// variants: conv_igemm_kernel dtype*4 + {0: BCH16, 1: BCH32, 2: BCH64, 3: BCH128}; 8/9: conv3d_tile_kernel f32/bf16
-constexpr int kProfVariants = 12;   // 10/11: conv3d_tile conv0 (f32/bf16) on its own
+// rows: 0..7 conv_igemm_glds_kernel dtype*4 + {0: BCH16, 1: BCH32, 2: BCH64, 3: BCH128}; 8/9 conv3d_tile_kernel f32/bf16
+// (conv1..conv11); 10/11 conv3d_tile_kernel conv0 + fused warp (f32/bf16); 12/13 conv_igemm_v3_kernel f32/bf16;
+// 14 conv0_sweep_kernel (bf16); 15 unused
+constexpr int kProfVariants = 16;
 bool prof_enabled();
 void prof_begin_launch(hipStream_t s, int variant, double flops, double bytes);
 void prof_end_launch(hipStream_t s);

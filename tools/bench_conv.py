@@ -27,9 +27,9 @@ for f in flags:
     lib.rgbm_prof_start()
     for _ in range(3): run()
     torch.cuda.synchronize()
-    st = (C.c_double * 48)(); lib.rgbm_prof_stop(st)
-    st = np.array(list(st)).reshape(12, 4)
-    for v in range(12):
+    st = (C.c_double * (4 * _lib.PROF_ROWS))(); lib.rgbm_prof_stop(st)
+    st = np.array(list(st)).reshape(_lib.PROF_ROWS, 4)
+    for v in range(_lib.PROF_ROWS):
         if st[v, 0] > 0:
             ms = st[v, 1] / st[v, 0]
             print(f"flags {f}: variant {v}: {ms:.4f} ms/launch  {flops / ms / 1e9:.0f} TFLOP/s   (N={N} {H}x{W} {Cin}->{Cout} k{k} d{dil} res={res})")
