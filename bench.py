@@ -171,9 +171,9 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and B == 256 and args.dtype == "bf16":
-            key = dom["kernel"].split(" (")[0].split("<")[0]
+            key = dom["kernel"].split(" (")[0].rstrip(">")       # kernel name incl. template arguments as rocprofv3 prints it
             for kname, nbytes in json.load(open(tpath)).items():
-                if key in kname and (dom["kernel"].split(">")[0].split("<")[-1].split(",")[0] in kname):
+                if key in kname:
                     traffic, traffic_src = float(nbytes), "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
                     break
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": peak,

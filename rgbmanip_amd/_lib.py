@@ -18,7 +18,7 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
 
 # rows of rgbm_prof_stop (include/rgbm.h): (kernel name as rocprofv3 prints it, arithmetic dtype)
-PROF_ROWS = 16
+PROF_ROWS = 32
 PROF_KERNELS = [
     ("conv_igemm_glds_kernel<float, 16, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 32, 256>", "fp32"),
     ("conv_igemm_glds_kernel<float, 64, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 128, 128>", "fp32"),
@@ -27,9 +27,19 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<float, ...> (conv1..conv11)", "fp32"), ("conv3d_tile_kernel<unsigned short, ...> (conv1..conv11)", "bf16"),
     ("conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "fp32"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "bf16"),
-    ("conv_igemm_v3_kernel<float>", "fp32"), ("conv_igemm_v3_kernel<unsigned short>", "bf16"),
+    ("conv_igemm_ws_kernel<float>", "fp32"), ("conv_igemm_ws_kernel<unsigned short>", "bf16"),    # + conv_igemm_v3_kernel for non-uniform taps
     ("conv0_sweep_kernel (conv0 + fused plane sweep)", "bf16"), ("unused", "bf16"),
-]
+    ("conv3d_tile_kernel<unsigned short, 32, 16, 6, 8, 8, 1, false, false> (conv0 on a materialised volume)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 8, 16, 2, 8, 8, 2, false, false> (conv1)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, false, false> (conv2)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 16, 32, 2, 8, 8, 2, false, false> (conv3)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 32, 32, 2, 8, 8, 1, false, false> (conv4)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 32, 64, 1, 8, 8, 2, false, false> (conv5)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 64, 64, 1, 8, 8, 1, false, false> (conv6)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 64, 32, 1, 8, 8, 1, true, false> (conv7)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 32, 16, 2, 8, 8, 1, true, false> (conv9)", "bf16"),
+    ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, true, false> (conv11)", "bf16"),
+] + [("unused", "bf16")] * 6
 
 
 class RgbmError(RuntimeError):

@@ -357,7 +357,8 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.Cout = t3d[li].Cout; d.relu = 1;
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
     d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
-    d.prof_variant = (layer == 10 || layer == 0) ? 10 + (dtype == BF16 ? 1 : 0) : 8 + (dtype == BF16 ? 1 : 0);   // conv0 counted on its own
+    // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
+    d.prof_variant = layer == 10 ? 10 + (dtype == BF16 ? 1 : 0) : (dtype == BF16 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);

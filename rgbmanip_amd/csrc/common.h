@@ -124,6 +124,8 @@ struct ConvDesc {
   int act; float slope; int res_mode; int bias_stride;  // bias index = n*bias_stride + ch
   long long M;                            // N*Dq*Hq*Wq
   int n_pix_tiles, n_ch_tiles;
+  // persistent kernel only (filled by its launcher): tiles in total, and exact-division magics for Wq, Hq, Dq
+  int n_tiles; unsigned fd_m[3]; int fd_s[3];
   double algo_flops, algo_bytes;          // algorithmic work of this launch (profiling only)
 };
 

@@ -4,6 +4,7 @@
 // is needed.  The LDS image of a tile is lane-linear (wave-uniform base + lane*16 bytes), therefore the bank-conflict
 // swizzle is applied on the SOURCE side: the lane that fills LDS slot (row, j) fetches global chunk j ^ ((row>>1)&7),
 // and readers XOR the same value (an involution).  Out-of-image / padded-K lanes fetch from a 16-byte zero page.
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -482,6 +483,312 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 128 tile, role-specialised: 8 multiply waves + 4 request waves, 3-stage LDS ring (uniform-tap layers only).
+// Per K tile and wave the 3-stage kernel above issues 97 VALU + 71 SALU + 16 ds_read + 7 VMEM instructions next to its 32
+// MFMAs (PMC, MFMA 34 % busy): the request bookkeeping, not bandwidth, sets the pace.  Here the 8 multiply waves execute
+// nothing but ds_read + MFMA + one barrier per K tile, and the whole request side (tap walk, validity masks, 12 LDS-DMA
+// pieces per wave and tile) lives in 4 extra waves, one per SIMD, whose scalar/vector work runs in the issue gaps of the
+// MFMA streams.  Same operand layout, swizzle, fragment maps and epilogue as the kernels above.
+// ---------------------------------------------------------------------------------------------------------
+// n / divisor for n < 2^31 with a host-made magic: one 32x32->64 multiply and a shift instead of ~35 instructions
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m, int sh) {
+  return (unsigned)(((unsigned long long)n * m) >> sh);
+}
+// output-grid coordinates of GEMM row m
+__device__ __forceinline__ void decode_row(const ConvDesc& d, unsigned m, unsigned& n, unsigned& qd, unsigned& qh, unsigned& qw) {
+  unsigned t = m;
+  unsigned q = fdiv(t, d.fd_m[0], d.fd_s[0]); qw = t - q * (unsigned)d.Wq; t = q;
+  q = fdiv(t, d.fd_m[1], d.fd_s[1]); qh = t - q * (unsigned)d.Hq; t = q;
+  q = fdiv(t, d.fd_m[2], d.fd_s[2]); qd = t - q * (unsigned)d.Dq; n = q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
+  constexpr int BCH = 128, BPIX = 256;
+  constexpr int E = 16 / sizeof(T);
+  constexpr int BK = 8 * E;
+  constexpr int XR = BPIX / 32;              // 8 gathered rows per request thread
+  constexpr int WL = BCH / 32;               // 4 weight rows per request thread
+  constexpr int NP = XR + WL;                // 12 LDS-DMA pieces per request wave and K tile
+  constexpr int FM = 4, FN = 4;
+  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (48 KB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
+  static_assert(NP == 12, "the counted waits below assume 12 pieces per tile");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7 multiply, 8..11 request
+  const int KT = d.KT;
+
+  // Persistent: workgroup b owns tiles b, b + grid, b + 2*grid, ... (grid is a multiple of 8, so all of them map to the
+  // same XCD) and the K-tile ring simply continues across tile boundaries: while the multiply waves write tile t's
+  // outputs, the first two K tiles of tile t+1 are already landing.  Measured on the one-tile-per-workgroup version:
+  // 15-19 us of prologue + pipeline fill + epilogue + relaunch per tile that nothing overlapped (a quarter of layer4).
+  const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = n_my * KT;               // K-tile steps of this workgroup; every wave passes `total` barriers
+  auto tile_of = [&](int k, int& pix_tile, int& ch_tile) {
+    const int v = (int)blockIdx.x + k * (int)gridDim.x;          // virtual workgroup id -> XCD-aware tile order
+    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
+    const int lid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+    pix_tile = lid / d.n_ch_tiles;
+    ch_tile = lid - pix_tile * d.n_ch_tiles;
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ request waves
+    const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+    const int pw = wave - 8;
+    const int tp = tid - 512;
+    const int j = tp & 7;
+    const int r0 = tp >> 3;                  // 0..31
+    const int js = j ^ ((r0 >> 1) & 7);
+    const char* rowp[XR];
+    unsigned rmask[XR];
+    const char* wrow[WL];
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));      // this wave's first piece, stage 0
+
+    auto enter_tile = [&](int k) {
+      int pix_tile, ch_tile;
+      tile_of(k, pix_tile, ch_tile);
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const long long m = (long long)pix_tile * BPIX + r0 + 32 * i;
+        int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
+        if (m < d.M) {
+          unsigned n, qd, qh, qw;
+          decode_row(d, (unsigned)m, n, qd, qh, qw);
+          xn = (int)n * d.Di;
+          xd0 = (int)qd * d.sd - d.pd;
+          xh0 = (int)qh * d.sh - d.ph;
+          xw0 = (int)qw * d.sw - d.pw;
+        }
+        unsigned mk = 0;
+        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
+        rmask[i] = mk;
+        const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
+        rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+      }
+#pragma unroll
+      for (int i = 0; i < WL; ++i)
+        wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + r0 + 32 * i) * d.Kpad + js * E);
+      tkd = tkh = tkw = tc = 0;
+    };
+
+    int ikt = 0, itile = 0;                  // K tile / tile index of the next request
+    auto issue = [&](int stage) {
+      if (ikt == 0) enter_tile(itile);
+      const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
+      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+      const long long soff =
+          ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * (long long)sizeof(T);
+      const bool cok = tkd < d.KD && tc + js * E < d.Cin;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const bool ok = cok && (rmask[i] & sel) == sel;
+        const char* src = ok ? rowp[i] + soff : zero;
+        glds16(src, sbase + (BCH * 8 + i * 256) * 16);               // X rows 32*i + 8*pw .. +7
+      }
+      const long long wk = (long long)ikt * BK * (long long)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wk, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7
+      tc += BK;
+      if (d.lcin >= 0 && tc >= d.Cin) {
+        tc = 0;
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      }
+      if (++ikt == KT) { ikt = 0; ++itile; }
+    };
+
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
+    int st = 0;
+    for (int g = 0; g < total; ++g) {
+      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step g landed; step g+1 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // step g is complete in LDS; the stage of step g-1 is free
+      if (g + 2 < total) issue(st == 0 ? 2 : st - 1);
+      st = st == 2 ? 0 : st + 1;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- multiply waves
+  const int wch = (wave >> 2) * 64;
+  const int wpix = (wave & 3) * 64;
+  const int lr = lane & 15, lg = lane >> 4;
+  // Fragment reads run half a K tile ahead of the MFMAs that consume them (two register sets): after the barrier of
+  // step g the first-half fragments are requested, the second half of the previous step is multiplied out of registers
+  // meanwhile, then the second-half fragments are requested under the first half's MFMAs.
+  uint4 af0[FM], bf0[FN], af1[FM], bf1[FN];
+  f32x4 acc[FM][FN];
+  auto load_half = [&](int st, int s, uint4 (&af)[FM], uint4 (&bf)[FN]) {
+    const uint4* W = lds3 + st * STAGE;
+    const uint4* X = W + BCH * 8;
+    const int cidx = s * 4 + lg;
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+      const int row = wch + a * 16 + lr;
+      af[a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+    }
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const int row = wpix + b * 16 + lr;
+      bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+    }
+  };
+  auto mma_half = [&](const uint4 (&af)[FM], const uint4 (&bf)[FN]) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+  };
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
+  int st = 0;
+  for (int k = 0; k < n_my; ++k) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+      // every fragment read of the previous step has returned before the request waves may refill its stage
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      load_half(st, 0, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt > 0) mma_half(af1, bf1);                  // second half of K tile kt-1
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(st, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st == 2 ? 0 : st + 1;
+    }
+    mma_half(af1, bf1);
+
+    // ---- epilogue of tile k (the request waves are already filling the ring for tile k+1) ----
+    // All 16 residual reads of a lane are requested before the first one is used: written as load-use-store per
+    // fragment they were 16 dependent HBM round trips, 15-17 us per tile with the matrix pipe idle (measured as the
+    // K-independent part of the launch time).
+#if IG_ABL & 16
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+      if (sum == 12345.678f) out[tid] = (T)1;
+      continue;
+    }
+#endif
+    int pix_tile, ch_tile;
+    tile_of(k, pix_tile, ch_tile);
+    long long obase[FN];
+    int nn[FN];
+    bool pok[FN];
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
+      pok[b] = m < d.M;
+      unsigned n, qd, qh, qw;
+      decode_row(d, pok[b] ? (unsigned)m : 0u, n, qd, qh, qw);
+      nn[b] = (int)n;
+      obase[b] = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo;
+    }
+    const int ch0 = ch_tile * BCH + wch + lg * 4;
+    typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type raw4;      // 4 elements as loaded
+#pragma unroll
+    for (int bh = 0; bh < FN; bh += 2) {               // two fragments (8 residual reads in flight) at a time
+      raw4 rr[FM][2];
+      if (d.res_mode != RES_NONE) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int a = 0; a < FM; ++a) {
+            const int ch = ch0 + a * 16;
+            const bool ok = pok[bh + bb] && ch < d.Cout;
+            rr[a][bb] = *reinterpret_cast<const raw4*>(res + (ok ? obase[bh + bb] + ch : 0ll));   // masked lanes read element 0
+          }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = bh + bb;
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+          const int ch = ch0 + a * 16;
+          if (!pok[b] || ch >= d.Cout) continue;
+          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+          if (d.bias) {
+            const float* bp = d.bias + (long long)nn[b] * d.bias_stride + ch;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bp[e];
+          }
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (d.res_mode != RES_NONE) load4(reinterpret_cast<const T*>(&rr[a][bb]), rv);
+          if (d.res_mode == RES_PRE_ACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
+          if (d.res_mode == RES_POST_ACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+          }
+          store4(out + obase[b] + ch, v);
+        }
+      }
+    }
+  }
+}
+
+// magic for n / dvs, n < 2^31: q = (n * m) >> sh  (round-up method, sh = 31 + ceil(log2 dvs))
+static void make_fastdiv(int dvs, unsigned& m, int& sh) {
+  int s = 0;
+  while ((1ll << s) < (long long)dvs) ++s;
+  sh = 31 + s;
+  m = (unsigned)(((1ull << sh) + (unsigned long long)dvs - 1ull) / (unsigned long long)dvs);
+}
+
+template <typename T>
+static int launch_ws(ConvDesc d, hipStream_t s) {
+  constexpr int BCH = 128, BPIX = 256;
+  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4);
+  d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
+  d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
+  const long long ntiles = (long long)d.n_pix_tiles * d.n_ch_tiles;
+  RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31) && d.M < (1ll << 31), "conv grid out of range");
+  d.n_tiles = (int)ntiles;
+  make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
+  make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
+  make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
+  static int n_cu = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_done = true;
+  }
+  if (n_cu == 0) {
+    int dev = 0;
+    RGBM_CHECK_HIP(hipGetDevice(&dev));
+    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;                       // one resident workgroup per CU (144 KB LDS); a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
+  prof_begin_launch(s, sizeof(T) == 2 ? 13 : 12, d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
+  prof_end_launch(s);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // every K tile inside one tap (see the UNI comment at the 2-stage kernel)
 static bool conv_uniform_taps(const ConvDesc& d, int bk) {
   if (d.KD > 8 || d.KH > 8 || d.KW > 8) return false;
@@ -538,8 +845,10 @@ template <typename T>
 static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   const bool uni = conv_uniform_taps(d, 8 * (16 / (int)sizeof(T))) && !(g_debug_flags & 16);
   // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
-  if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256)
+  if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
+    if (uni && !(g_debug_flags & 64)) return launch_ws<T>(d, s);                    // role-specialised (uniform taps only)
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
+  }
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
 }
 

@@ -22,5 +22,5 @@ for flags in (0,):
     torch.cuda.synchronize()
     st = (C.c_double * (4 * _lib.PROF_ROWS))(); lib.rgbm_prof_stop(st)
     st = np.array(list(st)).reshape(_lib.PROF_ROWS, 4)
-    print(f"cost_impl {ci} flags {flags}: conv0 {(st[11,1]+st[14,1])/3:.3f} ms   conv1..11 {st[9,1]/3:.3f} ms  (B={B}: 1 chunk of {2*B} views)")
+    print(f"cost_impl {ci} flags {flags}: conv0 {(st[11,1]+st[14,1])/3:.3f} ms   conv1..11 {st[17:26,1].sum()/3:.3f} ms  (B={B}: 1 chunk of {2*B} views)")
 lib.rgbm_debug_flags(0)
