@@ -165,7 +165,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * bracketed by HIP events recorded on its own stream.  stats: host double[32*4], one row per kernel family:
  * 0..7 conv_igemm_glds_kernel<dtype, BCH> (row = dtype*4 + {0:16,1:32,2:64,3:128}-channel tile), 8/9 conv3d_tile_kernel
  * f32/bf16 (conv1..conv11), 10/11 conv3d_tile_kernel conv0 + fused plane sweep f32/bf16, 12/13 conv_igemm_v3_kernel
- * f32/bf16, 14 conv0_sweep_kernel (bf16), 16..25 conv3d_tile_kernel bf16 per layer (conv0..conv6, conv7, conv9, conv11;
+ * f32/bf16, 14 conv0_sweep_kernel (bf16), 15 conv_igemm_ws64_kernel (bf16), 16..25 conv3d_tile_kernel bf16 per layer (conv0..conv6, conv7, conv9, conv11;
  * row 8 then holds only the f32 3-D layers and row 9 stays empty), others unused; columns {launches, total ms, algorithmic FLOPs, algorithmic bytes}.
  * stop synchronises on the recorded events. */
 /* ablation switches for kernel benchmarking only (0 = normal operation) */

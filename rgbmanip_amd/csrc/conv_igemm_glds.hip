@@ -789,6 +789,271 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 pixel x 64 channel tile, bf16, three roles (layers with 33..64 output channels and no residual: up_2, up_3).
+// These layers have short K (9..36 K tiles) and 6.6 GB of activations per launch: with the 2-stage kernel the epilogue
+// (8-byte stores from the MFMA C layout) and the pipeline refill of every tile left them at 0.43 PFLOP/s / 1.5 TB/s.
+//   waves 0-3  multiply: ds_read + MFMA only; at the end of a tile bias + activation + bf16 pack -> LDS staging tile
+//   waves 4-7  request : tap walk, validity masks, 10 LDS-DMA pieces per K tile, counted vmcnt (loads only: stores
+//                        share vmcnt on gfx9 and complete out of order, so they must not come from these waves)
+//   waves 8-11 store   : move the staged tile of the PREVIOUS pixel tile to global memory as whole 128-byte rows, a slice
+//                        per K step, while the multiply waves are already deep in the next tile
+// Persistent over tiles with one continuous 3-stage K ring, one barrier per K step for all 12 waves plus one final
+// barrier that publishes the last staged tile.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) {
+  typedef unsigned short T;
+  constexpr int BCH = 64, BPIX = 256;
+  constexpr int E = 8, BK = 64;
+  constexpr int XR = BPIX / 32;              // 8 gathered rows per request thread
+  constexpr int WL = BCH / 32;               // 2 weight rows per request thread
+  constexpr int NP = XR + WL;                // 10 pieces per request wave and K tile
+  constexpr int FM = 4, FN = 4;
+  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (40 KB)
+  constexpr int SROW = 144;                  // bytes per staged pixel row (128 + 16 pad)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
+  unsigned char* stg = reinterpret_cast<unsigned char*>(lds3 + 3 * STAGE);
+  static_assert(NP == 10, "the counted waits below assume 10 pieces per tile");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KT = d.KT;
+  const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = n_my * KT;               // every wave passes total + 1 barriers
+  auto tile_of = [&](int k) {
+    const int v = (int)blockIdx.x + k * (int)gridDim.x;
+    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
+    return (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;      // pixel tile (one channel tile)
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ store waves
+    const int ts = tid - 512;
+    const int c = ts & 7;                     // 16-byte chunk = 8 channels
+    const int r0 = ts >> 3;                   // rows r0 + 32*i
+    T* __restrict__ out = reinterpret_cast<T*>(d.out);
+    const int ch = c * 8;
+    const int nch = d.Cout - ch;              // <= 0: nothing, 4: half chunk, >= 8: whole chunk
+    const int per = (8 + (KT - 1) - 1) / (KT - 1);       // row groups per K step (KT >= 2)
+    auto flush = [&](int k, int i0, int i1) {            // row groups [i0, i1) of tile k
+      if (nch <= 0) return;
+      const int pix_tile = tile_of(k);
+      for (int i = i0; i < i1 && i < 8; ++i) {
+        const int r = r0 + 32 * i;
+        const long long m = (long long)pix_tile * BPIX + r;
+        if (m >= d.M) continue;
+        unsigned n, qd, qh, qw;
+        decode_row(d, (unsigned)m, n, qd, qh, qw);
+        const long long o = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo + ch;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + r * SROW + c * 16);
+        if (nch >= 8) *reinterpret_cast<uint4*>(out + o) = v;
+        else *reinterpret_cast<uint2*>(out + o) = make_uint2(v.x, v.y);
+      }
+    };
+    int g = 0;
+    for (int k = 0; k < n_my; ++k)
+      for (int kt = 0; kt < KT; ++kt, ++g) {
+        __builtin_amdgcn_s_barrier();
+        // the staged tile k-1 was published by barrier (k, 0); it must be drained before barrier (k, KT-1), after which
+        // the multiply waves overwrite it
+        if (k > 0 && kt < KT - 1) flush(k - 1, kt * per, (kt + 1) * per);
+      }
+    __builtin_amdgcn_s_barrier();             // publishes the last staged tile
+    flush(n_my - 1, 0, 8);
+    return;
+  }
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ request waves
+    const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+    const int pw = wave - 4;
+    const int tp = tid - 256;
+    const int j = tp & 7;
+    const int r0 = tp >> 3;                  // 0..31
+    const int js = j ^ ((r0 >> 1) & 7);
+    const char* rowp[XR];
+    unsigned rmask[XR];
+    const char* wrow[WL];
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));
+
+    auto enter_tile = [&](int k) {
+      const int pix_tile = tile_of(k);
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const long long m = (long long)pix_tile * BPIX + r0 + 32 * i;
+        int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
+        if (m < d.M) {
+          unsigned n, qd, qh, qw;
+          decode_row(d, (unsigned)m, n, qd, qh, qw);
+          xn = (int)n * d.Di;
+          xd0 = (int)qd * d.sd - d.pd;
+          xh0 = (int)qh * d.sh - d.ph;
+          xw0 = (int)qw * d.sw - d.pw;
+        }
+        unsigned mk = 0;
+        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
+        rmask[i] = mk;
+        const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
+        rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+      }
+      tkd = tkh = tkw = tc = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < WL; ++i)              // one channel tile: the weight rows never change
+      wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(r0 + 32 * i) * d.Kpad + js * E);
+
+    int ikt = 0, itile = 0;
+    auto issue = [&](int stage) {
+      if (ikt == 0) enter_tile(itile);
+      const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
+      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+      const long long soff =
+          ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * (long long)sizeof(T);
+      const bool cok = tkd < d.KD && tc + js * E < d.Cin;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const bool ok = cok && (rmask[i] & sel) == sel;
+        const char* src = ok ? rowp[i] + soff : zero;
+        glds16(src, sbase + (BCH * 8 + i * 256) * 16);
+      }
+      const long long wk = (long long)ikt * BK * (long long)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wk, sbase + (i * 256) * 16);
+      tc += BK;
+      if (d.lcin >= 0 && tc >= d.Cin) {
+        tc = 0;
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      }
+      if (++ikt == KT) { ikt = 0; ++itile; }
+    };
+
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
+    int st = 0;
+    for (int g = 0; g < total; ++g) {
+      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (g + 2 < total) issue(st == 0 ? 2 : st - 1);
+      st = st == 2 ? 0 : st + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // -------------------------------------------------------------------- multiply waves
+  const int wpix = wave * 64;
+  const int lr = lane & 15, lg = lane >> 4;
+  uint4 af0[FM], bf0[FN], af1[FM], bf1[FN];
+  f32x4 acc[FM][FN];
+  auto load_half = [&](int st, int s, uint4 (&af)[FM], uint4 (&bf)[FN]) {
+    const uint4* W = lds3 + st * STAGE;
+    const uint4* X = W + BCH * 8;
+    const int cidx = s * 4 + lg;
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+      const int row = a * 16 + lr;
+      af[a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+    }
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const int row = wpix + b * 16 + lr;
+      bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+    }
+  };
+  auto mma_half = [&](const uint4 (&af)[FM], const uint4 (&bf)[FN]) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+  };
+  int st = 0;
+  for (int k = 0; k < n_my; ++k) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads returned, staged tile written
+      __builtin_amdgcn_s_barrier();
+      load_half(st, 0, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt > 0) mma_half(af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(st, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st == 2 ? 0 : st + 1;
+    }
+    mma_half(af1, bf1);
+    // ---- bias + activation + bf16 pack into the staging tile (the store waves have drained the previous one) ----
+    const int pix_tile = tile_of(k);
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const int row = wpix + b * 16 + lr;
+      int n = 0;
+      if (d.bias && d.bias_stride != 0) {
+        const long long m = (long long)pix_tile * BPIX + row;
+        unsigned nn, qd, qh, qw;
+        decode_row(d, m < d.M ? (unsigned)m : 0u, nn, qd, qh, qw);
+        n = (int)nn;
+      }
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        const int ch = a * 16 + lg * 4;
+        float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+        if (d.bias && ch < d.Cout) {
+          const float* bp = d.bias + (long long)n * d.bias_stride + ch;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
+        *reinterpret_cast<uint2*>(stg + row * SROW + ch * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+static int launch_ws64(ConvDesc d, hipStream_t s) {
+  constexpr int BCH = 64, BPIX = 256;
+  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4) + (size_t)BPIX * 144;
+  d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
+  d.n_ch_tiles = 1;
+  d.n_tiles = d.n_pix_tiles;
+  make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
+  make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
+  make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
+  static int n_cu = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_done = true;
+  }
+  if (n_cu == 0) {
+    int dev = 0;
+    RGBM_CHECK_HIP(hipGetDevice(&dev));
+    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int grid = d.n_tiles < n_cu ? d.n_tiles : n_cu;
+  prof_begin_launch(s, 15, d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL(conv_igemm_ws64_kernel, dim3((unsigned)grid), dim3(768), LDS, s, d);
+  prof_end_launch(s);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // every K tile inside one tap (see the UNI comment at the 2-stage kernel)
 static bool conv_uniform_taps(const ConvDesc& d, int bk) {
   if (d.KD > 8 || d.KH > 8 || d.KW > 8) return false;
@@ -849,6 +1114,11 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     if (uni && !(g_debug_flags & 64)) return launch_ws<T>(d, s);                    // role-specialised (uniform taps only)
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
+  // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel
+  if (sizeof(T) == 2 && uni && conv_ch_tile(d.Cout) == 64 && d.res_mode == RES_NONE && d.KT >= 2 && d.M >= 256 * 256 &&
+      d.M < (1ll << 31) && !(g_debug_flags & 128) &&
+      (((unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T))) & 15ull) == 0ull)
+    return launch_ws64(d, s);
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
 }
 

@@ -41,6 +41,14 @@ CONV2D_CASES = [
     ("final_1x1", 1, 64, 20, 20, 32, 1, 1, 0, 1, True, 0, 0),
     ("psp_1x1_tinyM", 3, 512, 2, 2, 128, 1, 1, 0, 1, False, 1, 0),
     ("big_k", 1, 1024, 6, 6, 256, 3, 1, 1, 1, True, 2, 0),
+    # M >= 65536 GEMM rows: the persistent role-specialised kernels (conv_igemm_ws_kernel / conv_igemm_ws64_kernel);
+    # M is not a multiple of the 256-row tile, so the last tile is ragged and workgroups own several tiles each
+    ("ws128_res_pre", 3, 64, 150, 150, 128, 3, 1, 1, 1, False, 1, 1),
+    ("ws128_dil2_bias_prelu", 3, 64, 148, 151, 256, 3, 1, 2, 2, True, 2, 0),
+    ("ws128_1x1_s1", 2, 192, 182, 181, 128, 1, 1, 0, 1, True, 1, 0),
+    ("ws64_prelu_bias", 3, 64, 150, 151, 64, 3, 1, 1, 1, True, 2, 0),
+    ("ws64_cout48", 3, 128, 149, 150, 48, 3, 1, 1, 1, True, 1, 0),
+    ("ws64_two_ktiles", 5, 128, 120, 121, 64, 1, 1, 0, 1, False, 0, 0),
 ]
 
 
