@@ -21,7 +21,7 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.
 
 class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
-                 cost_impl: int | None = None):
+                 cost_impl: int | None = None, sparse_tail: int | None = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -47,6 +47,8 @@ class AdaPoseNet:
             _lib.check(self.lib.rgbm_adapose_set_chunk(self._h, int(max_chunk_views)), "rgbm_adapose_set_chunk")
         if cost_impl is not None:
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"cost_impl", int(cost_impl)), "rgbm_adapose_set_option")
+        if sparse_tail is not None:
+            _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"sparse_tail", int(sparse_tail)), "rgbm_adapose_set_option")
         self._ws = None
         self._ws_B = None
 

@@ -381,6 +381,12 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
     if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
     if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
+    if (cost_impl == 3 && dtype == BF16 && sparse_tail) {
+      // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
+      if (int rc = launch_prob_sparse(bf.u9, bf.c[0], t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc,
+                                      B, P, D, S, S, s)) return rc;
+      continue;
+    }
     if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;
     if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 1, s)) return rc;
   }

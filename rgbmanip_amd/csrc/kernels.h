@@ -55,6 +55,11 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
 void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& packed);
 int launch_conv0_sweep(const Conv3dTileDesc& d, hipStream_t s);
 
+// prob_sparse.hip — conv11 + skip + prob conv + softmax + depth on the neighbourhoods of the chosen pixels (bf16)
+int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
+                       const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
+                       int D, int H, int W, hipStream_t s);
+
 // postproc.hip
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
                        const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s);

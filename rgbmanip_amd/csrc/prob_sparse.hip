@@ -1,0 +1,177 @@
+// Sparse tail of the cost-regularisation net (bf16 nets): conv11 (ConvTranspose3d 16->8, k3 s2 p1 op1 + BN + ReLU), the
+// skip add u11 = c0 + conv11(u9), the prob conv (Conv3d 8->1, k3 p1), softmax over depth and the depth regression
+// (network_v5.py:278-299, 449-455) — evaluated ONLY where the network consumes them.  prob is gathered at the P = 1024
+// chosen pixels of a view, so of the 24 x 224 x 224 u11 volume only the 3 x 3 pixel neighbourhoods of those pixels are
+// ever read: at most 9216 of 50176 pixel columns (18 %), far fewer for a real (connected) object mask.  The dense
+// pipeline it replaces spent 9.1 ms per batch writing u11 (conv11 is bound by partial-line memory instructions, 2.65 TB/s)
+// plus 2.1 ms gathering from it.
+//
+// One wave per chosen pixel.  The transposed conv is computed per output-parity class exactly like the halo-tile kernel
+// (conv3d_tile.hip, TR mode: 8 classes with 1..8 taps, two taps of 16 channels per 16x16x32 MFMA step, the same packed
+// weight fragments), but its B operand is gathered straight from u9 instead of a staged halo: lane (voxel, k-group) loads
+// the 16-byte half voxel its MFMA lane needs.  A class has up to 12 x 2 x 2 = 48 neighbourhood voxels = 3 fragments.  The
+// 3 x 3 x D neighbourhood of u11 is kept in LDS in fp32 (never rounded to bf16, never written to HBM), then 24 lanes run
+// the 27-tap prob conv, and the wave reduces softmax and depth.
+#include "common.h"
+#include "kernels.h"
+
+namespace rgbm {
+
+namespace {
+
+constexpr int PS_DMAX = 24;
+
+struct ProbSparseDesc {
+  const unsigned short* u9;     // [Vc][D/2][H/2][W/2][16] bf16
+  const unsigned short* c0;     // [Vc][D][H][W][8] bf16
+  const unsigned short* w11;    // conv3d_tile_pack(conv11): [14 steps][16][4][8] bf16
+  const float* bias11;          // [16] folded BN shift
+  const float* wprob;           // [27][8]
+  const int* choose;            // [V][P]
+  const float* depths;          // [B][D]
+  float* prob;                  // [V][P][D]
+  float* depth_out;             // [V][P]
+  int v0, Vc, B, P, D, H, W;
+};
+
+template <int N> struct PC { static constexpr int value = N; };
+
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d) {
+  __shared__ __attribute__((aligned(16))) float U[4][PS_DMAX * 9 * 8];      // u11 on the 3x3xD neighbourhood, per wave
+  __shared__ float wp[27 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int i = tid; i < 27 * 8; i += 256) wp[i] = d.wprob[i];
+  const int D = d.D, H = d.H, W = d.W, Dq = D >> 1, Hq = H >> 1, Wq = W >> 1;
+  const long long pidx = (long long)blockIdx.x * 4 + wave;              // point index within the chunk (wave-uniform)
+  const bool active = pidx < (long long)d.Vc * d.P;
+  const int vl = active ? (int)(pidx / d.P) : 0;
+  const int v = d.v0 + vl;
+  const long long o = (long long)v * d.P + (pidx - (long long)vl * d.P);
+  const int pix = active ? d.choose[o] : 0;
+  const int y = pix / W, x = pix - y * W;
+  float* Uw = U[wave];
+  for (int i = lane; i < D * 72; i += 64) Uw[i] = 0.f;                  // neighbours outside the image / volume: zero padding
+  __syncthreads();
+
+  const uint4* wq = reinterpret_cast<const uint4*>(d.w11);
+  const unsigned short* u9v = d.u9 + (long long)vl * Dq * Hq * Wq * 16;
+  const unsigned short* c0v = d.c0 + (long long)vl * D * H * W * 8;
+
+  auto run_class = [&](auto pc) {
+    constexpr int PASS = decltype(pc)::value;
+    constexpr int pd = (PASS >> 2) & 1, ph = (PASS >> 1) & 1, pw = PASS & 1;
+    constexpr int KH = 1 + ph, KW = 1 + pw, NT = (1 + pd) * KH * KW, NS = (NT + 1) / 2;
+    constexpr int S0 = PASS == 0 ? 0 : PASS == 1 ? 1 : PASS == 2 ? 2 : PASS == 3 ? 3 : PASS == 4 ? 5 : PASS == 5 ? 6 : PASS == 6 ? 8 : 10;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      // neighbourhood voxels of this parity class: slot = depth index * 4 + row slot * 2 + column slot
+      const int slot = f * 16 + lr;
+      const int zi = slot >> 2, rs = (slot >> 1) & 1, cs = slot & 1;
+      const int oz = pd + 2 * zi;
+      const bool ym = (y & 1) == ph, xm = (x & 1) == pw;                // the centre row / column has this parity
+      const int yy = ym ? y : (rs ? y + 1 : y - 1);
+      const int xx = xm ? x : (cs ? x + 1 : x - 1);
+      const bool valid = active && oz < D && (ym ? rs == 0 : true) && (xm ? cs == 0 : true) &&
+                         (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const int qd = oz >> 1, qh = yy >> 1, qw = xx >> 1;              // input (u9) voxel of tap (0,0,0)
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        // MFMA step s: lane groups 0,1 carry tap 2s, groups 2,3 tap 2s+1; each group one 16-byte half of the 16 channels
+        const int t0 = 2 * s, t1 = 2 * s + 1;
+        const bool hi = lg >= 2;
+        const int td = hi ? t1 / (KH * KW) : t0 / (KH * KW);
+        const int th = hi ? (t1 / KW) % KH : (t0 / KW) % KH;
+        const int tw = hi ? t1 % KW : t0 % KW;
+        const bool pad = hi ? (t1 >= NT) : false;
+        const int iz = qd + td, iy = qh + th, ix = qw + tw;
+        const bool inb = valid && !pad && iz < Dq && iy < Hq && ix < Wq;  // beyond the input grid: the conv's zero halo
+        uint4 b = make_uint4(0u, 0u, 0u, 0u);
+        if (inb) b = *reinterpret_cast<const uint4*>(u9v + ((((long long)iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8));
+        const uint4 a = wq[((S0 + s) * 16 + lr) * 4 + lg];
+        acc = mma16(a, b, acc);
+      }
+      if (valid && lg < 2) {
+        const int ch = lg * 4;
+        float cv[4];
+        load4(c0v + ((((long long)oz * H + yy) * W + xx) * 8 + ch), cv);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[e] + d.bias11[ch + e];
+          t = t < 0.f ? 0.f : t;                                        // NaN propagates, like torch.relu
+          r[e] = cv[e] + t;                                             // skip add is post-ReLU (network_v5.py:289)
+        }
+        *reinterpret_cast<f32x4*>(Uw + ((oz * 3 + (yy - y + 1)) * 3 + (xx - x + 1)) * 8 + ch) = r;
+      }
+    }
+  };
+  run_class(PC<0>{}); run_class(PC<1>{}); run_class(PC<2>{}); run_class(PC<3>{});
+  run_class(PC<4>{}); run_class(PC<5>{}); run_class(PC<6>{}); run_class(PC<7>{});
+  __syncthreads();
+
+  // ---- prob conv at the D depths of this pixel (lane = depth), then softmax and depth regression across the wave ----
+  float logit = -INFINITY;
+  if (lane < D) {
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int zz = lane + kd - 1;
+      if ((unsigned)zz >= (unsigned)D) continue;
+      const float* up = Uw + zz * 72;
+      const float* ww = wp + kd * 72;
+#pragma unroll
+      for (int i = 0; i < 72; i += 4) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(up + i);
+        acc += u[0] * ww[i] + u[1] * ww[i + 1] + u[2] * ww[i + 2] + u[3] * ww[i + 3];
+      }
+    }
+    logit = acc;
+  }
+  float m = logit;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  // a NaN logit must poison the whole pixel like torch.softmax does (fmaxf drops NaNs)
+  float nanflag = (lane < D && logit != logit) ? 1.f : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nanflag += __shfl_xor(nanflag, off);
+  float e = lane < D ? expf(logit - m) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  float pr = e * (1.f / sum);
+  if (nanflag > 0.f) pr = __builtin_nanf("");
+  float dep = lane < D ? pr * d.depths[(v % d.B) * D + lane] : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) dep += __shfl_xor(dep, off);
+  if (active) {
+    if (lane < D) d.prob[o * D + lane] = pr;
+    if (lane == 0) d.depth_out[o] = dep;
+  }
+}
+
+int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
+                       const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
+                       int D, int H, int W, hipStream_t s) {
+  RGBM_REQUIRE(u9 && c0 && w11_packed && bias11 && wprob && choose && depths && prob && depth_out, "prob_sparse arguments");
+  RGBM_REQUIRE(D <= PS_DMAX && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0, "prob_sparse supports even D <= 24 and even H, W");
+  ProbSparseDesc d;
+  d.u9 = reinterpret_cast<const unsigned short*>(u9);
+  d.c0 = reinterpret_cast<const unsigned short*>(c0);
+  d.w11 = reinterpret_cast<const unsigned short*>(w11_packed);
+  d.bias11 = bias11; d.wprob = wprob; d.choose = choose; d.depths = depths; d.prob = prob; d.depth_out = depth_out;
+  d.v0 = v0; d.Vc = Vc; d.B = B; d.P = P; d.D = D; d.H = H; d.W = W;
+  const long long npts = (long long)Vc * P;
+  RGBM_REQUIRE(npts > 0 && (npts + 3) / 4 < (1ll << 31), "prob_sparse grid out of range");
+  hipLaunchKernelGGL(prob_sparse_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rgbm

@@ -154,6 +154,27 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
         assert _rel(got, ref) < 2e-2, ci
 
 
+def test_bf16_sparse_tail_vs_dense_tail(inputs, oracle_taps):
+    """prob_sparse.hip (conv11 + skip + prob conv + softmax + depth only where prob is gathered; u11 kept in fp32) against
+    the dense conv11 + gathering prob kernel it replaces (u11 rounded to bf16), same bf16 u9 / c0 / weights; and both
+    against the oracle's probability volume samples."""
+    _, taps = oracle_taps
+    got = {}
+    for st in (0, 1):
+        net = _net("bf16", cost_impl=3, sparse_tail=st)
+        out = _run(net, inputs, stop_after=2)
+        prob = net.fetch(2, "prob", 4 * 1024 * 24).view(4, 1024, 24).cpu().numpy()
+        got[st] = prob
+    assert np.isfinite(got[1]).all()
+    np.testing.assert_allclose(got[1].sum(-1), 1.0, rtol=0, atol=1e-5)
+    assert np.abs(got[1] - got[0]).max() < 2e-2                      # one bf16 rounding of u11 apart
+    ref = np.transpose(taps["v1_prob"].numpy(), (0, 2, 1))           # [2,1024,24]
+    e_dense = np.abs(got[0][:2] - ref).max()
+    e_sparse = np.abs(got[1][:2] - ref).max()
+    print("prob error vs oracle: dense tail", e_dense, "sparse tail", e_sparse)
+    assert e_sparse < 3e-2 and e_sparse < e_dense + 5e-3
+
+
 def test_nan_projection_stays_per_sample(inputs):
     """A degenerate pair (singular projection) must poison only its own pose."""
     inp = {k: v.copy() for k, v in inputs.items()}
