@@ -9,7 +9,7 @@
 // One wave per chosen pixel.  The transposed conv is computed per output-parity class exactly like the halo-tile kernel
 // (conv3d_tile.hip, TR mode: 8 classes with 1..8 taps, two taps of 16 channels per 16x16x32 MFMA step, the same packed
 // weight fragments), but its B operand is gathered straight from u9 instead of a staged halo: lane (voxel, k-group) loads
-// the 16-byte half voxel its MFMA lane needs.  A class has up to 12 x 2 x 2 = 48 neighbourhood voxels = 3 fragments.  The
+// the 16-byte half voxel its MFMA lane needs.  A class has 12, 24 or 48 neighbourhood voxels = 1..3 fragments.  The
 // 3 x 3 x D neighbourhood of u11 is kept in LDS in fp32 (never rounded to bf16, never written to HBM), then 24 lanes run
 // the 27-tap prob conv, and the wave reduces softmax and depth.
 #include "common.h"
@@ -69,19 +69,24 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
     constexpr int pd = (PASS >> 2) & 1, ph = (PASS >> 1) & 1, pw = PASS & 1;
     constexpr int KH = 1 + ph, KW = 1 + pw, NT = (1 + pd) * KH * KW, NS = (NT + 1) / 2;
     constexpr int S0 = PASS == 0 ? 0 : PASS == 1 ? 1 : PASS == 2 ? 2 : PASS == 3 ? 3 : PASS == 4 ? 5 : PASS == 5 ? 6 : PASS == 6 ? 8 : 10;
+    // neighbourhood voxels of this parity class: nr x nc pixel columns (1 or 2 each way) x D/2 depths, enumerated column
+    // by column so that the valid slots are contiguous and empty fragments can be skipped (wave-uniform: y, x are)
+    const bool ym = (y & 1) == ph, xm = (x & 1) == pw;                  // the centre row / column has this parity
+    const int nr = ym ? 1 : 2, nc = xm ? 1 : 2;
+    const int nvox = nr * nc * 12;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-      // neighbourhood voxels of this parity class: slot = depth index * 4 + row slot * 2 + column slot
+      if (f * 16 >= nvox) break;
       const int slot = f * 16 + lr;
-      const int zi = slot >> 2, rs = (slot >> 1) & 1, cs = slot & 1;
+      const int ci = slot / 12, zi = slot - ci * 12;
+      const int rs = ym ? 0 : (ci & 1), cs = ym ? ci : (ci >> 1);       // ci = rs + nr*cs
       const int oz = pd + 2 * zi;
-      const bool ym = (y & 1) == ph, xm = (x & 1) == pw;                // the centre row / column has this parity
       const int yy = ym ? y : (rs ? y + 1 : y - 1);
       const int xx = xm ? x : (cs ? x + 1 : x - 1);
-      const bool valid = active && oz < D && (ym ? rs == 0 : true) && (xm ? cs == 0 : true) &&
-                         (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const bool valid = active && slot < nvox && oz < D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
       const int qd = oz >> 1, qh = yy >> 1, qw = xx >> 1;              // input (u9) voxel of tap (0,0,0)
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      // every gather of the fragment is requested before the first MFMA (masked lanes read voxel 0 and are zeroed)
+      uint4 bv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         // MFMA step s: lane groups 0,1 carry tap 2s, groups 2,3 tap 2s+1; each group one 16-byte half of the 16 channels
@@ -93,15 +98,18 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
         const bool pad = hi ? (t1 >= NT) : false;
         const int iz = qd + td, iy = qh + th, ix = qw + tw;
         const bool inb = valid && !pad && iz < Dq && iy < Hq && ix < Wq;  // beyond the input grid: the conv's zero halo
-        uint4 b = make_uint4(0u, 0u, 0u, 0u);
-        if (inb) b = *reinterpret_cast<const uint4*>(u9v + ((((long long)iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8));
-        const uint4 a = wq[((S0 + s) * 16 + lr) * 4 + lg];
-        acc = mma16(a, b, acc);
+        const long long off = inb ? ((((long long)iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8) : 0ll;
+        const uint4 t = *reinterpret_cast<const uint4*>(u9v + off);
+        bv[s] = inb ? t : make_uint4(0u, 0u, 0u, 0u);
       }
-      if (valid && lg < 2) {
-        const int ch = lg * 4;
-        float cv[4];
-        load4(c0v + ((((long long)oz * H + yy) * W + xx) * 8 + ch), cv);
+      const bool wr = valid && lg < 2;
+      const int ch = (lg & 1) * 4;
+      float cv[4];
+      load4(c0v + (wr ? ((((long long)oz * H + yy) * W + xx) * 8 + ch) : 0ll), cv);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc = mma16(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
+      if (wr) {
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
