@@ -54,7 +54,8 @@ int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* 
 int rgbm_adapose_destroy(rgbm_adapose_t* h);
 /* views per cost-volume chunk (default 32); bounds the workspace */
 int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
-/* options: "max_chunk" (views per cost-volume chunk), "sparse_tail" (bf16 + cost_impl 3 only; 1 [default] = conv11, the
+/* options: "max_chunk" (views per cost-volume chunk), "fuse_final" (bf16 only; 1 [default] = PSPNet's final 1x1 runs inside
+ * up_3's kernel and the 64-channel up_3 output is never written; 0 = two launches), "sparse_tail" (bf16 + cost_impl 3 only; 1 [default] = conv11, the
  * skip add, the prob conv, softmax and depth are evaluated only on the 3x3 neighbourhoods of the chosen pixels and u11
  * is never written; 0 = dense conv11 + gathering prob kernel), "cost_impl" (3 = 2 with the depth-sweeping conv0 kernel [default for bf16;
  * fp32 nets run 2]; 2 = halo-tiled 3-D convs with the plane-sweep volume fused into conv0's loader; 1 = halo-tiled convs on a materialised volume; 0 = generic implicit

@@ -21,7 +21,7 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.
 
 class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
-                 cost_impl: int | None = None, sparse_tail: int | None = None):
+                 cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -49,6 +49,8 @@ class AdaPoseNet:
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"cost_impl", int(cost_impl)), "rgbm_adapose_set_option")
         if sparse_tail is not None:
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"sparse_tail", int(sparse_tail)), "rgbm_adapose_set_option")
+        for key, val in (options or {}).items():          # any rgbm_adapose_set_option key (include/rgbm.h), e.g. fuse_final
+            _lib.check(self.lib.rgbm_adapose_set_option(self._h, key.encode(), int(val)), "rgbm_adapose_set_option")
         self._ws = None
         self._ws_B = None
 

@@ -337,8 +337,8 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u1, bf.ups, V, 2 * H, 2 * W, 256, 4 * H, 4 * W, 256, 0, s)) return rc;
   if (int rc = up2.run(bf.ups, bf.u2, V, 1, 4 * H, 4 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
-  if (int rc = up3.run(bf.ups, bf.u3, V, 1, 8 * H, 8 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = fin.run(bf.u3, bf.feat, V, 1, 8 * H, 8 * W, 32, nullptr, 0, nullptr, 0, s)) return rc;
+  // up_3 + final: one launch on the bf16 path (the 64-channel up_3 output then never reaches HBM: `u3` is not written)
+  if (int rc = up3.run_then_1x1(fin, bf.ups, bf.u3, 64, bf.feat, 32, V, 1, 8 * H, 8 * W, fuse_final != 0, nullptr, s)) return rc;
   return 0;
 }
 

@@ -126,10 +126,15 @@ struct ConvDesc {
   int n_pix_tiles, n_ch_tiles;
   // persistent kernel only (filled by its launcher): tiles in total, and exact-division magics for Wq, Hq, Dq
   int n_tiles; unsigned fd_m[3]; int fd_s[3];
+  // optional 1x1 conv fused behind the activation (conv_igemm_ws64_kernel only): y2 = act2(W2 . act(y) + bias2); when set,
+  // `out` is not written.  w2: [cout2_pad][kpad2] K-major bf16 rows of 64 input channels.
+  const void* w2; const float* bias2; void* out2; int ldo2, cout2, kpad2, act2; float slope2;
   double algo_flops, algo_bytes;          // algorithmic work of this launch (profiling only)
 };
 
 int launch_conv(const ConvDesc& d, int dtype, hipStream_t s);
+// true if launch_conv would run d on the three-role 64-channel kernel (the only one that can fuse a trailing 1x1)
+bool conv_ws64_eligible(const ConvDesc& d, int dtype);
 // picks the channel-tile size used by launch_conv for Cout (weights must be padded to it)
 int conv_ch_tile(int Cout);
 int conv_bk(int dtype);  // K-tile in elements

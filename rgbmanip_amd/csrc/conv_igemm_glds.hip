@@ -42,6 +42,9 @@ template <> struct MmaG<unsigned short> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
+  __device__ static __forceinline__ f32x4 run2(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
 };
 template <> struct MmaG<float> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
@@ -851,16 +854,71 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
         else *reinterpret_cast<uint2*>(out + o) = make_uint2(v.x, v.y);
       }
     };
+    // Fused trailing 1x1 (y2 = act2(W2 . y + bias2), e.g. PSPNet's `final` after up_3): the staged tile already is the B
+    // operand layout of an MFMA (pixel row = 64 contiguous channels), so the store waves multiply it by W2 (kept in
+    // registers) and write only y2; the 64-channel tensor never reaches HBM.
+    const int sw = wave - 8;
+    const int lr = lane & 15, lg = lane >> 4;
+    uint4 A2[2][2];
+    float b2[2][4];
+    if (d.w2) {
+      const unsigned short* w2 = reinterpret_cast<const unsigned short*>(d.w2);
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          A2[of][ks] = make_uint4(0u, 0u, 0u, 0u);
+          if (of * 16 < d.cout2) A2[of][ks] = *reinterpret_cast<const uint4*>(w2 + (long long)(of * 16 + lr) * d.kpad2 + ks * 32 + lg * 8);
+        }
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c2 = of * 16 + lg * 4 + e;
+          b2[of][e] = (d.bias2 && c2 < d.cout2) ? d.bias2[c2] : 0.f;
+        }
+    }
+    const int perf = (4 + (KT - 1) - 1) / (KT - 1);       // fused: 16-pixel fragments per K step (4 per wave and tile)
+    auto flush_fused = [&](int k, int j0, int j1) {
+      const int pix_tile = tile_of(k);
+      unsigned short* out2 = reinterpret_cast<unsigned short*>(d.out2);
+      for (int j = j0; j < j1 && j < 4; ++j) {
+        const int r = sw * 64 + j * 16 + lr;
+        const long long m = (long long)pix_tile * BPIX + r;
+        const uint4 B0 = *reinterpret_cast<const uint4*>(stg + r * SROW + lg * 16);
+        const uint4 B1 = *reinterpret_cast<const uint4*>(stg + r * SROW + 64 + lg * 16);
+        unsigned n, qd, qh, qw;
+        decode_row(d, m < d.M ? (unsigned)m : 0u, n, qd, qh, qw);
+        const long long o = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo2;
+#pragma unroll
+        for (int of = 0; of < 2; ++of) {
+          if (of * 16 >= d.cout2) break;
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc = MmaG<T>::run2(A2[of][0], B0, acc);
+          acc = MmaG<T>::run2(A2[of][1], B1, acc);
+          if (m < d.M) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_g(acc[e] + b2[of][e], d.act2, d.slope2);
+            store4(out2 + o + of * 16 + lg * 4, v);
+          }
+        }
+      }
+    };
     int g = 0;
     for (int k = 0; k < n_my; ++k)
       for (int kt = 0; kt < KT; ++kt, ++g) {
         __builtin_amdgcn_s_barrier();
         // the staged tile k-1 was published by barrier (k, 0); it must be drained before barrier (k, KT-1), after which
         // the multiply waves overwrite it
-        if (k > 0 && kt < KT - 1) flush(k - 1, kt * per, (kt + 1) * per);
+        if (k > 0 && kt < KT - 1) {
+          if (d.w2) flush_fused(k - 1, kt * perf, (kt + 1) * perf);
+          else flush(k - 1, kt * per, (kt + 1) * per);
+        }
       }
     __builtin_amdgcn_s_barrier();             // publishes the last staged tile
-    flush(n_my - 1, 0, 8);
+    if (d.w2) flush_fused(n_my - 1, 0, 4);
+    else flush(n_my - 1, 0, 8);
     return;
   }
 
@@ -1115,11 +1173,17 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
   // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel
-  if (sizeof(T) == 2 && uni && conv_ch_tile(d.Cout) == 64 && d.res_mode == RES_NONE && d.KT >= 2 && d.M >= 256 * 256 &&
-      d.M < (1ll << 31) && !(g_debug_flags & 128) &&
-      (((unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T))) & 15ull) == 0ull)
-    return launch_ws64(d, s);
+  if (sizeof(T) == 2 && conv_ws64_eligible(d, BF16)) return launch_ws64(d, s);
+  RGBM_REQUIRE(d.w2 == nullptr, "a fused 1x1 needs the ws64 kernel (check conv_ws64_eligible first)");
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
+}
+
+bool conv_ws64_eligible(const ConvDesc& d, int dtype) {
+  if (dtype != BF16 || (g_debug_flags & (4 | 16 | 128))) return false;
+  if (!conv_uniform_taps(d, 64) || conv_ch_tile(d.Cout) != 64 || d.res_mode != RES_NONE || d.KT < 2) return false;
+  if (d.M < 256 * 256 || d.M >= (1ll << 31)) return false;
+  if (d.w2) return d.Cout == 64 && d.kpad2 == 64 && (d.cout2 == 16 || d.cout2 == 32) && d.ldo2 % 4 == 0;
+  return (((unsigned long long)d.out | ((unsigned long long)d.ldo * 2ull)) & 15ull) == 0ull;
 }
 
 int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {

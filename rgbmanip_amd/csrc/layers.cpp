@@ -134,12 +134,11 @@ void ConvLayer::out_dims(int Di, int Hi, int Wi, int& Do, int& Ho, int& Wo) cons
   Wo = (Wi + 2 * g.pw - g.dilw * (g.KW - 1) - 1) / g.sw + 1;
 }
 
-int ConvLayer::run(const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
-                   const float* bias_override, int bias_stride, hipStream_t s) const {
+int ConvLayer::build_desc(ConvDesc& d, const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res,
+                          int res_mode, const float* bias_override, int bias_stride, int cls) const {
   RGBM_REQUIRE(!packs.empty(), "conv layer not initialised");
   int Do, Ho, Wo;
   out_dims(Di, Hi, Wi, Do, Ho, Wo);
-  ConvDesc d;
   memset(&d, 0, sizeof(d));
   d.in = in; d.out = out; d.res = res;
   d.bias = bias_override ? bias_override : bias;
@@ -149,35 +148,67 @@ int ConvLayer::run(const void* in, void* out, int N, int Di, int Hi, int Wi, int
   d.Cout = Cout_pad; d.ldo = ldo;
   d.Do = Do; d.Ho = Ho; d.Wo = Wo;
   d.act = g.act; d.slope = g.slope; d.res_mode = res ? res_mode : RES_NONE;
+  const PackedConv& pc = packs[cls];
+  d.wgt = pc.w;
+  d.KD = pc.KD; d.KH = pc.KH; d.KW = pc.KW;
+  d.ntaps = pc.ntaps; d.KT = pc.KT; d.Kpad = pc.Kpad;
+  d.lcin = (pc.ntaps > 1 || is_pow2(Cin_pad)) ? ilog2(Cin_pad) : -1;
+  if (g.transposed) {
+    d.Dq = Di; d.Hq = Hi; d.Wq = Wi;
+    d.sd = d.sh = d.sw = 1; d.pd = d.ph = d.pw = 0;
+    d.dild = d.dilh = d.dilw = 1;
+    d.osd = d.osh = d.osw = 2;
+    d.opd = (cls >> 2) & 1; d.oph = (cls >> 1) & 1; d.opw = cls & 1;
+  } else {
+    d.Dq = Do; d.Hq = Ho; d.Wq = Wo;
+    d.sd = g.sd; d.sh = g.sh; d.sw = g.sw; d.pd = g.pd; d.ph = g.ph; d.pw = g.pw;
+    d.dild = g.dild; d.dilh = g.dilh; d.dilw = g.dilw;
+    d.osd = d.osh = d.osw = 1;
+    d.opd = d.oph = d.opw = 0;
+  }
+  d.M = (long long)N * d.Dq * d.Hq * d.Wq;
+  // algorithmic work: real (unpadded) channels, every tap counted (zero padding included, as usual)
+  d.algo_flops = 2.0 * (double)d.M * g.Cout * (double)pc.ntaps * g.Cin;
+  d.algo_bytes = ((double)d.M * g.Cout + (cls == 0 ? (double)N * Di * Hi * Wi * g.Cin : 0.0) +
+                  (res ? (double)d.M * g.Cout : 0.0)) * (double)dtype_size(dtype) +
+                 (double)g.Cout * pc.ntaps * g.Cin * (double)dtype_size(dtype);
+  return 0;
+}
+
+int ConvLayer::run(const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
+                   const float* bias_override, int bias_stride, hipStream_t s) const {
   const int nclass = g.transposed ? 8 : 1;
   for (int cls = 0; cls < nclass; ++cls) {
-    const PackedConv& pc = packs[cls];
-    d.wgt = pc.w;
-    d.KD = pc.KD; d.KH = pc.KH; d.KW = pc.KW;
-    d.ntaps = pc.ntaps; d.KT = pc.KT; d.Kpad = pc.Kpad;
-    d.lcin = (pc.ntaps > 1 || is_pow2(Cin_pad)) ? ilog2(Cin_pad) : -1;
-    if (g.transposed) {
-      d.Dq = Di; d.Hq = Hi; d.Wq = Wi;
-      d.sd = d.sh = d.sw = 1; d.pd = d.ph = d.pw = 0;
-      d.dild = d.dilh = d.dilw = 1;
-      d.osd = d.osh = d.osw = 2;
-      d.opd = (cls >> 2) & 1; d.oph = (cls >> 1) & 1; d.opw = cls & 1;
-    } else {
-      d.Dq = Do; d.Hq = Ho; d.Wq = Wo;
-      d.sd = g.sd; d.sh = g.sh; d.sw = g.sw; d.pd = g.pd; d.ph = g.ph; d.pw = g.pw;
-      d.dild = g.dild; d.dilh = g.dilh; d.dilw = g.dilw;
-      d.osd = d.osh = d.osw = 1;
-      d.opd = d.oph = d.opw = 0;
-    }
-    d.M = (long long)N * d.Dq * d.Hq * d.Wq;
-    // algorithmic work: real (unpadded) channels, every tap counted (zero padding included, as usual)
-    d.algo_flops = 2.0 * (double)d.M * g.Cout * (double)pc.ntaps * g.Cin;
-    d.algo_bytes = ((double)d.M * g.Cout + (cls == 0 ? (double)N * Di * Hi * Wi * g.Cin : 0.0) +
-                    (res ? (double)d.M * g.Cout : 0.0)) * (double)dtype_size(dtype) +
-                   (double)g.Cout * pc.ntaps * g.Cin * (double)dtype_size(dtype);
+    ConvDesc d;
+    if (int rc = build_desc(d, in, out, N, Di, Hi, Wi, ldo, res, res_mode, bias_override, bias_stride, cls)) return rc;
     if (int rc = launch_conv(d, dtype, s)) return rc;
   }
   return 0;
+}
+
+int ConvLayer::run_then_1x1(const ConvLayer& next, const void* in, void* mid, int ldmid, void* out2, int ldo2, int N, int Di, int Hi,
+                            int Wi, bool allow_fuse, bool* fused, hipStream_t s) const {
+  if (fused) *fused = false;
+  const ConvGeom& ng = next.g;
+  const bool is1x1 = !ng.transposed && ng.KD == 1 && ng.KH == 1 && ng.KW == 1 && ng.sd == 1 && ng.sh == 1 && ng.sw == 1 &&
+                     ng.pd == 0 && ng.ph == 0 && ng.pw == 0 && next.packs.size() == 1;
+  if (allow_fuse && is1x1 && !g.transposed && dtype == BF16 && next.dtype == BF16 && next.Cin_pad == Cout_pad) {
+    ConvDesc d;
+    if (int rc = build_desc(d, in, mid, N, Di, Hi, Wi, ldmid, nullptr, RES_NONE, nullptr, 0, 0)) return rc;
+    d.w2 = next.packs[0].w; d.bias2 = next.bias; d.out2 = out2; d.ldo2 = ldo2; d.cout2 = next.Cout_pad;
+    d.kpad2 = next.packs[0].Kpad; d.act2 = ng.act; d.slope2 = ng.slope;
+    if (conv_ws64_eligible(d, dtype)) {
+      d.algo_flops += 2.0 * (double)d.M * ng.Cout * ng.Cin;
+      d.algo_bytes += ((double)d.M * ng.Cout - (double)d.M * g.Cout) * 2.0;      // writes y2 instead of y
+      if (int rc = launch_conv(d, dtype, s)) return rc;
+      if (fused) *fused = true;
+      return 0;
+    }
+  }
+  if (int rc = run(in, mid, N, Di, Hi, Wi, ldmid, nullptr, RES_NONE, nullptr, 0, s)) return rc;
+  int Do, Ho, Wo;
+  out_dims(Di, Hi, Wi, Do, Ho, Wo);
+  return next.run(mid, out2, N, Do, Ho, Wo, ldo2, nullptr, RES_NONE, nullptr, 0, s);
 }
 
 }  // namespace rgbm

@@ -53,6 +53,12 @@ struct ConvLayer {
   int run(const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
           const float* bias_override, int bias_stride, hipStream_t s) const;
   void out_dims(int Di, int Hi, int Wi, int& Do, int& Ho, int& Wo) const;
+  // this conv followed by `next` (a 1x1, stride 1): one fused launch writing only out2 when the kernel selection allows it
+  // (*fused = true; `mid` is then NOT written), otherwise the two layers one after the other through `mid`.
+  int run_then_1x1(const ConvLayer& next, const void* in, void* mid, int ldmid, void* out2, int ldo2, int N, int Di, int Hi, int Wi,
+                   bool allow_fuse, bool* fused, hipStream_t s) const;
+  int build_desc(ConvDesc& d, const void* in, void* out, int N, int Di, int Hi, int Wi, int ldo, const void* res, int res_mode,
+                 const float* bias_override, int bias_stride, int cls) const;
 };
 
 // device upload helpers

@@ -154,6 +154,26 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
         assert _rel(got, ref) < 2e-2, ci
 
 
+def test_bf16_fused_final_conv(inputs, oracle_taps):
+    """up_3 + final in one launch (the store waves of conv_igemm_ws64_kernel multiply the staged bf16 tile by the 1x1
+    weights) against the two-launch path: same bf16 operands, same fp32 accumulation, so the feature maps must agree to
+    one bf16 rounding; and both must stay close to the oracle's feature map."""
+    _, taps = oracle_taps
+    feats = {}
+    for ff in (0, 1):
+        net = _net("bf16", options={"fuse_final": ff})
+        _run(net, inputs, stop_after=1)
+        feats[ff] = net.fetch(2, "feat", 4 * 224 * 224 * 32).view(4, 224, 224, 32).cpu().numpy()
+    scale = np.abs(feats[0]).max()
+    assert np.isfinite(feats[1]).all()
+    assert np.abs(feats[1] - feats[0]).max() / scale < 8e-3
+    assert np.abs(feats[1] - feats[0]).mean() / np.abs(feats[0]).mean() < 1e-3
+    ref = taps["feat1"].numpy()                                        # [2,32,224,224]
+    for ff in (0, 1):
+        got = np.transpose(feats[ff][:2], (0, 3, 1, 2))
+        assert _rel(got, ref) < 3e-2, ff
+
+
 def test_bf16_sparse_tail_vs_dense_tail(inputs, oracle_taps):
     """prob_sparse.hip (conv11 + skip + prob conv + softmax + depth only where prob is gathered; u11 kept in fp32) against
     the dense conv11 + gathering prob kernel it replaces (u11 rounded to bf16), same bf16 u9 / c0 / weights; and both
