@@ -64,6 +64,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
   __shared__ unsigned hist[4096];
   __shared__ unsigned long long sel_prefix;
   __shared__ unsigned sel_rank, sel_lt, sel_eq, total_cnt;
+  __shared__ unsigned wsum[PP_THREADS / 64];
   __shared__ float hmax[3];
 
   const int b = blockIdx.x, t = threadIdx.x;
@@ -114,25 +115,47 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
       }
     }
     __syncthreads();
-    if (t == 0) {
-      if (pass == 0) {
-        unsigned n = 0;
-        for (int i = 0; i < 4096; ++i) n += hist[i];
-        total_cnt = n;
-        sel_rank = n / 2;               // upper middle (0-based) of the i<j list
-      }
-      unsigned rk = sel_rank, acc = 0;
-      int d = 0;
+    // bucket selection by all 1024 threads (4 bins each): block-wide exclusive scan of the bin counts, then the one
+    // thread whose bins contain the wanted rank publishes the digit.  (A single thread walking 4096 bins per pass cost
+    // ~0.9 ms of the 3.3 ms this kernel took for 256 poses.)
+    {
       const int nb = 1 << wd;
-      for (d = 0; d < nb; ++d) {
-        if (acc + hist[d] > rk) break;
-        acc += hist[d];
+      unsigned c[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] = (4 * t + k < nb) ? hist[4 * t + k] : 0u;
+      const unsigned tsum = c[0] + c[1] + c[2] + c[3];
+      unsigned incl = tsum;
+      const int ln = t & 63, wv = t >> 6;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (ln >= off) incl += o;
       }
-      if (d >= nb) d = nb - 1;
-      sel_prefix = (pass == 0 ? 0ull : (sel_prefix << wd)) | (unsigned long long)d;
-      if (pass == 0) sel_lt = acc; else sel_lt += acc;
-      sel_rank = rk - acc;
-      sel_eq = hist[d];
+      if (ln == 63) wsum[wv] = incl;
+      __syncthreads();
+      unsigned wbase = 0, total = 0;
+      for (int k = 0; k < PP_THREADS / 64; ++k) { const unsigned w = wsum[k]; if (k < wv) wbase += w; total += w; }
+      const unsigned excl = wbase + incl - tsum;
+      const unsigned rk = pass == 0 ? total / 2 : sel_rank;      // pass 0: upper middle (0-based) of the i<j list
+      __syncthreads();                                            // everybody has read sel_rank / wsum
+      if (pass == 0 && t == 0) total_cnt = total;
+      // rank inside my bins, or (defensive, cannot happen for a consistent histogram) past the end: last bin
+      const bool mine = (rk >= excl && rk < excl + tsum) || (rk >= total && 4 * t <= nb - 1 && nb - 1 < 4 * t + 4);
+      if (mine) {
+        unsigned acc = excl;
+        int dsel = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (dsel < 0) {
+            if (acc + c[k] > rk) dsel = 4 * t + k; else acc += c[k];
+          }
+        }
+        if (dsel < 0) { dsel = nb - 1; acc = total - hist[nb - 1]; }
+        sel_prefix = (pass == 0 ? 0ull : (sel_prefix << wd)) | (unsigned long long)dsel;
+        if (pass == 0) sel_lt = acc; else sel_lt += acc;
+        sel_rank = rk - acc;
+        sel_eq = hist[dsel];
+      }
     }
     __syncthreads();
     prefix = sel_prefix;
