@@ -494,6 +494,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
 // pieces per wave and tile) lives in 4 extra waves, one per SIMD, whose scalar/vector work runs in the issue gaps of the
 // MFMA streams.  Same operand layout, swizzle, fragment maps and epilogue as the kernels above.
 // ---------------------------------------------------------------------------------------------------------
+// LDS chunk swizzle of the weight rows in conv_igemm_ws_kernel: conflict-free for its permuted fragment rows
+__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
 // n / divisor for n < 2^31 with a host-made magic: one 32x32->64 multiply and a shift instead of ~35 instructions
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m, int sh) {
   return (unsigned)(((unsigned long long)n * m) >> sh);
@@ -578,8 +581,10 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
         rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
       }
 #pragma unroll
-      for (int i = 0; i < WL; ++i)
-        wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + r0 + 32 * i) * d.Kpad + js * E);
+      for (int i = 0; i < WL; ++i) {
+        const int row = r0 + 32 * i;
+        wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
+      }
       tkd = tkh = tkw = tc = 0;
     };
 
@@ -636,8 +641,8 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     const int cidx = s * 4 + lg;
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
-      const int row = wch + a * 16 + lr;
-      af[a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+      const int row = wch + (lr >> 2) * 16 + a * 4 + (lr & 3);       // MFMA row lr of fragment a = channel (lr>>2)*16 + a*4 + (lr&3)
+      af[a] = W[row * 8 + (cidx ^ swz_w(row))];
     }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
@@ -704,47 +709,59 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
       nn[b] = (int)n;
       obase[b] = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo;
     }
-    const int ch0 = ch_tile * BCH + wch + lg * 4;
-    typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type raw4;      // 4 elements as loaded
+    // channel map of this kernel: MFMA row r of fragment a is channel (r>>2)*16 + a*4 + (r&3) of the wave's 64, so the four
+    // fragments give a lane 16 CONSECUTIVE channels (lg*16 ..) of its pixel: 16-byte residual reads and stores
+    // (half as many memory instructions as the plain C layout's 8-byte pieces; the epilogue is issue-bound)
+    const int chL = ch_tile * BCH + wch + lg * 16;
+    constexpr int CHK = 16 / (int)sizeof(T);             // channels per 16-byte chunk
+    constexpr int NQ = 16 / CHK;                         // chunks per lane and pixel
 #pragma unroll
-    for (int bh = 0; bh < FN; bh += 2) {               // two fragments (8 residual reads in flight) at a time
-      raw4 rr[FM][2];
+    for (int bh = 0; bh < FN; bh += 2) {                 // two pixel fragments (2*NQ residual reads in flight) at a time
+      uint4 rr[NQ][2];
       if (d.res_mode != RES_NONE) {
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int a = 0; a < FM; ++a) {
-            const int ch = ch0 + a * 16;
-            const bool ok = pok[bh + bb] && ch < d.Cout;
-            rr[a][bb] = *reinterpret_cast<const raw4*>(res + (ok ? obase[bh + bb] + ch : 0ll));   // masked lanes read element 0
+          for (int q = 0; q < NQ; ++q) {
+            const int c = chL + q * CHK;
+            const bool ok = pok[bh + bb] && c + CHK <= d.Cout;
+            rr[q][bb] = *reinterpret_cast<const uint4*>(res + (ok ? obase[bh + bb] + c : 0ll));      // masked lanes read element 0
           }
       }
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         const int b = bh + bb;
 #pragma unroll
-        for (int a = 0; a < FM; ++a) {
-          const int ch = ch0 + a * 16;
-          if (!pok[b] || ch >= d.Cout) continue;
-          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-          if (d.bias) {
-            const float* bp = d.bias + (long long)nn[b] * d.bias_stride + ch;
+        for (int q = 0; q < NQ; ++q) {
+          const int c = chL + q * CHK;
+          if (!pok[b] || c >= d.Cout) continue;
+          const bool whole = c + CHK <= d.Cout;          // Cout is a multiple of 4: a bf16 tail chunk holds 4 channels
+          float v[CHK], rv[CHK];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bp[e];
+          for (int e = 0; e < CHK; ++e) v[e] = acc[(q * CHK + e) >> 2][b][(q * CHK + e) & 3];
+          if (d.bias) {
+            const float* bp = d.bias + (long long)nn[b] * d.bias_stride + c;
+#pragma unroll
+            for (int e = 0; e < CHK; ++e) if (e < 4 || whole) v[e] += bp[e];
           }
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (d.res_mode != RES_NONE) load4(reinterpret_cast<const T*>(&rr[a][bb]), rv);
+#pragma unroll
+          for (int e = 0; e < CHK; ++e) rv[e] = 0.f;
+          if (d.res_mode != RES_NONE) {
+            if (whole) unpack_chunk(rr[q][bb], rv, T());
+            else load4(res + obase[b] + c, rv);
+          }
           if (d.res_mode == RES_PRE_ACT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            for (int e = 0; e < CHK; ++e) v[e] += rv[e];
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
+          for (int e = 0; e < CHK; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
           if (d.res_mode == RES_POST_ACT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            for (int e = 0; e < CHK; ++e) v[e] += rv[e];
           }
-          store4(out + obase[b] + ch, v);
+          if (whole) *reinterpret_cast<uint4*>(out + obase[b] + c) = pack_chunk(v, T());
+          else store4(out + obase[b] + c, v);
         }
       }
     }
@@ -1169,7 +1186,9 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   const bool uni = conv_uniform_taps(d, 8 * (16 / (int)sizeof(T))) && !(g_debug_flags & 16);
   // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
-    if (uni && !(g_debug_flags & 64)) return launch_ws<T>(d, s);                    // role-specialised (uniform taps only)
+    // role-specialised (uniform taps, 16-byte aligned output / residual rows)
+    const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
+    if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) return launch_ws<T>(d, s);
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
   // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel
