@@ -821,6 +821,14 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
 // Persistent over tiles with one continuous 3-stage K ring, one barrier per K step for all 12 waves plus one final
 // barrier that publishes the last staged tile.
 // ---------------------------------------------------------------------------------------------------------
+//
+// RH (row halo; 3x3, stride 1, pad = dilation <= 4, Cin a multiple of 64): a K step is one kernel ROW (kh) of one 64-channel
+// input chunk.  The 3 kw taps of that row read the same pixels shifted by 0, dil, 2*dil GEMM rows, so ONE X stage of
+// 256 + 2*dil rows serves all three (the multiply waves read their B fragments at row offsets kw*dil; lanes whose
+// neighbour falls off the image row read a zero row instead), with the 3 x 64 weight rows of that kernel row beside it.
+// Per tile the L2->LDS traffic drops 2.1x (3 x 57 KB instead of 9 x 40 KB for Cin = 64) and the barriers 3x; a step holds
+// 96 MFMAs per wave.  Two 57 KB stages (plain double buffering) + the staging tile fit the 160 KB LDS.
+template <bool RH>
 __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) {
   typedef unsigned short T;
   constexpr int BCH = 64, BPIX = 256;
@@ -829,16 +837,22 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
   constexpr int WL = BCH / 32;               // 2 weight rows per request thread
   constexpr int NP = XR + WL;                // 10 pieces per request wave and K tile
   constexpr int FM = 4, FN = 4;
-  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (40 KB)
+  constexpr int HXROWS = 264;                // RH: X rows per stage (256 + 2*dil, padded to whole 8-row pieces)
+  constexpr int HWROWS = 3 * BCH;            // RH: weight rows per stage (kw-major)
+  constexpr int NST = RH ? 2 : 3;            // ring depth
+  constexpr int STAGE = RH ? (HWROWS + HXROWS) * 8 : (BCH + BPIX) * 8;    // uint4 slots per stage (57 KB / 40 KB)
   constexpr int SROW = 144;                  // bytes per staged pixel row (128 + 16 pad)
   extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
-  unsigned char* stg = reinterpret_cast<unsigned char*>(lds3 + 3 * STAGE);
+  const uint4* zrow = lds3 + NST * STAGE;    // RH: 8 slots (one row) of zeros
+  unsigned char* stg = reinterpret_cast<unsigned char*>(lds3 + NST * STAGE + (RH ? 8 : 0));
   static_assert(NP == 10, "the counted waits below assume 10 pieces per tile");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KT = d.KT;
+  const int NCC = d.Cin >> 6;                // RH: 64-channel input chunks
+  const int KT = RH ? 3 * NCC : d.KT;        // K steps per tile
+  if (RH && tid < 8) lds3[NST * STAGE + tid] = make_uint4(0u, 0u, 0u, 0u);      // visible after the first barrier
   const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = n_my * KT;               // every wave passes total + 1 barriers
   auto tile_of = [&](int k) {
@@ -941,6 +955,70 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
 
   if (wave >= 4) {
     // ------------------------------------------------------------------ request waves
+    if constexpr (RH) {
+      const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+      const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+      const int pw = wave - 4;
+      const int j = lane & 7, r8 = lane >> 3;
+      const int dil = d.dilw;
+      constexpr int NXP = HXROWS / 8;                      // 33 X pieces, 24 W pieces per step, dealt round-robin to 4 waves
+      constexpr int NWP = HWROWS / 8;
+      constexpr int MXP = (NXP + 3) / 4, MWP = NWP / 4;    // per wave: up to 9 X pieces, 6 W pieces
+      const char* xrowp[MXP];
+      unsigned xmask[MXP];
+      const char* wrowp[MWP];
+      const char* zero = reinterpret_cast<const char*>(g_zero_page);
+      const unsigned ldsb = __builtin_amdgcn_readfirstlane(lds_addr(lds3));
+#pragma unroll
+      for (int i = 0; i < MWP; ++i) {                      // weight row wr = kw*64 + channel: K index of step (kh, cc) = (kh*3 + kw)*Cin + cc*64
+        const int wr = (pw + 4 * i) * 8 + r8;
+        const int kw = wr >> 6, ch = wr & 63;
+        wrowp[i] = reinterpret_cast<const char*>(wgt + (long long)ch * d.Kpad + (long long)kw * d.Cin + (j ^ ((wr >> 1) & 7)) * E);
+      }
+      auto enter_tile = [&](int k) {
+        const long long p0 = (long long)tile_of(k) * BPIX;
+#pragma unroll
+        for (int i = 0; i < MXP; ++i) {
+          const int xr = (pw + 4 * i) * 8 + r8;            // LDS row xr holds GEMM row m = p0 - dil + xr
+          const long long m = p0 - dil + xr;
+          unsigned mk = 0;
+          long long pix0 = 0;
+          if ((pw + 4 * i) < NXP && xr < BPIX + 2 * dil && m >= 0 && m < d.M) {
+            unsigned n, qd, qh, qw;
+            decode_row(d, (unsigned)m, n, qd, qh, qw);
+            for (int kh = 0; kh < 3; ++kh) mk |= (unsigned)((unsigned)((int)qh + (kh - 1) * dil) < (unsigned)d.Hi) << kh;
+            pix0 = ((long long)n * d.Hi + ((int)qh - dil)) * d.Wi + (int)qw;      // input pixel of kernel row 0
+          }
+          xmask[i] = mk;
+          xrowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((xr >> 1) & 7)) * E) * 2ll;
+        }
+      };
+      int ikh = 0, icc = 0, itile = 0;
+      auto issue = [&](int stage) {
+        if (ikh == 0 && icc == 0) enter_tile(itile);
+        const unsigned sbase = ldsb + (unsigned)stage * (STAGE * 16);
+        const long long xoff = ((long long)ikh * dil * d.Wi * d.Cin + icc * 64) * 2ll;
+        const long long woff = ((long long)ikh * 3 * d.Cin + icc * 64) * 2ll;
+#pragma unroll
+        for (int i = 0; i < MXP; ++i) {
+          if (pw + 4 * i < NXP) {                          // wave-uniform
+            const char* src = ((xmask[i] >> ikh) & 1u) ? xrowp[i] + xoff : zero;
+            glds16(src, sbase + (HWROWS * 8 + (pw + 4 * i) * 64) * 16);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MWP; ++i) glds16(wrowp[i] + woff, sbase + ((pw + 4 * i) * 64) * 16);
+        if (++icc == NCC) { icc = 0; if (++ikh == 3) { ikh = 0; ++itile; } }
+      };
+      if (total > 0) issue(0);
+      for (int g = 0; g < total; ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // step g landed (double buffering: nothing else is in flight)
+        __builtin_amdgcn_s_barrier();                        // ... and every wave is done with the other stage
+        if (g + 1 < total) issue((g + 1) & 1);
+      }
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
     const int pw = wave - 4;
@@ -1054,6 +1132,51 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     for (int a = 0; a < FM; ++a)
 #pragma unroll
       for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RH) {
+      // per tile: which lanes lose their left / right neighbour to the image edge (they read the zero row instead)
+      const int dil = d.dilw;
+      const long long p0 = (long long)tile_of(k) * BPIX;
+      bool eL[FN], eR[FN];
+#pragma unroll
+      for (int b = 0; b < FN; ++b) {
+        const long long m = p0 + wpix + b * 16 + lr;
+        unsigned n, qd, qh, qw;
+        decode_row(d, m < d.M ? (unsigned)m : 0u, n, qd, qh, qw);
+        eL[b] = (int)qw - dil < 0;
+        eR[b] = (int)qw + dil >= d.Wi;
+      }
+      for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint4* W = lds3 + (st & 1) * STAGE;
+        const uint4* X = W + HWROWS * 8;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int cidx = s2 * 4 + lg;
+            uint4 af[FM], bf[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+              const int row = kw * 64 + a * 16 + lr;
+              af[a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+              const int row = wpix + b * 16 + lr + kw * dil;
+              const bool edge = kw == 0 ? eL[b] : (kw == 2 ? eR[b] : false);
+              const uint4* src = edge ? zrow + cidx : X + row * 8 + (cidx ^ ((row >> 1) & 7));
+              bf[b] = *src;
+            }
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+              for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+          }
+        }
+        ++st;
+      }
+    } else {
     for (int kt = 0; kt < KT; ++kt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads returned, staged tile written
       __builtin_amdgcn_s_barrier();
@@ -1068,6 +1191,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
       st = st == 2 ? 0 : st + 1;
     }
     mma_half(af1, bf1);
+    }
     // ---- bias + activation + bf16 pack into the staging tile (the store waves have drained the previous one) ----
     const int pix_tile = tile_of(k);
 #pragma unroll
@@ -1099,9 +1223,18 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
   __builtin_amdgcn_s_barrier();
 }
 
+// row-halo variant of the 64-channel kernel: 2-D 3x3, stride 1, "same" padding, Cin a multiple of 64
+static bool conv_rowhalo_ok(const ConvDesc& d) {
+  return d.KD == 1 && d.KH == 3 && d.KW == 3 && d.sd == 1 && d.sh == 1 && d.sw == 1 && d.Dq == 1 && d.Di == 1 &&
+         d.dilh == d.dilw && d.dilw >= 1 && d.dilw <= 4 && d.ph == d.dilh && d.pw == d.dilw && d.pd == 0 &&
+         d.lcin >= 6 && d.Hq == d.Hi && d.Wq == d.Wi && d.Wi > 2 * d.dilw && d.osh == 1 && d.osw == 1 && !(g_debug_flags & 256);
+}
+
 static int launch_ws64(ConvDesc d, hipStream_t s) {
   constexpr int BCH = 64, BPIX = 256;
-  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4) + (size_t)BPIX * 144;
+  const bool rh = conv_rowhalo_ok(d);
+  const size_t LDS = rh ? 2 * (size_t)(3 * BCH + 264) * 8 * sizeof(uint4) + 128 + (size_t)BPIX * 144
+                        : 3 * (size_t)(BCH + BPIX) * 8 * sizeof(uint4) + (size_t)BPIX * 144;
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = 1;
   d.n_tiles = d.n_pix_tiles;
@@ -1111,7 +1244,8 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   static int n_cu = 0;
   static bool attr_done = false;
   if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   if (n_cu == 0) {
@@ -1123,7 +1257,8 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   }
   const int grid = d.n_tiles < n_cu ? d.n_tiles : n_cu;
   prof_begin_launch(s, 15, d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL(conv_igemm_ws64_kernel, dim3((unsigned)grid), dim3(768), LDS, s, d);
+  if (rh) hipLaunchKernelGGL(conv_igemm_ws64_kernel<true>, dim3((unsigned)grid), dim3(768), LDS, s, d);
+  else hipLaunchKernelGGL(conv_igemm_ws64_kernel<false>, dim3((unsigned)grid), dim3(768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

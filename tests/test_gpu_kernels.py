@@ -49,6 +49,9 @@ CONV2D_CASES = [
     ("ws64_prelu_bias", 3, 64, 150, 151, 64, 3, 1, 1, 1, True, 2, 0),
     ("ws64_cout48", 3, 128, 149, 150, 48, 3, 1, 1, 1, True, 1, 0),
     ("ws64_two_ktiles", 5, 128, 120, 121, 64, 1, 1, 0, 1, False, 0, 0),
+    ("ws64_rowhalo_dil2", 3, 64, 150, 151, 64, 3, 1, 2, 2, True, 1, 0),
+    ("ws64_rowhalo_dil4_cin256", 2, 256, 190, 187, 56, 3, 1, 4, 4, False, 2, 0),
+    ("ws64_narrow_rows", 40, 64, 200, 9, 64, 3, 1, 1, 1, True, 1, 0),
 ]
 
 
