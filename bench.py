@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
     ap.add_argument("--ppo-envs", type=int, default=512, help="envs per GPU for the PPO leg (0 = skip it)")
+    ap.add_argument("--no-prepare", action="store_true", help="skip the device-side prepare_model_input leg")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()
@@ -136,6 +137,41 @@ def main():
         elapsed = float(tt.item())
     n_valid = int(valid.sum().item())
     finite = bool(torch.isfinite(bbox).all().item())
+
+    # ---- SURVEY 8f-1 leg (not part of `value`): device-side prepare_model_input on 480x640 frames, vs the host numpy path ----
+    prep_res = None
+    if rank == 0 and not args.no_prepare:
+        from rgbmanip_amd.adapose import prepare_inputs
+        from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+        nf = 256
+        gen = torch.Generator(device=device).manual_seed(0)
+        frames = torch.rand(nf, 480, 640, 3, generator=gen, device=device)
+        yy, xx = torch.meshgrid(torch.arange(480, device=device), torch.arange(640, device=device), indexing="ij")
+        cy = 140 + 200 * torch.rand(nf, generator=gen, device=device)
+        cx = 160 + 320 * torch.rand(nf, generator=gen, device=device)
+        ry = 40 + 80 * torch.rand(nf, generator=gen, device=device)
+        rx = 40 + 110 * torch.rand(nf, generator=gen, device=device)
+        masks = ((((yy[None] - cy[:, None, None]) / ry[:, None, None]) ** 2 + ((xx[None] - cx[:, None, None]) / rx[:, None, None]) ** 2) < 1).to(torch.uint8)
+        Kf = torch.tensor([[439.31, 0, 320.0], [0, 439.31, 240.0], [0, 0, 1.0]], dtype=torch.float64, device=device).repeat(nf, 1, 1)
+        prepare_inputs(frames, masks, Kf, 224, 1024, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for it in range(3):
+            po = prepare_inputs(frames, masks, Kf, 224, 1024, it)
+        torch.cuda.synchronize()
+        dev_ms = (time.perf_counter() - t1) / 3 * 1e3
+        est = AdaPoseEstimator_v5.__new__(AdaPoseEstimator_v5)          # host arithmetic only: no network needed
+        est.rng = np.random.default_rng(0)
+        est._frame = 0
+        fh, mh = frames[:4].cpu().numpy(), masks[:4].cpu().numpy()
+        t1 = time.perf_counter()
+        for i in range(4):
+            est.prepare_model_input(fh[i], mh[i], Kf[0].cpu().numpy(), 224)
+        host_ms = (time.perf_counter() - t1) / 4 * 1e3
+        prep_res = {"frames": nf, "device_ms_per_frame": round(dev_ms / nf, 4), "device_frames_per_sec": round(nf / dev_ms * 1e3, 1),
+                    "host_numpy_ms_per_frame": round(host_ms, 2), "valid_frames": int(po["valid"].sum().item()),
+                    "note": "480x640x3 f32 frame + mask -> 224x224 normalised crop, 1024 choose indices, cropped intrinsics (interface_v5.py:58-170)"}
+        del frames, masks
 
     # ---- PPO leg: AdaPose-in-the-loop rollout (synthetic vec-env stand-in) + HIP learn phase, cfg/controller/rl.yaml ----
     ppo_res = None
@@ -194,6 +230,8 @@ def main():
         }
         if ppo_res is not None:
             res["ppo"] = ppo_res
+        if prep_res is not None:
+            res["prepare_model_input"] = prep_res
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -80,6 +80,22 @@ int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, con
                              int32_t* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Batched device-side input preparation.
+ * Replaces: AdaPoseEstimator_v5.prepare_model_input   models/pose_estimator/AdaPose/interface_v5.py:58-170
+ *           get_bbox                                  models/pose_estimator/AdaPose/lib/utils.py:10-38
+ * rgb [N,H,W,3] f32 in [0,1] (the env's camera frames), mask [N,H,W] u8 (0/1), K [N,3,3] f64 camera intrinsics  ->
+ * img [N,3,S,S] f32 (cropped, INTER_LINEAR-resized, ImageNet-normalised), choose [N,P] i32 (pixel indices of the
+ * INTER_NEAREST-resized mask: every nonzero pixel in order, wrap-padded to P, or an ordered random P-subset),
+ * pts2d [N,P,2] f32 (optional, may be NULL), Kcrop [N,3,3] f64 (crop-adjusted intrinsics), window [N,4] i32
+ * (rmin,rmax,cmin,cmax), valid [N] i32 (0 where the reference returns None: empty mask / empty resized mask; such
+ * frames get finite dummy outputs).  scratch: N*S*S bytes.  The P-subset is drawn by a seeded hash instead of the
+ * reference's global np.random.shuffle (same distribution, reproducible).  H, W >= 40; S*S <= 65536.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, int N, int H, int W, int S, int P,
+                        uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
+                        int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * PPO rollout storage.
  * Replaces: RolloutStorage.compute_returns   algo/ppo/ppo/storage.py:50-64
  * rewards/values/returns/adv [T,N] f32, dones [T,N] u8, last_values [N] f32.

@@ -145,3 +145,31 @@ def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_
                                             _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(ts), _lib.ptr(valid),
                                             _lib.stream_ptr(stream)), "rgbm_adapose_postprocess")
     return bbox, ts, valid
+
+
+def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None):
+    """Batched device-side `AdaPoseEstimator_v5.prepare_model_input` (`interface_v5.py:58-170`).
+
+    rgb [N,H,W,3] float32 in [0,1], mask [N,H,W] (0/1), K [N,3,3]: torch CUDA tensors (or anything torch.as_tensor accepts).
+    Returns dict(img [N,3,S,S] f32, choose [N,P] i32, Kcrop [N,3,3] f64, window [N,4] i32, valid [N] i32[, pts2d])."""
+    lib = _lib.load()
+    dev = rgb.device if isinstance(rgb, torch.Tensor) and rgb.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    rgb = torch.as_tensor(rgb).to(device=dev, dtype=torch.float32).contiguous()
+    mask = (torch.as_tensor(mask).to(device=dev) != 0).to(torch.uint8).contiguous()
+    K = torch.as_tensor(K).to(device=dev, dtype=torch.float64).contiguous()
+    N, H, W, _ = rgb.shape
+    S, P = int(img_size), int(n_pts)
+    img = torch.empty(N, 3, S, S, dtype=torch.float32, device=dev)
+    choose = torch.empty(N, P, dtype=torch.int32, device=dev)
+    pts2d = torch.empty(N, P, 2, dtype=torch.float32, device=dev) if want_pts2d else None
+    Kcrop = torch.empty(N, 3, 3, dtype=torch.float64, device=dev)
+    window = torch.empty(N, 4, dtype=torch.int32, device=dev)
+    valid = torch.empty(N, dtype=torch.int32, device=dev)
+    scratch = torch.empty(N * S * S, dtype=torch.uint8, device=dev)
+    _lib.check(lib.rgbm_prepare_inputs(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), N, H, W, S, P, int(seed) & 0xFFFFFFFF,
+                                       _lib.ptr(img), _lib.ptr(choose), _lib.ptr(pts2d), _lib.ptr(Kcrop), _lib.ptr(window),
+                                       _lib.ptr(valid), _lib.ptr(scratch), _lib.stream_ptr(stream)), "rgbm_prepare_inputs")
+    out = {"img": img, "choose": choose, "Kcrop": Kcrop, "window": window, "valid": valid}
+    if want_pts2d:
+        out["pts2d"] = pts2d
+    return out

@@ -265,6 +265,14 @@ extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, 
   return rc;
 }
 
+// Batched device-side prepare_model_input (interface_v5.py:58-170); see include/rgbm.h.
+extern "C" int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, int N, int H, int W, int S,
+                                   int P, uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
+                                   int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream) {
+  return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, N, H, W, S, P, seed, img_out, choose_out, pts2d_out, Kcrop_out,
+                               window_out, valid_out, scratch, (hipStream_t)stream);
+}
+
 extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; return 0; }
 
 // ---- PPO policy -------------------------------------------------------------------------------------------------

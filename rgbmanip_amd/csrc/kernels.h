@@ -60,6 +60,11 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
                        int D, int H, int W, hipStream_t s);
 
+// prepare.hip — batched device-side AdaPoseEstimator_v5.prepare_model_input
+int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, int N, int H, int W, int S, int P,
+                          unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
+                          unsigned char* small_scratch, hipStream_t s);
+
 // postproc.hip
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
                        const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s);

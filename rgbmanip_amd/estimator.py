@@ -8,14 +8,16 @@ never raises for bad samples (empty mask / non-finite result -> `default_bbox`, 
 Differences that are the point of this build: `estimate` prepares all N samples, runs ONE batched network call and ONE
 batched post-processing launch on the device instead of N serial B=1 calls with a host round trip each
 (interface_v5.py:218-225, 259-286, 318-321), and it skips `draw_result` (a discarded debug drawing, :364).
-The crop/resize/sampling step is still host numpy here (SURVEY.md §8f-1 ranks its device version next).
+The crop/resize/sampling step runs on the host in numpy by default (the reference's arithmetic incl. its global-RNG
+subset) or, with cfg["hip_prepare"] == "device", batched on the GPU (`rgbm_prepare_inputs`; the 1024-subset
+is then a seeded hash, cfg["hip_prepare_seed"]); `estimate_device` takes device-resident frames and never leaves the GPU.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-from .adapose import AdaPoseNet, postprocess
+from .adapose import AdaPoseNet, postprocess, prepare_inputs
 
 DEFAULT_BBOX = np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]],
                           dtype=np.float64) + 10.0
@@ -84,6 +86,16 @@ def _resize_linear(img, size):
     return top * (1 - ay) + bot * ay
 
 
+def _mix32(seed, frame, idx):
+    """Seeded subset hash of csrc/prepare.hip (murmur3 finaliser), uint32 arithmetic."""
+    with np.errstate(over="ignore"):
+        h = np.uint32(seed) ^ (np.uint32(frame) * np.uint32(0x9E3779B9)) ^ (np.asarray(idx, dtype=np.uint32) * np.uint32(0x85EBCA6B))
+        h = h ^ (h >> np.uint32(16)); h = h * np.uint32(0x85EBCA6B)
+        h = h ^ (h >> np.uint32(13)); h = h * np.uint32(0xC2B2AE35)
+        h = h ^ (h >> np.uint32(16))
+    return h.astype(np.uint32)
+
+
 class AdaPoseEstimator_v5(BasePoseEstimator):
     def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0):
         super().__init__(env, cfg, logger)
@@ -100,6 +112,9 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         self.dtype = dtype or cfg.get("hip_dtype", "fp32")
         self.estimator = AdaPoseNet(state_dict, dtype=self.dtype, device=device)
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
+        self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
+        self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))
+        self._frame = 0               # hash-subset mode of the host path: index of the sample being prepared
 
     # ------------------------------------------------------------------ interface_v5.py:58-170
     def prepare_model_input(self, rgb, mask, intrinsic, resize_size):
@@ -110,10 +125,14 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         small = _resize_nearest(mask[rmin:rmax, cmin:cmax].astype(np.float32), resize_size)
         choose = small.flatten().nonzero()[0]
         if len(choose) > 1024:
-            keep = np.zeros(len(choose), dtype=int)
-            keep[:1024] = 1
-            self.rng.shuffle(keep)
-            choose = choose[keep.nonzero()]
+            if isinstance(self.rng, tuple):             # ("hash", seed): the device path's reproducible subset, on the host
+                keys = _mix32(self.rng[1], self._frame, choose).astype(np.uint64)
+                choose = choose[np.sort(np.lexsort((np.arange(len(choose)), keys))[:1024])]
+            else:
+                keep = np.zeros(len(choose), dtype=int)
+                keep[:1024] = 1
+                self.rng.shuffle(keep)
+                choose = choose[keep.nonzero()]
         elif len(choose) == 0:
             return None, None, None, None
         else:
@@ -134,10 +153,20 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                  view2_mask_batch, view2_extrinsic_batch):
         S = self.cfg["img_size"]
         n = len(rgb1_batch)
+        if self.prepare_mode == "device":
+            return self.estimate_device(np.asarray(camera_intrinsic_batch), np.asarray(rgb1_batch, dtype=np.float32),
+                                        np.asarray(view1_mask_batch), np.asarray(view1_extrinsic_batch),
+                                        np.asarray(rgb2_batch, dtype=np.float32), np.asarray(view2_mask_batch),
+                                        np.asarray(view2_extrinsic_batch)).cpu().numpy()
         out = np.repeat(DEFAULT_BBOX[None], n, axis=0)
         rows, img1, img2, ch1, ch2, P1, P2, K1, E1 = [], [], [], [], [], [], [], [], []
         for i in range(n):
+            self._frame = i
+            if isinstance(self.rng, tuple):
+                self.rng = ("hash", self.prepare_seed)
             a = self.prepare_model_input(rgb1_batch[i], view1_mask_batch[i], camera_intrinsic_batch[i], S)
+            if isinstance(self.rng, tuple):
+                self.rng = ("hash", self.prepare_seed + 1)
             b = self.prepare_model_input(rgb2_batch[i], view2_mask_batch[i], camera_intrinsic_batch[i], S)
             if a[0] is None or b[0] is None:
                 continue
@@ -158,6 +187,31 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         bbox, _, _ = postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], ch1, np.stack(K1), np.stack(E1), img_size=S)
         out[np.asarray(rows)] = bbox.cpu().numpy()
         return out
+
+    # ------------------------------------------------------------------ the same pipeline without leaving the device
+    def estimate_device(self, K, rgb1, mask1, E1, rgb2, mask2, E2):
+        """`estimate` for frames that already live on the GPU (or get uploaded once): K [N,3,3], rgb [N,H,W,3] float32 in [0,1],
+        mask [N,H,W], E [N,4,4] world->camera.  Returns a CUDA tensor [N,8,3] float64; samples the reference would skip
+        (empty mask) or reject (non-finite box) hold `default_bbox`."""
+        S = self.cfg["img_size"]
+        dev = self.estimator.device
+        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), torch.as_tensor(K).to(dev), S, 1024,
+                           self.prepare_seed)
+        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), torch.as_tensor(K).to(dev), S, 1024,
+                           self.prepare_seed + 1)
+        E1d = torch.as_tensor(E1).to(device=dev, dtype=torch.float64)
+        E2d = torch.as_tensor(E2).to(device=dev, dtype=torch.float64)
+        n = E1d.shape[0]
+
+        def proj(Kc, E):                                  # P = K' E[:3], padded to 4x4 (interface_v5.py:264-270), fp64 -> fp32
+            P = torch.eye(4, dtype=torch.float64, device=dev).repeat(n, 1, 1)
+            P[:, :3, :] = Kc @ E[:, :3, :]
+            return P.to(torch.float32)
+        depths = torch.from_numpy(np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (n, 1))).to(dev)
+        pred = self.estimator(a["img"], a["choose"], b["img"], b["choose"], proj(a["Kcrop"], E1d), proj(b["Kcrop"], E2d), depths)
+        bbox, _, _ = postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], a["choose"], a["Kcrop"], E1d, img_size=S)
+        ok = ((a["valid"] != 0) & (b["valid"] != 0)).view(n, 1, 1)
+        return torch.where(ok, bbox, torch.from_numpy(DEFAULT_BBOX).to(dev).expand(n, 8, 3))
 
     def predict(self, camera_intrinsic, rgb1, view1_mask, view1_extrinsic, rgb2, view2_mask, view2_extrinsic):
         return self.estimate([camera_intrinsic], [rgb1], [view1_mask], [view1_extrinsic], [rgb2], [view2_mask],

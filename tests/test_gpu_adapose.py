@@ -262,3 +262,73 @@ def test_estimator_plugin_estimate_vs_oracle_pipeline():
                                         torch.from_numpy(P1).float()[None], torch.from_numpy(P2).float()[None], dep)
         exp = postproc_ref.bbox_world(o["view1_nocs"][0].numpy(), o["view1_depth"][0].numpy(), o["view1_r"][0].numpy(), a[1], a[3], E1[i])
         assert _rel(out[i], exp) < 1e-3, i
+
+
+def _prepare_case(seed=3):
+    """Five 480x640 frames: big ellipse (subset), small blob near the border (wrap-pad, clamped window), empty mask, two
+    corner blobs (empty resized mask), thin line (few resized pixels)."""
+    rng = np.random.default_rng(seed)
+    N, H, W = 5, 480, 640
+    rgb = rng.random((N, H, W, 3), dtype=np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    mask = np.zeros((N, H, W), dtype=np.uint8)
+    mask[0] = (((yy - 250) / 120.0) ** 2 + ((xx - 300) / 170.0) ** 2) < 1.0
+    mask[1] = (((yy - 12) / 9.0) ** 2 + ((xx - 630) / 7.0) ** 2) < 1.0       # window clamped at the top-right corner
+    mask[3][440:480, 600:640] = 1
+    mask[3][0:30, 0:25] = 1                      # bbox spans the frame -> centred 440 window misses both blobs -> empty resized mask
+    mask[4][200:203, 50:400] = 1
+    K = np.tile(np.array([[439.31, 0, 320.0], [0, 439.31, 240.0], [0, 0, 1.0]]), (N, 1, 1))
+    K[:, 0, 2] += np.arange(N) * 1.5
+    return rgb, mask, K
+
+
+def test_prepare_inputs_bit_exact_vs_oracle():
+    """Device-side prepare_model_input (rgbm_prepare_inputs) against the numpy restatement of
+    interface_v5.py:58-170: windows, chosen indices, cropped intrinsics and pts2d exactly; images bit for bit."""
+    from oracle import postproc_ref
+    from rgbmanip_amd.adapose import prepare_inputs
+    rgb, mask, K = _prepare_case()
+    seed = 77
+    out = prepare_inputs(torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(K).cuda(), 224, 1024,
+                         seed, want_pts2d=True)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    n_subset = 0
+    for f in range(rgb.shape[0]):
+        view, choose, pts2d, Kn = postproc_ref.prepare_model_input(rgb[f], mask[f], K[f], 224, rng=("hash", seed, f))
+        if view is None:
+            assert got["valid"][f] == 0, f
+            assert np.isfinite(got["img"][f]).all()
+            continue
+        assert got["valid"][f] == 1, f
+        assert np.array_equal(got["choose"][f], choose.astype(np.int32)), f
+        assert np.array_equal(got["Kcrop"][f], Kn), f
+        assert np.array_equal(got["pts2d"][f], pts2d.astype(np.float32)), f
+        assert np.array_equal(got["img"][f], view.astype(np.float32)), (f, np.abs(got["img"][f] - view).max())
+        n_subset += int(mask[f].sum() > 0 and len(np.unique(choose)) == 1024)
+    assert got["valid"].tolist() == [1, 1, 0, 0, 1]         # frame 2: empty mask; frame 3: empty *resized* mask
+    assert n_subset >= 1                      # at least one frame exercised the random-subset branch
+
+
+def test_estimate_device_prepare_matches_host_prepare():
+    """The estimator plugin with cfg hip_prepare='device' (frames uploaded once, everything else on the GPU) against the
+    host-numpy preparation with the same hash subset: same crops bit for bit, so the same boxes."""
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+    rgb, mask, K = _prepare_case(seed=5)
+    N = rgb.shape[0]
+    rgb2 = np.ascontiguousarray(rgb[:, :, ::-1])          # a second "view": mirrored frames and masks
+    mask2 = np.ascontiguousarray(mask[:, :, ::-1])
+    inp = synth.adapose_inputs(N, seed=2)
+    E1, E2 = inp["E1"].astype(np.float64), inp["E2"].astype(np.float64)
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False)
+    sd = synth.adapose_state_dict(seed=0, prefix="module.")
+    host = AdaPoseEstimator_v5(None, dict(cfg, hip_prepare="host", hip_prepare_seed=9), None, state_dict=sd, dtype="fp32")
+    host.rng = ("hash", 9)
+    dev = AdaPoseEstimator_v5(None, dict(cfg, hip_prepare="device", hip_prepare_seed=9), None, state_dict=sd, dtype="fp32")
+    b_host = host.estimate(K, rgb, mask, E1, rgb2, mask2, E2)
+    b_dev = dev.estimate(K, rgb, mask, E1, rgb2, mask2, E2)
+    assert b_host.shape == (N, 8, 3) and b_dev.shape == (N, 8, 3)
+    assert np.array_equal(b_host[2], b_dev[2])            # empty mask -> default bbox on both paths
+    assert np.allclose(b_host[2], np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]]) + 10.0)
+    np.testing.assert_allclose(b_dev, b_host, rtol=1e-6, atol=1e-7)
