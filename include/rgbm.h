@@ -95,6 +95,11 @@ int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const dou
                         uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
                         int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream);
 
+/* Per-env mask extent for the controller's view queue.
+ * Replaces: the np.nonzero / np.where loop of ControlInterface.add_view   models/controller/rl_pose.py:130-149
+ * mask [N,H,W] u8 -> ext [N,4] i32 = (row min, col min, row max, col max), (2H, 2W, 0, 0) for an empty mask; count [N]. */
+int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * PPO rollout storage.
  * Replaces: RolloutStorage.compute_returns   algo/ppo/ppo/storage.py:50-64

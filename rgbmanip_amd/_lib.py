@@ -89,6 +89,7 @@ SIGNATURES = {
     "rgbm_build_volume": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_conv0_sweep": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_prepare_inputs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rgbm_debug_flags": (_i, [_i]),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),

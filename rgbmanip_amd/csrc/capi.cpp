@@ -273,6 +273,10 @@ extern "C" int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev
                                window_out, valid_out, scratch, (hipStream_t)stream);
 }
 
+extern "C" int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream) {
+  return launch_mask_extent(mask_dev, N, H, W, ext_out, count_out, (hipStream_t)stream);
+}
+
 extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; return 0; }
 
 // ---- PPO policy -------------------------------------------------------------------------------------------------

@@ -198,7 +198,35 @@ __global__ __launch_bounds__(PRE_THREADS) void choose_kernel(const unsigned char
   }
 }
 
+// ---- ControlInterface.add_view (rl_pose.py:130-149): per-env mask extent, in rows (dim 1) and columns (dim 2) -----------
+__global__ __launch_bounds__(PRE_THREADS) void mask_extent_kernel(const unsigned char* __restrict__ mask, int H, int W,
+                                                                   int* __restrict__ ext /*[N,4] rmin,cmin,rmax,cmax*/,
+                                                                   int* __restrict__ count /*[N]*/) {
+  __shared__ int s_y1, s_x1, s_y2, s_x2, s_n;
+  const int f = blockIdx.x, t = threadIdx.x;
+  if (t == 0) { s_y1 = 2 * H; s_x1 = 2 * W; s_y2 = 0; s_x2 = 0; s_n = 0; }      // the reference's defaults for "no pixel"
+  __syncthreads();
+  const unsigned char* m = mask + (long long)f * H * W;
+  int y1 = 2 * H, x1 = 2 * W, y2 = 0, x2 = 0, n = 0;
+  for (int i = t; i < H * W; i += PRE_THREADS) {
+    if (m[i]) {
+      const int y = i / W, x = i - y * W;
+      y1 = min(y1, y); y2 = max(y2, y); x1 = min(x1, x); x2 = max(x2, x); ++n;
+    }
+  }
+  if (n) { atomicMin(&s_y1, y1); atomicMax(&s_y2, y2); atomicMin(&s_x1, x1); atomicMax(&s_x2, x2); atomicAdd(&s_n, n); }
+  __syncthreads();
+  if (t == 0) { ext[f * 4 + 0] = s_y1; ext[f * 4 + 1] = s_x1; ext[f * 4 + 2] = s_y2; ext[f * 4 + 3] = s_x2; count[f] = s_n; }
+}
+
 }  // namespace
+
+int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext, int* count, hipStream_t s) {
+  RGBM_REQUIRE(mask && ext && count && N > 0 && H > 0 && W > 0, "mask_extent arguments");
+  hipLaunchKernelGGL(mask_extent_kernel, dim3(N), dim3(PRE_THREADS), 0, s, mask, H, W, ext, count);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 unsigned prepare_mix32(unsigned seed, unsigned frame, unsigned idx) { return mix32(seed, frame, idx); }
 

@@ -254,3 +254,28 @@ def ppo_rollout(T: int, N: int, seed: int = 0, obs=60, states=75, act=12):
         "last_values": g.normal(1.0, 2.0, size=(N, 1)).astype(np.float32),
     }
     return r
+
+
+# --------------------------------------------------------------------------- ControlInterface view stream
+def control_view(num_envs: int, step: int, seed: int = 0, H: int = 480, W: int = 640):
+    """One seeded `MultiVecEnv.get_image()` result + camera pose + GT box for the view-queue tests and goldens.
+
+    Colour frames are a per-(step, env) constant plus a faint ramp so a captured frame identifies its origin; masks are
+    rectangles, with env 1 empty at step 2 and every env empty at step 4 (the reference's global `if p_env.shape[0]` branch)."""
+    rng = np.random.default_rng(seed * 1000 + step)
+    color = np.empty((num_envs, H, W, 3), dtype=np.float32)
+    ramp = (np.arange(W, dtype=np.float32) / (8.0 * W))[None, :, None]
+    mask = np.zeros((num_envs, H, W), dtype=bool)
+    for e in range(num_envs):
+        color[e] = (step * 16 + e + 1) / 256.0 + ramp
+        if step == 4 or (step == 2 and e == 1):
+            continue
+        r0, c0 = int(rng.integers(20, 300)), int(rng.integers(20, 400))
+        mask[e, r0:r0 + int(rng.integers(30, 150)), c0:c0 + int(rng.integers(30, 200))] = True
+    K = np.tile(np.array([[439.31, 0, 320.0], [0, 439.31, 240.0], [0, 0, 1.0]]), (num_envs, 1, 1)) + rng.normal(0, 0.1, (num_envs, 3, 3))
+    E = np.tile(np.eye(4), (num_envs, 1, 1))
+    E[:, :3, :] += rng.normal(0, 0.2, (num_envs, 3, 4))
+    pose = rng.normal(0, 0.5, (num_envs, 7))
+    gt = rng.normal(0, 0.3, (num_envs, 8, 3))
+    image = {"camera0": {"Color": color, "Mask": mask, "Intrinsic": K, "Extrinsic": E}}
+    return image, pose, gt

@@ -332,3 +332,46 @@ def test_estimate_device_prepare_matches_host_prepare():
     assert np.array_equal(b_host[2], b_dev[2])            # empty mask -> default bbox on both paths
     assert np.allclose(b_host[2], np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]]) + 10.0)
     np.testing.assert_allclose(b_dev, b_host, rtol=1e-6, atol=1e-7)
+
+
+def test_device_control_queue_matches_reference_golden(golden_dir):
+    """rgbmanip_amd.control_interface.ControlInterface (device-resident queues, rgbm_mask_extent, index-arithmetic view
+    selection) against the reference ControlInterface's own outputs (tests/golden/control.npz)."""
+    from test_oracle_golden import _control_fake_estimator, drive_control_queue
+    from rgbmanip_amd.control_interface import ControlInterface
+    g = np.load(os.path.join(golden_dir, "control.npz"))
+    for task in ("cabinet", "mugs"):
+        est = _control_fake_estimator(task)
+        ci = ControlInterface(3, est, 5)
+        obs, states, boxes = drive_control_queue(ci, est, lambda: ci.get_observation().cpu().numpy(), lambda: ci.get_state().cpu().numpy())
+        np.testing.assert_array_equal(obs, g[task + "_obs"])
+        np.testing.assert_array_equal(states, g[task + "_state"])
+        np.testing.assert_array_equal(boxes, g[task + "_pred"])
+        for key in ("id1", "id2", "m1", "m2", "K", "E1", "E2"):
+            np.testing.assert_array_equal(np.stack([c[key] for c in est.calls]), g[task + "_" + key], err_msg=key)
+        np.testing.assert_array_equal(ci.available.cpu().numpy(), g[task + "_available"])
+        np.testing.assert_array_equal(ci.available_num.cpu().numpy(), g[task + "_available_num"])
+        np.testing.assert_array_equal(ci.bbox_queue.cpu().numpy(), g[task + "_bbox_queue"])
+
+
+def test_device_control_queue_with_hip_estimator():
+    """The queue feeding the real estimator without leaving the GPU (`estimate_device`) gives the boxes the numpy-facing
+    `estimate` gives for the same two selected views."""
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.control_interface import ControlInterface
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+    N = 3
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device", hip_prepare_seed=1)
+    est = AdaPoseEstimator_v5(None, cfg, None, state_dict=synth.adapose_state_dict(seed=0, prefix="module."), dtype="fp32")
+    ci = ControlInterface(N, est, 5)
+    for t in range(3):
+        img, pose, gt = synth.control_view(N, t, seed=6)
+        ci.add_view(img, pose)
+        ci.accumulate_steps += 1
+    got = ci.get_estimation().cpu().numpy()
+    idx, has = ci.select_views()
+    sel = lambda q, s: ci._gather(q, idx[s], has[s]).cpu().numpy()
+    ref = est.estimate(sel(ci.intrinsic_queue, 0), sel(ci.image_queue, 0), sel(ci.mask_queue, 0), sel(ci.extrinsic_queue, 0),
+                       sel(ci.image_queue, 1), sel(ci.mask_queue, 1), sel(ci.extrinsic_queue, 1))
+    assert got.shape == (N, 8, 3)
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)

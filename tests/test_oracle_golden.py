@@ -82,3 +82,63 @@ def test_ppo_act_evaluate_gae_update(golden_dir):
     assert abs(mvl - float(g["n32_mvl"])) < 1e-3 * abs(float(g["n32_mvl"]))
     assert abs(msl - float(g["n32_msl"])) < 1e-3 * abs(float(g["n32_msl"])) + 1e-6
     assert _rel(flat, g["n32_params_after"]) < 1e-3
+
+
+def _control_fake_estimator(task):
+    class Fake:
+        def __init__(self):
+            self.cfg = {"task_name": task}
+            self.calls = []
+
+        def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+            import numpy as np
+            self.calls.append(dict(id1=rgb1[:, 0, 0, 0].copy(), id2=rgb2[:, 0, 0, 0].copy(), m1=m1.sum((1, 2)), m2=m2.sum((1, 2)),
+                                   K=K.copy(), E1=E1.copy(), E2=E2.copy()))
+            base = np.arange(24, dtype=np.float64).reshape(1, 8, 3)
+            return base + (m1.sum((1, 2)) * 1e-3 + rgb2[:, 0, 0, 0])[:, None, None]
+    return Fake()
+
+
+def drive_control_queue(ci, est, get_obs, get_state, num_envs=3, seed=4):
+    """The call sequence tools/make_goldens.py::gen_control ran on the reference ControlInterface."""
+    import numpy as np
+    from rgbmanip_amd import synth
+    t = 0
+    img, pose, gt = synth.control_view(num_envs, t, seed); t += 1
+    ci.add_view(img, pose)                                   # reset_robot (rl_pose.py:103-116)
+    ci.accumulate_steps += 1
+    obs, states, boxes = [get_obs()], [get_state()], []
+    for step in range(7):
+        img, pose, gt = synth.control_view(num_envs, t, seed); t += 1
+        ci.add_view(img, pose)
+        pred = ci.get_estimation()
+        ci.add_bbox(pred, gt)
+        boxes.append(np.asarray(pred.cpu() if hasattr(pred, "cpu") else pred))
+        obs.append(get_obs()); states.append(get_state())
+        ci.accumulate_steps += 1
+        if ci.accumulate_steps == 6:
+            ci.reset_queue()
+            img, pose, gt = synth.control_view(num_envs, t, seed); t += 1
+            ci.add_view(img, pose)
+            ci.accumulate_steps += 1
+    return np.stack(obs), np.stack(states), np.stack(boxes)
+
+
+def test_control_queue_oracle_matches_reference_golden(golden_dir):
+    """oracle/control_ref.py against the reference ControlInterface itself (tests/golden/control.npz): observation / state
+    encoders, the any-env availability quirk, queue wrap-around, reset, view selection, mug corner permutation."""
+    import numpy as np
+    from oracle.control_ref import ControlQueueRef
+    g = np.load(os.path.join(golden_dir, "control.npz"))
+    for task in ("cabinet", "mugs"):
+        est = _control_fake_estimator(task)
+        ci = ControlQueueRef(3, 5, est)
+        obs, states, boxes = drive_control_queue(ci, est, ci.get_observation, ci.get_state)
+        np.testing.assert_array_equal(obs, g[task + "_obs"])
+        np.testing.assert_array_equal(states, g[task + "_state"])
+        np.testing.assert_array_equal(boxes, g[task + "_pred"])
+        for key in ("id1", "id2", "m1", "m2", "K", "E1", "E2"):
+            np.testing.assert_array_equal(np.stack([c[key] for c in est.calls]), g[task + "_" + key], err_msg=key)
+        np.testing.assert_array_equal(ci.available, g[task + "_available"])
+        np.testing.assert_array_equal(ci.available_num, g[task + "_available_num"])
+        np.testing.assert_array_equal(ci.bbox_queue, g[task + "_bbox_queue"])

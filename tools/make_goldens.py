@@ -295,12 +295,89 @@ def gen_ppo(out_dir):
     np.savez_compressed(os.path.join(out_dir, "ppo.npz"), **save)
 
 
+def gen_control(out_dir):
+    """View queue / encoders / view selection of the reference ControlInterface (rl_pose.py:14-223) on the seeded view
+    stream of rgbmanip_amd.synth.control_view: the class is imported as shipped; only the modules it drags in for the
+    simulator are replaced by name stubs, and the env / estimator are recording fakes."""
+    from rgbmanip_amd import synth
+    stub("env.sapien_envs.open_cabinet", CAMERA_INTRINSIC=[0.05, 100, 1, 640, 480])
+    stub("env.sapien_envs", open_cabinet=sys.modules["env.sapien_envs.open_cabinet"])
+    stub("models.manipulation.open_cabinet", OpenCabinetManipulation=object)
+    stub("models.controller.base_controller", BaseController=object)
+    stub("models.pose_estimator.base_estimator", BasePoseEstimator=object)      # the real one imports the SAPIEN env base
+    cwd = os.getcwd()
+    os.chdir("/tmp")                                   # ControlInterface.__init__ creates saves/third_stage in the cwd
+    try:
+        from models.controller.rl_pose import ControlInterface
+        N, seed = 3, 4
+
+        class FakeEnv:
+            num_envs = N
+
+            def __init__(self):
+                self.t = 0
+                self.cur = None
+
+            def cam_move_to(self, *a, **k):
+                return np.ones(N), np.ones(N)
+
+            def get_image(self):
+                self.cur = synth.control_view(N, self.t, seed)
+                self.t += 1
+                return self.cur[0]
+
+            def camera_pose(self, robot_frame=True):
+                return self.cur[1]
+
+        class FakeEstimator:
+            def __init__(self, task):
+                self.cfg = {"task_name": task}
+                self.calls = []
+
+            def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+                self.calls.append(dict(id1=rgb1[:, 0, 0, 0].copy(), id2=rgb2[:, 0, 0, 0].copy(), m1=m1.sum((1, 2)), m2=m2.sum((1, 2)),
+                                       K=K.copy(), E1=E1.copy(), E2=E2.copy()))
+                base = np.arange(24, dtype=np.float64).reshape(1, 8, 3)
+                return base + (m1.sum((1, 2)) * 1e-3 + rgb2[:, 0, 0, 0])[:, None, None]
+
+        cfg = {"controller": {"max_steps": 4, "action_type": "pose", "pose_min": [0.1, -0.4, 0.5], "pose_max": [0.5, 0.4, 1.1]}}
+        save = {}
+        for task in ("cabinet", "mugs"):
+            env, est = FakeEnv(), FakeEstimator(task)
+            ci = ControlInterface(env, est, None, cfg)
+            obs, states, boxes = [ci.get_observation().numpy()], [ci.get_state().numpy()], []
+            for step in range(7):
+                ci.add_view(env.get_image(), env.camera_pose(robot_frame=True))
+                pred = ci.get_estimation()
+                ci.add_bbox(pred, env.cur[2])
+                boxes.append(pred.copy())
+                obs.append(ci.get_observation().numpy())
+                states.append(ci.get_state().numpy())
+                ci.accumulate_steps += 1
+                if ci.accumulate_steps == 6:             # exercise reset_queue + a fresh first view mid-stream
+                    ci.reset_queue()
+                    ci.add_view(env.get_image(), env.camera_pose(robot_frame=True))
+                    ci.accumulate_steps += 1
+            save[task + "_obs"] = np.stack(obs)
+            save[task + "_state"] = np.stack(states)
+            save[task + "_pred"] = np.stack(boxes)
+            for key in ("id1", "id2", "m1", "m2", "K", "E1", "E2"):
+                save[task + "_" + key] = np.stack([c[key] for c in est.calls])
+            save[task + "_available"] = ci.available.copy()
+            save[task + "_available_num"] = ci.available_num.copy()
+            save[task + "_bbox_queue"] = ci.bbox_queue.copy()
+        np.savez_compressed(os.path.join(out_dir, "control.npz"), **save)
+        print("control golden:", {k: v.shape for k, v in save.items() if k.startswith("cabinet")})
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     install_stubs()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["adapose", "postproc", "ppo"]
+    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control"]
     net_out = inp = None
     if "adapose" in which or "postproc" in which:
         net_out, inp = gen_adapose(out_dir)
@@ -308,4 +385,6 @@ if __name__ == "__main__":
         gen_postproc(out_dir, net_out, inp)
     if "ppo" in which:
         gen_ppo(out_dir)
+    if "control" in which:
+        gen_control(out_dir)
     print("done")
