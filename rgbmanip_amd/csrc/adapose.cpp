@@ -378,7 +378,12 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0)) return rc;
-    if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
+    if (cost_impl == 3 && dtype == BF16 && igemm_conv6) {
+      // conv6 (64 -> 64, K = 27 x 64): a plain GEMM shape, 2.7x faster on the role-specialised implicit-GEMM kernel
+      if (int rc = c3d[6].run(bf.c[5], bf.c[6], Vc, D / 8, S / 8, S / 8, 64, nullptr, RES_NONE, nullptr, 0, s)) return rc;
+    } else {
+      if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
+    }
     if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
     if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
     if (cost_impl == 3 && dtype == BF16 && sparse_tail) {

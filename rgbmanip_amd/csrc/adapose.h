@@ -22,7 +22,7 @@ struct AdaPose {
   int dtype = F32;
   int img = 224, n_pts = 1024, n_depth = 24;
   int img_cpad = 4;
-  int max_chunk = 32;            // views per cost-volume chunk (bounds the workspace)
+  int max_chunk = 128;           // views per cost-volume chunk (bounds the workspace: ~80 MB per view in bf16)
 
   struct Block { ConvLayer c1, c2, ds; bool has_ds = false; int stride = 1, planes = 0; };
   ConvLayer conv1;
@@ -32,6 +32,7 @@ struct AdaPose {
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
   struct Tile3d { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0; };
   Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11
+  int igemm_conv6 = 1;          // bf16 + cost_impl 3: conv6 through the implicit-GEMM path instead of the halo-tile kernel
   int fuse_final = 1;           // bf16: PSPNet `final` 1x1 fused into up_3's kernel (0 = two launches; `u3` is then materialised)
   int sparse_tail = 1;          // cost_impl 3: evaluate conv11 + prob only where prob is gathered (0 = dense conv11, for A/B and tests)
   void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (bf16 nets only)

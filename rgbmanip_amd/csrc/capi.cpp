@@ -60,6 +60,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   RGBM_REQUIRE(h && key, "set_option arguments");
   const std::string k = key;
   if (k == "max_chunk") { RGBM_REQUIRE(value > 0, "max_chunk"); h->net.max_chunk = value; }
+  else if (k == "igemm_conv6") { RGBM_REQUIRE(value == 0 || value == 1, "igemm_conv6"); h->net.igemm_conv6 = value; }
   else if (k == "fuse_final") { RGBM_REQUIRE(value == 0 || value == 1, "fuse_final"); h->net.fuse_final = value; }
   else if (k == "sparse_tail") { RGBM_REQUIRE(value == 0 || value == 1, "sparse_tail"); h->net.sparse_tail = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
