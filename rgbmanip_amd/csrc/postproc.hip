@@ -19,6 +19,7 @@ namespace rgbm {
 
 constexpr int PP_MAXP = 1024;
 constexpr int PP_THREADS = 1024;
+constexpr int PP_CAND = 3072;
 
 __device__ __forceinline__ bool pair_ratio(const double* cx, const double* cy, const double* cz, const float* nx,
                                            const float* ny, const float* nz, int i, int j, double& ratio) {
@@ -65,6 +66,9 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
   __shared__ unsigned long long sel_prefix;
   __shared__ unsigned sel_rank, sel_lt, sel_eq, total_cnt;
   __shared__ unsigned wsum[PP_THREADS / 64];
+  __shared__ unsigned long long cand[PP_CAND];   // keys of the selected 24-bit bucket (short cut after two radix passes)
+  __shared__ unsigned ncand, cand_lt;
+  __shared__ unsigned long long cand_med, cand_below;
   __shared__ float hmax[3];
 
   const int b = blockIdx.x, t = threadIdx.x;
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
   const int shifts[6] = {52, 40, 28, 16, 4, 0};
   const int widths[6] = {12, 12, 12, 12, 12, 4};
   unsigned lt_total = 0;                // number of elements strictly below the selected bucket (overall)
+  bool used_cand = false;
   for (int pass = 0; pass < 6; ++pass) {
     for (int i = t; i < 4096; i += PP_THREADS) hist[i] = 0u;
     __syncthreads();
@@ -162,6 +167,40 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
     rank = sel_rank;
     lt_total = sel_lt;
     if (total_cnt == 0) break;
+    // Short cut: after two passes the bucket is 2^-12 wide in relative terms and holds a few hundred of the 523 776 ratios.
+    // Collect its keys once and finish the selection on that list instead of four more passes over all pairs.
+    if (pass == 1 && sel_eq <= (unsigned)PP_CAND) {
+      if (t == 0) { ncand = 0u; cand_lt = 0u; cand_below = 0ull; }
+      __syncthreads();
+      if (worker) {
+        for (int q = q_lo; q < q_hi; ++q) {
+          int i, j;
+          pair_ij(P, r, q, i, j);
+          double ratio;
+          if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
+          const unsigned long long key = (unsigned long long)__double_as_longlong(ratio);
+          if ((key >> 40) == prefix) cand[atomicAdd(&ncand, 1u)] = key;
+        }
+      }
+      __syncthreads();
+      const unsigned m = ncand;                    // == sel_eq
+      for (unsigned c = t; c < m; c += PP_THREADS) {
+        const unsigned long long kc = cand[c];
+        unsigned lt = 0, eq_before = 0;
+        for (unsigned o = 0; o < m; ++o) { const unsigned long long ko = cand[o]; lt += ko < kc; eq_before += (ko == kc) & (o < c); }
+        if (lt + eq_before == rank) { cand_med = kc; cand_lt = lt; }     // exactly one candidate has this rank
+      }
+      __syncthreads();
+      const unsigned long long kmed = cand_med;
+      unsigned long long below = 0ull;             // largest key strictly below the median inside the bucket (0 = none)
+      for (unsigned c = t; c < m; c += PP_THREADS) { const unsigned long long kc = cand[c]; if (kc < kmed && kc > below) below = kc; }
+      if (below) atomicMax(&cand_below, below);
+      __syncthreads();
+      prefix = kmed;                               // the full 64-bit key
+      lt_total = sel_lt + cand_lt;
+      used_cand = true;
+      break;
+    }
   }
   const unsigned n_valid = total_cnt;
   if (n_valid > 0) {
@@ -175,6 +214,10 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
     } else {
       med_lo = med_hi;
     }
+  }
+  if (have && need_lower && used_cand && cand_below != 0ull) {
+    med_lo = __longlong_as_double((long long)cand_below);      // the lower middle lies in the same bucket
+    need_lower = false;
   }
   if (have && need_lower) {
     // max over valid ratios strictly below med_hi
