@@ -48,7 +48,7 @@ def make_inputs(B, device, unique=16):
     return out, dev
 
 
-def cpu_baseline(n_chunks=2, chunk=2):
+def cpu_baseline(n_chunks=6, chunk=2):
     """Oracle (kind "port") on the host cores: network forward + numpy post-processing, bounded sample."""
     from oracle import adapose_ref, postproc_ref
     from rgbmanip_amd import synth
