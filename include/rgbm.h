@@ -101,6 +101,62 @@ int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const dou
 int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Controller step on the device: everything ControlInterface.step does between the simulator and the
+ * estimator, one thread per environment, float64 in numpy's evaluation order.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Replaces: utils.transform.lookat_quat   utils/transform.py:50-99 (per-row branches; batch_zero = its whole-batch norm test)
+ * dir [N,3] f64 -> quat [N,4] f64 (w,x,y,z).  The reference takes an eigenvector of Horn's matrix whose SIGN is LAPACK's
+ * choice; here the first non-negligible component is positive (same rotation). */
+int rgbm_lookat_quat(const double* dir_dev, int N, int batch_zero, double* quat_dev, void* stream);
+/* Replaces: the action decode of ControlInterface.step   models/controller/rl_pose.py:390-408 (action_type "pose")
+ * action [N,lda] f32 (device) -> pose [N,7] f64: clip(a[:3] + pose_mid, pose_min, pose_max), lookat_quat((1, dy, dz)).
+ * pose_mid / pose_min / pose_max: 3 host doubles each. */
+int rgbm_control_action_to_pose(const float* action_dev, int lda, const double* pose_mid, const double* pose_min,
+                                const double* pose_max, int N, double* pose_dev, void* stream);
+/* Replaces: ControlInterface.get_reward   models/controller/rl_pose.py:225-358, including quat_to_axis' batch scramble
+ * (utils/transform.py:234) and LOSS:far aliasing the scaled far term (:247, :322).  All pointers are device pointers. */
+typedef struct rgbm_control_reward_args {
+  const float* action;        /* [N,lda] f32 policy action: xyz, dy, dz, -, view weights (T) */
+  const double* cam_pose;     /* [N,7]   env.camera_pose(robot_frame=True) */
+  const double* target;       /* [N,7]   last_pose_target */
+  const float* move_success;  /* [N]     cam_move_to()[0] as float32 */
+  const double* bbox;         /* [N,4]   bbox_queue[s % T] */
+  const double* avail;        /* [N]     available[s % T] */
+  const double* gt_bbox;      /* [N,8,3] gt_bbox[s] */
+  const double* pred_bbox;    /* [N,8,3] pred_bbox[s] */
+  const double* pose_cur;     /* [N,7]   pose_queue[s] */
+  const double* pose_prev;    /* [N,7]   pose_queue[s-1] */
+  const double* robot_pose;   /* [N,7]   env.robot_pose() */
+  const double* success;      /* [N] */
+  double* reward;             /* [N] out */
+  double* terms;              /* [17][N] out or NULL: the 14 REW:* terms in sum order, LOSS:center_diff, LOSS:open_diff, LOSS:far */
+  double coef[14];            /* diff, move_success, move_period, far, ori, xyz_lookat, bbox, bbox_boundary, have_bbox, center,
+                                 open, view, view_norm, success */
+  double proper_pos[3];
+  double precision2;          /* precision^2: 0.01 for mugs, 0.04 otherwise */
+  int N, T, lda, pots, first; /* T = max_steps (view weights per action); first = (accumulate_steps == 0) */
+  int pad_;
+} rgbm_control_reward_args;
+int rgbm_control_reward(const rgbm_control_reward_args* args, void* stream);
+/* Replaces: the centre / axis math of ControlInterface.call_manipulation   models/controller/rl_pose.py:364-377
+ * est [N,8,3] f64 -> center [N,3], direction [N,3,3]. */
+int rgbm_control_grasp_frame(const double* est_dev, int N, double* center_dev, double* direction_dev, void* stream);
+
+/* Synthetic camera of the MultiVecEnv stand-in (no reference code: the reference renders with SAPIEN).
+ * Produces what MultiVecEnv.get_image() returns (env/my_vec_env.py:266, base_manipulation.py:653-687) for a scene of one
+ * oriented box per env.  rays [N,12] is scratch written by rgbm_synth_camera and read by rgbm_synth_render.
+ * Bit-identical to oracle/synth_env_ref.py. */
+typedef struct rgbm_synth_scene {
+  const double* cam_pose;     /* [N,7] camera pose in the robot frame (x forward, y left, z up) */
+  const double* robot_pose;   /* [N,7] robot root (position used) */
+  const double* box;          /* [N,15] centre (3), axis rows X,Y,Z (9), half extents (3) */
+  double fx, fy, cx, cy;
+  int N, H, W, env0;
+} rgbm_synth_scene;
+int rgbm_synth_camera(const rgbm_synth_scene* scene, double* K_dev, double* E_dev, double* rays_dev, void* stream);
+int rgbm_synth_render(const rgbm_synth_scene* scene, const double* rays_dev, float* color_dev, uint8_t* mask_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * PPO rollout storage.
  * Replaces: RolloutStorage.compute_returns   algo/ppo/ppo/storage.py:50-64
  * rewards/values/returns/adv [T,N] f32, dones [T,N] u8, last_values [N] f32.

@@ -59,6 +59,19 @@ class AdaposeOut(C.Structure):
                                            "view1_t", "view2_t", "view1_s", "view2_s")]
 
 
+class ControlRewardArgs(C.Structure):            # rgbm_control_reward_args
+    _fields_ = [(n, C.c_void_p) for n in ("action", "cam_pose", "target", "move_success", "bbox", "avail", "gt_bbox", "pred_bbox",
+                                           "pose_cur", "pose_prev", "robot_pose", "success", "reward", "terms")] + [
+        ("coef", C.c_double * 14), ("proper_pos", C.c_double * 3), ("precision2", C.c_double),
+        ("N", C.c_int), ("T", C.c_int), ("lda", C.c_int), ("pots", C.c_int), ("first", C.c_int), ("pad_", C.c_int)]
+
+
+class SynthScene(C.Structure):                   # rgbm_synth_scene
+    _fields_ = [("cam_pose", C.c_void_p), ("robot_pose", C.c_void_p), ("box", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("env0", C.c_int)]
+
+
 _vp, _i, _f, _d, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_int64
 
 # symbol -> (restype, argtypes); must list every function declared in include/rgbm.h
@@ -90,6 +103,12 @@ SIGNATURES = {
     "rgbm_conv0_sweep": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_prepare_inputs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rgbm_lookat_quat": (_i, [_vp, _i, _i, _vp, _vp]),
+    "rgbm_control_action_to_pose": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp, _vp]),
+    "rgbm_control_reward": (_i, [C.POINTER(ControlRewardArgs), _vp]),
+    "rgbm_control_grasp_frame": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "rgbm_synth_camera": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
+    "rgbm_synth_render": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_debug_flags": (_i, [_i]),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),

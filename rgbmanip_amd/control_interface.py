@@ -1,41 +1,99 @@
-"""Device-resident view queue of the RL pose controller.
+"""Device-resident RL pose controller interface.
 
-Mirrors the estimator-facing half of `ControlInterface` (`/root/reference/models/controller/rl_pose.py:14-223`): the
-queues of the last `max_steps` views per env (`reset_queue`, `add_view`, `add_bbox`), the policy's observation / state
-encoders (`get_observation`, `get_state`) and `get_estimation`, which picks each env's two most recent usable views and
-calls the pose estimator — here without leaving the GPU: frames, masks and camera matrices stay CUDA tensors (float32
-frames instead of the reference's float64 host arrays), the per-env mask extent comes from `rgbm_mask_extent`, the view
-selection is index arithmetic instead of the O(max_steps * N) Python double loop copying 480x640x3 images, and the
-estimator is entered through `estimate_device`.  Reward shaping, camera motion and the manipulation call (`step`,
-`get_reward`, `call_manipulation`, `reset_robot`) need the simulator and stay with the reference's controller.
+Mirrors `ControlInterface` of `/root/reference/models/controller/rl_pose.py:14-462` — same constructor, attributes, method
+names and return values — with every per-step array kept on the GPU:
+
+* view queues (`reset_queue`, `add_view`, `add_bbox`, rl_pose.py:85-156): frames, masks and camera matrices stay CUDA
+  tensors (float32 frames instead of float64 host arrays); the per-env mask extent comes from `rgbm_mask_extent`;
+* policy encoders (`get_observation`, `get_state`, :158-187);
+* `get_estimation` (:189-223): the two most recent usable views per env are selected by index arithmetic instead of the
+  O(max_steps * N) Python loop copying 480x640x3 images, and the estimator is entered through `estimate_device`;
+* `step` (:380-453): action decode (`rgbm_control_action_to_pose`), camera move + render through the vec-env, estimation,
+  `get_reward` (:225-358, one `rgbm_control_reward` launch), `get_done`, automatic `reset` after a finished episode;
+* `call_manipulation` (:364-378): grasp centre / axes via `rgbm_control_grasp_frame`, handed to `manipulation.plan_pathway`.
+
+Reference quirks that change values are reproduced and tested against goldens recorded from the reference class
+(tests/golden/control.npz, control_step.npz): every env becomes "available" as soon as any env's mask has a pixel (:132),
+`quat_to_axis` scrambles its batch (utils/transform.py:234), `LOSS:far` reports the scaled far term (:247, :322).  Two
+things differ on purpose: the target quaternion's sign is canonical (first non-zero component positive) where the reference
+inherits LAPACK's eigenvector sign, and `available` keeps 0/1 where the reference scales the current slot by
+`have_bbox_coef` in place (:253, :327; only its truth value is ever read).  `_save_data` (eval-time dataset export, :56-83)
+is not provided.  The vec-env may return numpy arrays (the reference's `MultiVecEnv`) or CUDA tensors
+(`rgbmanip_amd.synthetic_env.SyntheticMultiVecEnv`).
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
 
 from . import _lib
+from .spaces import Box
 
 CAMERA_INTRINSIC = [0.05, 100, 1, 640, 480]        # env/sapien_envs/open_cabinet.py:20 (near, far, ?, width, height)
 _MUG_PERM = [0, 2, 4, 6, 1, 3, 5, 7]               # rl_pose.py:220-221
+REWARD_KEYS = ["REW:diff", "REW:move_success", "REW:move_period", "REW:far", "REW:ori_rew", "REW:xyz_lookat", "REW:bbox_penalty",
+               "REW:bbox_boundary_penalty", "REW:have_bbox", "REW:center_rew", "REW:open_rew", "REW:view_rew",
+               "REW:view_norm_penalty", "REW:success", "LOSS:center_diff", "LOSS:open_diff", "LOSS:far"]      # rl_pose.py:336-354
+_COEF_KEYS = ["diff_coef", "move_success_coef", "move_period_coef", "far_coef", "ori_coef", "xyz_lookat_coef", "bbox_coef",
+              "bbox_boundary_coef", "have_bbox_coef", "center_coef", "open_coef", "view_coef", "view_norm_coef", "success_coef"]
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
 
 
 class ControlInterface:
-    def __init__(self, num_envs: int, pose_estimator, max_steps: int, device=None):
-        self.num_envs = int(num_envs)
+    def __init__(self, vec_env, pose_estimator, manipulation=None, cfg=None, device=None):
+        self.env = vec_env
         self.estimator = pose_estimator
-        self.max_steps = int(max_steps)            # the reference passes cfg["controller"]["max_steps"] + 1
+        self.manipulation = manipulation
+        self.cfg = cfg
+        self.num_envs = int(vec_env.num_envs)
+        self.max_steps = int(cfg["controller"]["max_steps"]) + 1
+        self.action_type = cfg["controller"]["action_type"]
+        if self.action_type != "pose":               # "joint" drives the simulator's joint controller 1024 steps (:421-429)
+            raise NotImplementedError("action_type 'joint' needs the simulator; only 'pose' is provided")
+        self.pose_min = np.asarray(cfg["controller"]["pose_min"], dtype=np.float64)
+        self.pose_max = np.asarray(cfg["controller"]["pose_max"], dtype=np.float64)
+        self.pose_mid = (self.pose_min + self.pose_max) / 2
+        self._init_common(device)
+        self.action_space = Box(low=-1.5, high=1.5, shape=(7 + self.max_steps,))
+        self.state_space = Box(low=-1.5, high=1.5, shape=(self.max_steps * 15,))
+        self.observation_space = Box(low=-1.5, high=1.5, shape=(self.max_steps * 12,))
+        self.last_pose_target = None
+        self.proper_pos = np.asarray([[0.0, 0.0, 0.9]])
+        self.proper_ori = np.asarray([[1.0, 0.0, -0.2]])
+        self.last_done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._last_done_any = False                  # done is uniform over envs (:360-362), so the host knows it
+        self.reset_queue()
+        self.reset_robot()
+
+    @classmethod
+    def queue_only(cls, num_envs: int, pose_estimator, max_steps: int, device=None):
+        """Only the view queue / encoders / `get_estimation` half, without a vec-env (`max_steps` as the reference's
+        attribute, i.e. cfg max_steps + 1)."""
+        self = cls.__new__(cls)
+        self.env, self.estimator, self.manipulation, self.cfg = None, pose_estimator, None, None
+        self.num_envs, self.max_steps = int(num_envs), int(max_steps)
+        self._init_common(device)
+        self.reset_queue()
+        return self
+
+    def _init_common(self, device):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.H, self.W = CAMERA_INTRINSIC[-1], CAMERA_INTRINSIC[-2]
         self.lib = _lib.load()
-        self.reset_queue()
 
-    # ------------------------------------------------------------------ rl_pose.py:89-101
+    # ------------------------------------------------------------------ rl_pose.py:85-97
     def reset_queue(self):
         T, N, H, W, dev = self.max_steps, self.num_envs, self.H, self.W, self.device
         z = lambda *shape, dtype=torch.float64: torch.zeros(*shape, dtype=dtype, device=dev)
-        self.image_queue = z(T, N, H, W, 3, dtype=torch.float32)
-        self.mask_queue = z(T, N, H, W, dtype=torch.uint8)
+        if getattr(self, "image_queue", None) is None:
+            # allocated (zeroed) once: a slot is only ever read while `available` marks it, and it is marked when written
+            self.image_queue = z(T, N, H, W, 3, dtype=torch.float32)
+            self.mask_queue = z(T, N, H, W, dtype=torch.uint8)
         self.bbox_queue = z(T, N, 4)
         self.pose_queue = z(T, N, 7)
         self.intrinsic_queue = z(T, N, 3, 3)
@@ -49,7 +107,19 @@ class ControlInterface:
     def _dev(self, x, dtype):
         return torch.as_tensor(x).to(device=self.device, dtype=dtype)
 
-    # ------------------------------------------------------------------ rl_pose.py:118-149
+    # ------------------------------------------------------------------ rl_pose.py:99-116
+    def reset_robot(self):
+        if getattr(self, "_reset_pose", None) is None:   # constant: computed (and copied to the host) once
+            pos = np.array([self.pose_min[0], 0.0, (self.pose_min[2] + self.pose_max[2]) / 2])
+            ori = self.lookat_quat(self.proper_ori)[0].cpu().numpy()
+            self._reset_pose = np.concatenate((pos, ori), axis=-1)
+        pose = self._reset_pose
+        self.env.cam_move_to(pose, time=2, wait=1, planner="path", robot_frame=True, skip_move=True)
+        image = self.env.get_image()
+        self.add_view(image, self.env.camera_pose(robot_frame=True))
+        self.accumulate_steps += 1
+
+    # ------------------------------------------------------------------ rl_pose.py:118-150
     def add_view(self, image, cam_pose):
         k = self.accumulate_steps % self.max_steps
         cam = image["camera0"]
@@ -70,7 +140,7 @@ class ControlInterface:
         scale = torch.tensor([self.H, self.W, self.H, self.W], dtype=torch.float64, device=self.device)
         self.bbox_queue[k] = ext.to(torch.float64) / scale
 
-    # ------------------------------------------------------------------ rl_pose.py:151-155
+    # ------------------------------------------------------------------ rl_pose.py:152-156
     def add_bbox(self, pred_bbox, gt_bbox):
         k = self.accumulate_steps % self.max_steps
         self.pred_bbox[k] = self._dev(pred_bbox, torch.float64)
@@ -81,7 +151,7 @@ class ControlInterface:
         t[:, self.accumulate_steps - 1] = 1.0
         return t
 
-    # ------------------------------------------------------------------ rl_pose.py:157-171
+    # ------------------------------------------------------------------ rl_pose.py:158-171
     def get_state(self):
         centre = (self.gt_bbox[:, :, 0] + self.gt_bbox[:, :, 6]) / 2
         cur = torch.cat((self.pose_queue, self.bbox_queue, centre), dim=-1).to(torch.float32)
@@ -92,7 +162,7 @@ class ControlInterface:
         cur = torch.cat((self.pose_queue, self.bbox_queue), dim=-1).to(torch.float32)
         return torch.cat((cur.permute(1, 0, 2).reshape(self.num_envs, -1), self._time()), dim=-1)
 
-    # ------------------------------------------------------------------ rl_pose.py:189-208
+    # ------------------------------------------------------------------ rl_pose.py:201-208
     def select_views(self):
         """Queue slots of the two views `get_estimation` hands to the estimator: the reference overwrites slot `used % 2` with
         every available view in queue order, so slot s ends up with the LAST available view whose rank has parity s."""
@@ -129,3 +199,99 @@ class ControlInterface:
         if self.estimator.cfg["task_name"] == "mugs":
             bbox = bbox[:, _MUG_PERM]
         return bbox
+
+    # ------------------------------------------------------------------ utils/transform.py:50-99
+    def lookat_quat(self, direction):
+        d = self._dev(direction, torch.float64).reshape(-1, 3).contiguous()
+        q = torch.empty(d.shape[0], 4, dtype=torch.float64, device=self.device)
+        batch_zero = 0                           # the reference tests the norm of the whole normalised batch (:69)
+        if d.shape[0] <= 64 and float(torch.linalg.norm(d / (torch.linalg.norm(d, dim=-1, keepdim=True) + 1e-9))) < 1e-6:
+            batch_zero = 1
+        _lib.check(self.lib.rgbm_lookat_quat(_lib.ptr(d), d.shape[0], batch_zero, _lib.ptr(q), _lib.stream_ptr()), "rgbm_lookat_quat")
+        return q
+
+    # ------------------------------------------------------------------ rl_pose.py:390-408
+    def action_to_pose(self, action):
+        a = self._dev(action, torch.float32).contiguous()
+        pose = torch.empty(self.num_envs, 7, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.rgbm_control_action_to_pose(_lib.ptr(a), a.shape[1], _d3(self.pose_mid), _d3(self.pose_min),
+                                                        _d3(self.pose_max), self.num_envs, _lib.ptr(pose), _lib.stream_ptr()),
+                   "rgbm_control_action_to_pose")
+        return pose
+
+    # ------------------------------------------------------------------ rl_pose.py:225-358
+    def get_reward(self, action, move_res, view_weight, success):
+        """`view_weight` is `action[:, 6:6+max_steps]` in the reference; the kernel reads it from `action` directly."""
+        N, T, s, dev = self.num_envs, self.max_steps, self.accumulate_steps, self.device
+        a = self._dev(action, torch.float32).contiguous()
+        hold = dict(
+            action=a, cam_pose=self._dev(self.env.camera_pose(robot_frame=True), torch.float64).contiguous(),
+            target=self._dev(self.last_pose_target, torch.float64).contiguous(),
+            move_success=self._dev(move_res[0], torch.float32).contiguous(),
+            bbox=self.bbox_queue[s % T], avail=self.available[s % T], gt_bbox=self.gt_bbox[s], pred_bbox=self.pred_bbox[s],
+            pose_cur=self.pose_queue[s], pose_prev=self.pose_queue[(s - 1) % T],
+            robot_pose=self._dev(self.env.robot_pose(), torch.float64).contiguous(),
+            success=self._dev(success, torch.float64).contiguous(),
+            reward=torch.empty(N, dtype=torch.float64, device=dev), terms=torch.empty(17, N, dtype=torch.float64, device=dev))
+        args = _lib.ControlRewardArgs()
+        for k, v in hold.items():
+            assert v.is_contiguous()
+            setattr(args, k, v.data_ptr())
+        args.coef = (C.c_double * 14)(*[float(self.cfg["reward"][k]) for k in _COEF_KEYS])
+        args.proper_pos = _d3(self.proper_pos[0])
+        task = self.estimator.cfg["task_name"]
+        precision = 0.1 if task == "mugs" else 0.2
+        args.precision2 = precision ** 2
+        args.N, args.T, args.lda, args.pots, args.first = N, T, a.shape[1], int(task == "pots"), int(s == 0)
+        _lib.check(self.lib.rgbm_control_reward(C.byref(args), _lib.stream_ptr()), "rgbm_control_reward")
+        info = {k: hold["terms"][i] for i, k in enumerate(REWARD_KEYS)}
+        return hold["reward"], info
+
+    # ------------------------------------------------------------------ rl_pose.py:360-362
+    def get_done(self):
+        return torch.ones(self.num_envs, dtype=torch.bool, device=self.device) * (self.max_steps <= self.accumulate_steps)
+
+    # ------------------------------------------------------------------ rl_pose.py:364-378
+    def call_manipulation(self, estimation, eval):
+        est = self._dev(estimation, torch.float64).contiguous()
+        center = torch.empty(self.num_envs, 3, dtype=torch.float64, device=self.device)
+        direction = torch.empty(self.num_envs, 3, 3, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.rgbm_control_grasp_frame(_lib.ptr(est), est.shape[0], _lib.ptr(center), _lib.ptr(direction),
+                                                     _lib.stream_ptr()), "rgbm_control_grasp_frame")
+        self.manipulation.plan_pathway(center, direction, eval)
+
+    # ------------------------------------------------------------------ rl_pose.py:380-453
+    def step(self, action, eval=False):
+        if self._last_done_any:
+            self.reset()
+        action = self._dev(action, torch.float32).contiguous()
+        weight = action[:, 6:6 + self.max_steps]
+        env_action = self.action_to_pose(action)
+        self.last_pose_target = env_action
+        no_collision = self.cfg["task"]["name"] in ["cabinet", "drawer"]
+        move_res = self.env.cam_move_to(env_action, time=2, wait=0.5, planner="path", robot_frame=True, skip_move=not eval,
+                                        no_collision_with_front=no_collision)
+        image = self.env.get_image()
+        self.add_view(image, self.env.camera_pose(robot_frame=True))
+        pred_bbox = self.get_estimation()
+        gt_bbox = self.env.get_observation(gt=True)["handle_bbox"]
+        self.add_bbox(pred_bbox, gt_bbox)
+        obs = self.get_observation()
+        success = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+        if self.accumulate_steps == self.max_steps - 1 and self.cfg["reward"]["success_coef"] > 1e-9 and not eval:
+            self.call_manipulation(pred_bbox, eval=True)
+            success = self._dev(self.env.get_observation(gt=True)["success"], torch.float64)[:, 0]
+        reward, info = self.get_reward(action, move_res, weight, success)
+        self.accumulate_steps += 1
+        done = self.get_done()
+        self.last_done = done
+        self._last_done_any = self.max_steps <= self.accumulate_steps
+        return obs, reward, done, info
+
+    # ------------------------------------------------------------------ rl_pose.py:455-462
+    def reset(self, indicies=None, reset_env=True):
+        if reset_env:
+            self.env.reset(indicies)
+        self.reset_queue()
+        self.reset_robot()
+        return self.get_observation()

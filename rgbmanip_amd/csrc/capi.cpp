@@ -7,6 +7,7 @@
 #include <string>
 
 #include "adapose.h"
+#include "control.h"
 
 using namespace rgbm;
 
@@ -276,6 +277,34 @@ extern "C" int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev
 
 extern "C" int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream) {
   return launch_mask_extent(mask_dev, N, H, W, ext_out, count_out, (hipStream_t)stream);
+}
+
+// ---- controller step (control.hip) and synthetic camera (synth_env.hip) ---------------------------------------------
+static_assert(sizeof(rgbm_control_reward_args) == sizeof(rgbm::ControlRewardArgs), "control reward args ABI mismatch");
+static_assert(sizeof(rgbm_synth_scene) == sizeof(rgbm::SynthScene), "synth scene ABI mismatch");
+extern "C" int rgbm_lookat_quat(const double* dir_dev, int N, int batch_zero, double* quat_dev, void* stream) {
+  return rgbm::launch_lookat_quat(dir_dev, quat_dev, N, batch_zero, (hipStream_t)stream);
+}
+extern "C" int rgbm_control_action_to_pose(const float* action_dev, int lda, const double* pose_mid, const double* pose_min,
+                                           const double* pose_max, int N, double* pose_dev, void* stream) {
+  return rgbm::launch_control_action(action_dev, lda, pose_mid, pose_min, pose_max, pose_dev, N, (hipStream_t)stream);
+}
+extern "C" int rgbm_control_reward(const rgbm_control_reward_args* args, void* stream) {
+  RGBM_REQUIRE(args, "control_reward args");
+  return rgbm::launch_control_reward(*reinterpret_cast<const rgbm::ControlRewardArgs*>(args), (hipStream_t)stream);
+}
+extern "C" int rgbm_control_grasp_frame(const double* est_dev, int N, double* center_dev, double* direction_dev, void* stream) {
+  return rgbm::launch_control_grasp_frame(est_dev, center_dev, direction_dev, N, (hipStream_t)stream);
+}
+extern "C" int rgbm_synth_camera(const rgbm_synth_scene* scene, double* K_dev, double* E_dev, double* rays_dev, void* stream) {
+  RGBM_REQUIRE(scene, "synth_camera scene");
+  return rgbm::launch_synth_camera(*reinterpret_cast<const rgbm::SynthScene*>(scene), K_dev, E_dev, rays_dev, (hipStream_t)stream);
+}
+extern "C" int rgbm_synth_render(const rgbm_synth_scene* scene, const double* rays_dev, float* color_dev, uint8_t* mask_dev,
+                                 void* stream) {
+  RGBM_REQUIRE(scene, "synth_render scene");
+  return rgbm::launch_synth_render(*reinterpret_cast<const rgbm::SynthScene*>(scene), rays_dev, color_dev, mask_dev,
+                                   (hipStream_t)stream);
 }
 
 extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; return 0; }

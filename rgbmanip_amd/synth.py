@@ -279,3 +279,67 @@ def control_view(num_envs: int, step: int, seed: int = 0, H: int = 480, W: int =
     gt = rng.normal(0, 0.3, (num_envs, 8, 3))
     image = {"camera0": {"Color": color, "Mask": mask, "Intrinsic": K, "Extrinsic": E}}
     return image, pose, gt
+
+
+CONTROL_REWARD_CFG = {            # cfg/controller/rl.yaml:11-26, verbatim
+    "diff_coef": -0.5, "move_success_coef": 8.0, "move_period_coef": -0.0, "far_coef": -2.5, "ori_coef": 0.25,
+    "xyz_lookat_coef": -0.05, "bbox_coef": -1.0, "bbox_boundary_coef": -1.0, "have_bbox_coef": 2.0, "center_coef": 12.0,
+    "open_coef": 8.0, "view_coef": 0.5, "view_norm_coef": -0.3, "success_coef": 0.0,
+}
+
+
+def control_cfg(task: str = "cabinet", success_coef: float = 0.0):
+    """The slice of the merged yaml config `ControlInterface` reads (cfg/controller/rl.yaml:3-26, cfg/task/*.yaml name)."""
+    reward = dict(CONTROL_REWARD_CFG)
+    reward["success_coef"] = success_coef
+    return {"controller": {"max_steps": 4, "action_type": "pose", "pose_min": [-0.3, -0.3, 0.4], "pose_max": [0.3, 0.3, 1.0],
+                           "early_stop": 4},
+            "reward": reward, "task": {"name": task}}
+
+
+def control_actions(num_envs: int, step: int, seed: int = 0, act: int = 12):
+    """Seeded policy actions (float32, as `ActorCritic.act` returns them) for the ControlInterface.step goldens; row 0 of
+    step 3 carries a large z offset so the pose clip of rl_pose.py:406 is exercised."""
+    a = np.random.default_rng(seed * 1000 + 700 + step).normal(0, 0.6, (num_envs, act)).astype(np.float32)
+    if step == 3:
+        a[0, 2] = 2.5
+    return a
+
+
+class ReplayVecEnv:
+    """Deterministic numpy stand-in for the slice of `MultiVecEnv` that `ControlInterface` calls (`env/my_vec_env.py:214,
+    266, 281, 382, 466, 482`): every answer is a seeded function of the call count, so the reference class (golden
+    generator), the oracle and the device implementation can be driven through identical episodes.  Calls are recorded."""
+
+    def __init__(self, num_envs: int, seed: int = 0):
+        self.num_envs, self.seed = num_envs, seed
+        self.t = 0
+        self.cur = None
+        self.moves, self.resets = [], 0
+        self._robot = np.random.default_rng(seed * 1000 + 900).normal(0, 0.2, (num_envs, 7))
+
+    def cam_move_to(self, pose, time=2, wait=1, planner="ik", robot_frame=False, skip_move=False, no_collision_with_front=True):
+        rng = np.random.default_rng(self.seed * 1000 + 500 + self.t)
+        pose = pose.detach().cpu().numpy() if hasattr(pose, "detach") else pose
+        self.moves.append(dict(pose=np.array(pose, dtype=np.float64), time=time, wait=wait, planner=planner,
+                               robot_frame=robot_frame, skip_move=skip_move, no_collision_with_front=no_collision_with_front))
+        return [(rng.random(self.num_envs) > 0.25), rng.integers(1, 2000, self.num_envs)]     # merge_obs of (bool, int) tuples
+
+    def get_image(self, mask="handle"):
+        self.cur = control_view(self.num_envs, self.t, self.seed)
+        self.t += 1
+        return self.cur[0]
+
+    def camera_pose(self, robot_frame=False):
+        return self.cur[1]
+
+    def robot_pose(self):
+        return self._robot
+
+    def get_observation(self, gt=False):
+        rng = np.random.default_rng(self.seed * 1000 + 300 + self.t)
+        return {"handle_bbox": self.cur[2], "success": (rng.random((self.num_envs, 1)) > 0.5).astype(np.float64)}
+
+    def reset(self, indices=None):
+        self.resets += 1
+        return None

@@ -1,0 +1,50 @@
+"""Shared by the CPU and GPU controller-step tests: the fake estimator / manipulation the golden generator used
+(tools/make_goldens.py::gen_control_step) and the episode driver."""
+import numpy as np
+
+from rgbmanip_amd import synth
+
+N_ENVS, SEED, STEPS = 3, 4, 10
+TASKS = (("cabinet", 0.0), ("mugs", 0.0), ("pots", 1.5))
+
+
+class StepFakeEstimator:
+    def __init__(self, task):
+        self.cfg = {"task_name": task}
+
+    def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+        K, rgb1, m1, E1, rgb2, m2, E2 = (np.asarray(a, dtype=np.float64) for a in (K, rgb1, m1, E1, rgb2, m2, E2))
+        base = np.arange(24, dtype=np.float64).reshape(1, 8, 3) * 0.01
+        return base + (m1.sum((1, 2)) * 1e-5 + rgb2[:, 0, 0, 0])[:, None, None] + np.sin(np.arange(24.0)).reshape(1, 8, 3) * E1[:, 0, 3, None, None]
+
+
+class RecordingManipulation:
+    def __init__(self):
+        self.calls = []
+
+    def plan_pathway(self, center, direction, eval):
+        to_np = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else np.array(a)
+        self.calls.append((to_np(center), to_np(direction), bool(eval)))
+
+
+def to_np(a):
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
+def drive_steps(make_ci, keys):
+    """Runs the golden's episodes on `make_ci(env, estimator, manipulation, cfg)`; returns {task: record of stacked arrays}."""
+    out = {}
+    for task, succ in TASKS:
+        env, est, man = synth.ReplayVecEnv(N_ENVS, SEED), StepFakeEstimator(task), RecordingManipulation()
+        ci = make_ci(env, est, man, synth.control_cfg(task, succ))
+        rec = {k: [] for k in ("obs", "reward", "done", "target", "terms", "state")}
+        rec["obs"].append(to_np(ci.get_observation()))
+        for step in range(STEPS):
+            obs, rew, done, info = ci.step(synth.control_actions(N_ENVS, step, SEED), eval=False)
+            rec["obs"].append(to_np(obs)); rec["reward"].append(to_np(rew)); rec["done"].append(to_np(done))
+            rec["target"].append(to_np(ci.last_pose_target).copy())
+            rec["terms"].append(np.stack([to_np(info[k]).astype(np.float64) for k in keys]))
+            rec["state"].append(to_np(ci.get_state()))
+        out[task] = {k: np.stack(v) for k, v in rec.items()}
+        out[task]["env"], out[task]["manipulation"] = env, man
+    return out

@@ -342,7 +342,7 @@ def test_device_control_queue_matches_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "control.npz"))
     for task in ("cabinet", "mugs"):
         est = _control_fake_estimator(task)
-        ci = ControlInterface(3, est, 5)
+        ci = ControlInterface.queue_only(3, est, 5)
         obs, states, boxes = drive_control_queue(ci, est, lambda: ci.get_observation().cpu().numpy(), lambda: ci.get_state().cpu().numpy())
         np.testing.assert_array_equal(obs, g[task + "_obs"])
         np.testing.assert_array_equal(states, g[task + "_state"])
@@ -363,7 +363,7 @@ def test_device_control_queue_with_hip_estimator():
     N = 3
     cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device", hip_prepare_seed=1)
     est = AdaPoseEstimator_v5(None, cfg, None, state_dict=synth.adapose_state_dict(seed=0, prefix="module."), dtype="fp32")
-    ci = ControlInterface(N, est, 5)
+    ci = ControlInterface.queue_only(N, est, 5)
     for t in range(3):
         img, pose, gt = synth.control_view(N, t, seed=6)
         ci.add_view(img, pose)

@@ -142,3 +142,64 @@ def test_control_queue_oracle_matches_reference_golden(golden_dir):
         np.testing.assert_array_equal(ci.available, g[task + "_available"])
         np.testing.assert_array_equal(ci.available_num, g[task + "_available_num"])
         np.testing.assert_array_equal(ci.bbox_queue, g[task + "_bbox_queue"])
+
+
+def test_control_step_oracle_matches_reference_golden(golden_dir):
+    """oracle/control_ref.py::ControlInterfaceRef (step, get_reward, get_done, reset, reset_robot, call_manipulation,
+    lookat_quat, quat_to_axis' batch scramble) against the reference class itself run through the same ReplayVecEnv
+    episodes (tests/golden/control_step.npz): three tasks, 10 steps = 2 automatic resets, success reward on for pots."""
+    import numpy as np
+    from control_util import drive_steps
+    from oracle import control_ref as cr
+    g = np.load(os.path.join(golden_dir, "control_step.npz"))
+    runs = drive_steps(cr.ControlInterfaceRef, cr.REWARD_KEYS)
+    for task, rec in runs.items():
+        np.testing.assert_array_equal(rec["obs"], g[task + "_obs"])
+        np.testing.assert_array_equal(rec["state"], g[task + "_state"])
+        np.testing.assert_array_equal(rec["done"], g[task + "_done"])
+        np.testing.assert_allclose(rec["target"], g[task + "_target"], rtol=0, atol=1e-15)      # same LAPACK, same eigenvector sign
+        np.testing.assert_allclose(rec["terms"], g[task + "_terms"], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(rec["reward"], g[task + "_reward"], rtol=0, atol=1e-14)
+        env, man = rec["env"], rec["manipulation"]
+        assert env.resets == int(g[task + "_resets"])
+        np.testing.assert_allclose(np.stack([np.broadcast_to(m["pose"], (3, 7)) for m in env.moves]), g[task + "_move_pose"], atol=1e-15)
+        flags = np.array([[m["skip_move"], m["no_collision_with_front"], m["robot_frame"]] for m in env.moves])
+        np.testing.assert_array_equal(flags, g[task + "_move_flags"])
+        if task == "pots":
+            np.testing.assert_array_equal(np.stack([c[0] for c in man.calls]), g["pots_manip_center"])
+            np.testing.assert_array_equal(np.stack([c[1] for c in man.calls]), g["pots_manip_direction"])
+            assert [c[2] for c in man.calls] == list(g["pots_manip_eval"])
+        else:
+            assert not man.calls
+    # lookat_quat: every per-row branch, up to the eigenvector's sign
+    q = cr.lookat_quat(g["lookat_dir"])
+    np.testing.assert_allclose(cr.canonical_quat(q), cr.canonical_quat(g["lookat_quat"]), rtol=0, atol=1e-12)
+
+
+def test_synth_camera_ref_is_geometrically_consistent():
+    """oracle/synth_env_ref.py: the rendered handle mask is the silhouette of the ground-truth corners under the returned
+    K and E (so mask, handle_bbox, Intrinsic and Extrinsic of the synthetic env agree with each other)."""
+    import numpy as np
+    from oracle import control_ref as cr, synth_env_ref as sr
+    from rgbmanip_amd import synthetic_env as se
+    N = 3
+    robots, boxes = (np.stack(a) for a in zip(*[se.sample_scene(i, 1) for i in range(N)]))
+    cam = np.zeros((N, 7)); cam[:, 0] = [-0.3, 0.0, 0.2]; cam[:, 1] = [0.0, 0.2, -0.1]; cam[:, 2] = [0.7, 0.6, 0.9]
+    cam[:, 3:] = cr.canonical_quat(cr.lookat_quat(np.array([[1.0, 0.0, -0.2], [1.0, -0.3, 0.1], [1.0, 0.2, -0.4]])))
+    f = se.CAM_F
+    K, E, rays = sr.camera_ref(cam, robots, boxes, f, f, 320.0, 240.0)
+    color, mask = sr.render_ref(rays, boxes, f, f, 320.0, 240.0, 480, 640)
+    assert color.dtype == np.float32 and 0.0 <= color.min() and color.max() <= 1.0
+    uv, z = sr.project_points(K, E, sr.box_corners(boxes))
+    assert (z > 0.3).all()
+    for e in range(N):
+        ys, xs = np.nonzero(mask[e])
+        assert xs.size > 200
+        lo, hi = uv[e].min(0), uv[e].max(0)
+        assert abs(xs.min() - lo[0]) <= 1.0 and abs(xs.max() - hi[0]) <= 1.0, (xs.min(), xs.max(), lo, hi)
+        assert abs(ys.min() - lo[1]) <= 1.0 and abs(ys.max() - hi[1]) <= 1.0, (ys.min(), ys.max(), lo, hi)
+    # rotation part of E is orthonormal, E maps the camera centre to the origin
+    R = E[:, :3, :3]
+    np.testing.assert_allclose(R @ np.transpose(R, (0, 2, 1)), np.tile(np.eye(3), (N, 1, 1)), atol=1e-12)
+    centre = robots[:, :3] + cam[:, :3]
+    np.testing.assert_allclose(np.einsum("nij,nj->ni", R, centre) + E[:, :3, 3], 0, atol=1e-12)

@@ -372,12 +372,85 @@ def gen_control(out_dir):
         os.chdir(cwd)
 
 
+REWARD_KEYS = ["REW:diff", "REW:move_success", "REW:move_period", "REW:far", "REW:ori_rew", "REW:xyz_lookat", "REW:bbox_penalty",
+               "REW:bbox_boundary_penalty", "REW:have_bbox", "REW:center_rew", "REW:open_rew", "REW:view_rew",
+               "REW:view_norm_penalty", "REW:success", "LOSS:center_diff", "LOSS:open_diff", "LOSS:far"]
+
+
+def gen_control_step(out_dir):
+    """`ControlInterface.step` / `get_reward` / `get_done` / `reset` / `reset_robot` / `call_manipulation`
+    (rl_pose.py:99-116, 225-462) of the reference class itself, driven through 2+ episodes by
+    rgbmanip_amd.synth.ReplayVecEnv, seeded actions and the same recording fake estimator as gen_control."""
+    from rgbmanip_amd import synth
+    stub("env.sapien_envs.open_cabinet", CAMERA_INTRINSIC=[0.05, 100, 1, 640, 480])
+    stub("env.sapien_envs", open_cabinet=sys.modules["env.sapien_envs.open_cabinet"])
+    stub("models.manipulation.open_cabinet", OpenCabinetManipulation=object)
+    stub("models.controller.base_controller", BaseController=object)
+    stub("models.pose_estimator.base_estimator", BasePoseEstimator=object)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        from models.controller.rl_pose import ControlInterface
+        from utils.transform import lookat_quat
+        N, seed = 3, 4
+
+        class FakeEstimator:
+            def __init__(self, task):
+                self.cfg = {"task_name": task}
+
+            def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+                base = np.arange(24, dtype=np.float64).reshape(1, 8, 3) * 0.01
+                return base + (m1.sum((1, 2)) * 1e-5 + rgb2[:, 0, 0, 0])[:, None, None] + np.sin(np.arange(24.0)).reshape(1, 8, 3) * E1[:, 0, 3, None, None]
+
+        class Manip:
+            def __init__(self):
+                self.calls = []
+
+            def plan_pathway(self, center, direction, eval):
+                self.calls.append((center.copy(), direction.copy(), bool(eval)))
+
+        save = {}
+        for task, succ in (("cabinet", 0.0), ("mugs", 0.0), ("pots", 1.5)):
+            cfg = synth.control_cfg(task, succ)
+            env, est, man = synth.ReplayVecEnv(N, seed), FakeEstimator(task), Manip()
+            ci = ControlInterface(env, est, man, cfg)
+            rec = {k: [] for k in ("obs", "reward", "done", "target", "terms", "state")}
+            rec["obs"].append(ci.get_observation().numpy())
+            for step in range(10):
+                a = torch.from_numpy(synth.control_actions(N, step, seed))
+                obs, rew, done, info = ci.step(a, eval=False)
+                rec["obs"].append(obs.numpy()); rec["reward"].append(rew.numpy()); rec["done"].append(done.numpy())
+                rec["target"].append(ci.last_pose_target.copy())
+                rec["terms"].append(np.stack([info[k].numpy().astype(np.float64) for k in REWARD_KEYS]))
+                rec["state"].append(ci.get_state().numpy())
+            for k, v in rec.items():
+                save[f"{task}_{k}"] = np.stack(v)
+            save[f"{task}_resets"] = np.array(env.resets)
+            save[f"{task}_move_pose"] = np.stack([np.broadcast_to(m["pose"], (N, 7)) for m in env.moves])
+            save[f"{task}_move_ndim"] = np.array([m["pose"].ndim for m in env.moves])
+            save[f"{task}_move_flags"] = np.array([[m["skip_move"], m["no_collision_with_front"], m["robot_frame"]] for m in env.moves])
+            save[f"{task}_move_tw"] = np.array([[m["time"], m["wait"]] for m in env.moves])
+            if man.calls:
+                save[f"{task}_manip_center"] = np.stack([c[0] for c in man.calls])
+                save[f"{task}_manip_direction"] = np.stack([c[1] for c in man.calls])
+                save[f"{task}_manip_eval"] = np.array([c[2] for c in man.calls])
+        # lookat_quat (utils/transform.py:50-99) on directions covering its three per-row branches
+        d = np.random.default_rng(11).normal(size=(64, 3))
+        d[0] = [0, 0, 1.0]; d[1] = [0, 0, -2.0]; d[2] = [1, 0, 0]; d[3] = [1e-4, 0, 1.0]; d[4] = [3, -4, 0]
+        save["lookat_dir"] = d
+        save["lookat_quat"] = lookat_quat(d)
+        np.savez_compressed(os.path.join(out_dir, "control_step.npz"), **save)
+        print("control_step golden:", {k: v.shape for k, v in save.items() if k.startswith("pots") or k.startswith("lookat")})
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     install_stubs()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control"]
+    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control", "control_step"]
     net_out = inp = None
     if "adapose" in which or "postproc" in which:
         net_out, inp = gen_adapose(out_dir)
@@ -387,4 +460,6 @@ if __name__ == "__main__":
         gen_ppo(out_dir)
     if "control" in which:
         gen_control(out_dir)
+    if "control_step" in which:
+        gen_control_step(out_dir)
     print("done")
