@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
     ap.add_argument("--ppo-envs", type=int, default=512, help="envs per GPU for the PPO leg (0 = skip it)")
+    ap.add_argument("--ppo-env", default="full", choices=["full", "bank"],
+                    help="full: ControlInterface over the synthetic MultiVecEnv (480x640 frames); bank: pre-cropped 224x224 view bank")
     ap.add_argument("--no-prepare", action="store_true", help="skip the device-side prepare_model_input leg")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
@@ -178,14 +180,30 @@ def main():
     if args.ppo_envs > 0:
         from rgbmanip_amd.config import rl_cfg
         from rgbmanip_amd.ppo import PPO
-        from rgbmanip_amd.synthetic_env import SyntheticPoseVecEnv
-        env = SyntheticPoseVecEnv(args.ppo_envs, net, device, seed=0, rank=rank)
-        ppo = PPO(env, rl_cfg(device=str(device), print_log=False, log_dir="/tmp/rgbm_bench_logs", save_dir="/tmp/rgbm_bench_saves"))
+        cfg = rl_cfg(task="cabinet", device=str(device), print_log=False, log_dir="/tmp/rgbm_bench_logs", save_dir="/tmp/rgbm_bench_saves")
+        if args.ppo_env == "full":
+            # the reference's loop: ControlInterface.step over a (synthetic) MultiVecEnv partition of this rank — camera move,
+            # 480x640 render, view queue, prepare_model_input, AdaPose, post-processing, reward — all on the device
+            from rgbmanip_amd.config import ADAPOSE_CFGS
+            from rgbmanip_amd.control_interface import ControlInterface
+            from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+            from rgbmanip_amd.synthetic_env import SyntheticManipulation, SyntheticMultiVecEnv
+            est = AdaPoseEstimator_v5(None, dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device"), None,
+                                      dtype=args.dtype, net=net)
+            venv = SyntheticMultiVecEnv(args.ppo_envs, device, seed=0, env_id_offset=rank * args.ppo_envs)
+            env = ControlInterface(venv, est, SyntheticManipulation(venv), cfg, device=device)
+            env_name = ("ControlInterface.step over SyntheticMultiVecEnv: render 480x640 -> view queue -> prepare_model_input -> "
+                        "AdaPose -> bbox -> 14-term reward, per env step, all on the device")
+        else:
+            from rgbmanip_amd.synthetic_env import SyntheticPoseVecEnv
+            env = SyntheticPoseVecEnv(args.ppo_envs, net, device, seed=0, rank=rank)
+            env_name = "SyntheticPoseVecEnv (pre-cropped view bank; one batched AdaPose estimate per env step)"
+        ppo = PPO(env, cfg)
         ppo.run(args.ppo_iters, log_interval=1, save_interval=10 ** 9)
         barrier()
         ppo_res = {"env_steps_per_sec": round(ppo.last_fps, 1), "num_envs_per_gpu": args.ppo_envs, "transitions_per_env": 16,
                    "collection_s": round(ppo.last_collection_time, 3), "learn_s": round(ppo.last_learn_time, 4),
-                   "optimizer_steps": 32, "env": "SyntheticPoseVecEnv (one batched AdaPose estimate per env step)",
+                   "optimizer_steps": 32, "env": env_name,
                    "lr_after": ppo.step_size}
 
     if rank == 0:

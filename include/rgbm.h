@@ -95,6 +95,14 @@ int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const dou
                         uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
                         int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream);
 
+/* The same, reading frame f's image and mask from entry frame_map[f] of rgb_dev / mask_dev (e.g. the controller's view
+ * queue [T*N,H,W,...]) instead of gathering the selected views first; frame_map[f] < 0 = no such view
+ * (treated as an empty mask: valid 0).  K_dev, every output and the subset hash stay indexed by f. */
+int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, const int32_t* frame_map_dev,
+                                int N, int H, int W, int S, int P, uint32_t seed, float* img_out, int32_t* choose_out,
+                                float* pts2d_out, double* Kcrop_out, int32_t* window_out, int32_t* valid_out, uint8_t* scratch,
+                                void* stream);
+
 /* Per-env mask extent for the controller's view queue.
  * Replaces: the np.nonzero / np.where loop of ControlInterface.add_view   models/controller/rl_pose.py:130-149
  * mask [N,H,W] u8 -> ext [N,4] i32 = (row min, col min, row max, col max), (2H, 2W, 0, 0) for an empty mask; count [N]. */

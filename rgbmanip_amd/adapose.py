@@ -147,17 +147,29 @@ def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_
     return bbox, ts, valid
 
 
-def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None):
+def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None,
+                   frame_map=None):
     """Batched device-side `AdaPoseEstimator_v5.prepare_model_input` (`interface_v5.py:58-170`).
 
     rgb [N,H,W,3] float32 in [0,1], mask [N,H,W] (0/1), K [N,3,3]: torch CUDA tensors (or anything torch.as_tensor accepts).
+    With `frame_map` [N] int32, rgb / mask are a pool [M,H,W,..] (e.g. a view queue) and frame f reads entry frame_map[f]
+    (negative: no view -> valid 0) — no gather of the selected frames is needed; K stays [N,3,3].
     Returns dict(img [N,3,S,S] f32, choose [N,P] i32, Kcrop [N,3,3] f64, window [N,4] i32, valid [N] i32[, pts2d])."""
     lib = _lib.load()
     dev = rgb.device if isinstance(rgb, torch.Tensor) and rgb.is_cuda else torch.device("cuda", torch.cuda.current_device())
     rgb = torch.as_tensor(rgb).to(device=dev, dtype=torch.float32).contiguous()
-    mask = (torch.as_tensor(mask).to(device=dev) != 0).to(torch.uint8).contiguous()
+    mask = torch.as_tensor(mask).to(device=dev)
+    if mask.dtype != torch.uint8:                       # the kernels test for non-zero, so a uint8 mask is used as it is
+        mask = (mask != 0).to(torch.uint8)
+    mask = mask.contiguous()
     K = torch.as_tensor(K).to(device=dev, dtype=torch.float64).contiguous()
-    N, H, W, _ = rgb.shape
+    _, H, W, _ = rgb.shape
+    N = K.shape[0]
+    if frame_map is None:
+        assert rgb.shape[0] == N and mask.shape[0] == N
+    else:
+        frame_map = torch.as_tensor(frame_map).to(device=dev, dtype=torch.int32).contiguous()
+        assert frame_map.shape == (N,) and mask.shape[0] == rgb.shape[0]
     S, P = int(img_size), int(n_pts)
     img = torch.empty(N, 3, S, S, dtype=torch.float32, device=dev)
     choose = torch.empty(N, P, dtype=torch.int32, device=dev)
@@ -166,9 +178,13 @@ def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: i
     window = torch.empty(N, 4, dtype=torch.int32, device=dev)
     valid = torch.empty(N, dtype=torch.int32, device=dev)
     scratch = torch.empty(N * S * S, dtype=torch.uint8, device=dev)
-    _lib.check(lib.rgbm_prepare_inputs(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), N, H, W, S, P, int(seed) & 0xFFFFFFFF,
-                                       _lib.ptr(img), _lib.ptr(choose), _lib.ptr(pts2d), _lib.ptr(Kcrop), _lib.ptr(window),
-                                       _lib.ptr(valid), _lib.ptr(scratch), _lib.stream_ptr(stream)), "rgbm_prepare_inputs")
+    tail = (N, H, W, S, P, int(seed) & 0xFFFFFFFF, _lib.ptr(img), _lib.ptr(choose), _lib.ptr(pts2d), _lib.ptr(Kcrop), _lib.ptr(window),
+            _lib.ptr(valid), _lib.ptr(scratch), _lib.stream_ptr(stream))
+    if frame_map is None:
+        _lib.check(lib.rgbm_prepare_inputs(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), *tail), "rgbm_prepare_inputs")
+    else:
+        _lib.check(lib.rgbm_prepare_inputs_indexed(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), _lib.ptr(frame_map), *tail),
+                   "rgbm_prepare_inputs_indexed")
     out = {"img": img, "choose": choose, "Kcrop": Kcrop, "window": window, "valid": valid}
     if want_pts2d:
         out["pts2d"] = pts2d

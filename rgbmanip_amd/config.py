@@ -5,6 +5,9 @@ import copy
 RL_CONTROLLER_CFG = {
     "name": "rl",
     "controller": {"max_steps": 4, "action_type": "pose", "pose_min": [-0.3, -0.3, 0.4], "pose_max": [0.3, 0.3, 1.0], "early_stop": 4},
+    "reward": {"diff_coef": -0.5, "move_success_coef": 8.0, "move_period_coef": -0.0, "far_coef": -2.5, "ori_coef": 0.25,
+               "xyz_lookat_coef": -0.05, "bbox_coef": -1.0, "bbox_boundary_coef": -1.0, "have_bbox_coef": 2.0, "center_coef": 12.0,
+               "open_coef": 8.0, "view_coef": 0.5, "view_norm_coef": -0.3, "success_coef": 0.0},
     "policy": {"actor_critic_class": "ActorCritic", "pi_hid_sizes": [96, 96, 32], "vf_hid_sizes": [96, 96, 32], "activation": "elu"},
     "learn": {
         "exp_name": "PPO", "reset": True, "num_transitions_per_env": 16, "num_transitions_eval": 512, "num_learning_epochs": 8,
@@ -31,7 +34,9 @@ ADAPOSE_CFGS = {
 }
 
 
-def rl_cfg(**learn_overrides):
+def rl_cfg(task="cabinet", **learn_overrides):
+    """cfg/controller/rl.yaml merged with the task name ControlInterface reads (cfg/task/*.yaml `name`)."""
     cfg = copy.deepcopy(RL_CONTROLLER_CFG)
     cfg["learn"].update(learn_overrides)
+    cfg["task"] = {"name": task}
     return cfg

@@ -186,16 +186,24 @@ class ControlInterface:
     # ------------------------------------------------------------------ rl_pose.py:189-223
     def get_estimation(self):
         idx, has = self.select_views()
+        T, N = self.max_steps, self.num_envs
         K = [self._gather(self.intrinsic_queue, idx[s], has[s]) for s in (0, 1)]
         E = [self._gather(self.extrinsic_queue, idx[s], has[s]) for s in (0, 1)]
-        rgb = [self._gather(self.image_queue, idx[s], has[s]) for s in (0, 1)]
-        mask = [self._gather(self.mask_queue, idx[s], has[s]) for s in (0, 1)]
-        if hasattr(self.estimator, "estimate_device"):
-            bbox = self.estimator.estimate_device(K[0], rgb[0], mask[0], E[0], rgb[1], mask[1], E[1])
-        else:                                                            # numpy-in / numpy-out estimators (interface_v5.py:213)
-            bbox = torch.from_numpy(np.asarray(self.estimator.estimate(
-                K[0].cpu().numpy(), rgb[0].cpu().numpy(), mask[0].cpu().numpy(), E[0].cpu().numpy(), rgb[1].cpu().numpy(),
-                mask[1].cpu().numpy(), E[1].cpu().numpy()))).to(self.device)
+        if hasattr(self.estimator, "estimate_device_indexed"):
+            # the estimator reads the selected frames straight out of the queue: no [N,480,640,3] gather copies
+            env = torch.arange(N, device=self.device)
+            fmap = [torch.where(has[s], idx[s] * N + env, torch.full_like(env, -1)).to(torch.int32) for s in (0, 1)]
+            bbox = self.estimator.estimate_device_indexed(K[0], self.image_queue.view(T * N, self.H, self.W, 3),
+                                                          self.mask_queue.view(T * N, self.H, self.W), E[0], E[1], fmap[0], fmap[1])
+        else:
+            rgb = [self._gather(self.image_queue, idx[s], has[s]) for s in (0, 1)]
+            mask = [self._gather(self.mask_queue, idx[s], has[s]) for s in (0, 1)]
+            if hasattr(self.estimator, "estimate_device"):
+                bbox = self.estimator.estimate_device(K[0], rgb[0], mask[0], E[0], rgb[1], mask[1], E[1])
+            else:                                                        # numpy-in / numpy-out estimators (interface_v5.py:213)
+                bbox = torch.from_numpy(np.asarray(self.estimator.estimate(
+                    K[0].cpu().numpy(), rgb[0].cpu().numpy(), mask[0].cpu().numpy(), E[0].cpu().numpy(), rgb[1].cpu().numpy(),
+                    mask[1].cpu().numpy(), E[1].cpu().numpy()))).to(self.device)
         if self.estimator.cfg["task_name"] == "mugs":
             bbox = bbox[:, _MUG_PERM]
         return bbox

@@ -271,8 +271,17 @@ extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, 
 extern "C" int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, int N, int H, int W, int S,
                                    int P, uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
                                    int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream) {
-  return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, N, H, W, S, P, seed, img_out, choose_out, pts2d_out, Kcrop_out,
+  return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, nullptr, N, H, W, S, P, seed, img_out, choose_out, pts2d_out, Kcrop_out,
                                window_out, valid_out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev,
+                                           const int32_t* frame_map_dev, int N, int H, int W, int S, int P, uint32_t seed,
+                                           float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
+                                           int32_t* window_out, int32_t* valid_out, uint8_t* scratch, void* stream) {
+  RGBM_REQUIRE(frame_map_dev, "prepare_inputs_indexed frame_map");
+  return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, frame_map_dev, N, H, W, S, P, seed, img_out, choose_out, pts2d_out,
+                               Kcrop_out, window_out, valid_out, scratch, (hipStream_t)stream);
 }
 
 extern "C" int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream) {

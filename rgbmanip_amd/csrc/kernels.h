@@ -61,7 +61,7 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
                        int D, int H, int W, hipStream_t s);
 
 // prepare.hip — batched device-side AdaPoseEstimator_v5.prepare_model_input
-int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, int N, int H, int W, int S, int P,
+int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
                           unsigned char* small_scratch, hipStream_t s);
 

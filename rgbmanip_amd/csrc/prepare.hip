@@ -26,16 +26,20 @@ __host__ __device__ inline unsigned mix32(unsigned seed, unsigned frame, unsigne
 }
 
 // ---- 1. mask bounding box -> crop window (get_bbox) -> cropped intrinsics ------------------------------------------
+// frame_map (optional): frame f reads image / mask number frame_map[f] of the arrays it is given (a view queue); a negative
+// entry is a missing view and behaves like an all-zero mask.  K, the outputs and the subset hash stay indexed by f.
 __global__ __launch_bounds__(PRE_THREADS) void mask_window_kernel(const unsigned char* __restrict__ mask, const double* __restrict__ K,
+                                                                   const int* __restrict__ frame_map,
                                                                    int H, int W, int S, int* __restrict__ window /*[N,4]*/,
                                                                    double* __restrict__ Kcrop /*[N,9]*/, int* __restrict__ valid) {
   __shared__ int s_y1, s_x1, s_y2, s_x2;
   const int f = blockIdx.x, t = threadIdx.x;
   if (t == 0) { s_y1 = H; s_x1 = W; s_y2 = -1; s_x2 = -1; }
   __syncthreads();
-  const unsigned char* m = mask + (long long)f * H * W;
+  const int sf = frame_map ? frame_map[f] : f;
+  const unsigned char* m = mask + (long long)(sf < 0 ? 0 : sf) * H * W;
   int y1 = H, x1 = W, y2 = -1, x2 = -1;
-  for (int i = t; i < H * W; i += PRE_THREADS) {
+  for (int i = t; sf >= 0 && i < H * W; i += PRE_THREADS) {
     if (m[i]) {
       const int y = i / W, x = i - y * W;
       y1 = min(y1, y); y2 = max(y2, y); x1 = min(x1, x); x2 = max(x2, x);
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(PRE_THREADS) void mask_window_kernel(const unsigned
 
 // ---- 2. crop + resize: nearest mask, bilinear RGB, ToTensor + Normalize ---------------------------------------------
 __global__ void crop_resize_kernel(const float* __restrict__ rgb /*[N,H,W,3]*/, const unsigned char* __restrict__ mask,
-                                   const int* __restrict__ window, int N, int H, int W, int S, float* __restrict__ img /*[N,3,S,S]*/,
-                                   unsigned char* __restrict__ small /*[N,S,S]*/) {
+                                   const int* __restrict__ frame_map, const int* __restrict__ window, int N, int H, int W, int S,
+                                   float* __restrict__ img /*[N,3,S,S]*/, unsigned char* __restrict__ small /*[N,S,S]*/) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)N * S * S) return;
   const int f = (int)(i / (S * S)), p = (int)(i - (long long)f * S * S), dy = p / S, dx = p - dy * S;
@@ -85,7 +89,9 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb /*[N,H,W,3]*/, 
   // INTER_NEAREST: sx = min(floor(dx * (src/dst)), src-1), fp64 like numpy's python-float scale
   const int ny = min((int)floor((double)dy * ((double)h / (double)S)), h - 1);
   const int nx = min((int)floor((double)dx * ((double)w / (double)S)), w - 1);
-  small[i] = mask[((long long)f * H + rmin + ny) * W + cmin + nx] ? 1 : 0;
+  const int mf = frame_map ? frame_map[f] : f;
+  const int sf = mf < 0 ? 0 : mf;
+  small[i] = (mf >= 0 && mask[((long long)sf * H + rmin + ny) * W + cmin + nx]) ? 1 : 0;
   // INTER_LINEAR on a float image: f = (d + 0.5) * scale - 0.5, clamp at both edges, weights in fp32
   auto taps = [](int d, int n_src, int n_dst, int& i0, int& i1, float& a) {
     const double fl = ((double)d + 0.5) * ((double)n_src / (double)n_dst) - 0.5;
@@ -99,7 +105,7 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb /*[N,H,W,3]*/, 
   float ay, ax;
   taps(dy, h, S, y0, y1, ay);
   taps(dx, w, S, x0, x1, ax);
-  const float* base = rgb + (long long)f * H * W * 3;
+  const float* base = rgb + (long long)sf * H * W * 3;
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -230,14 +236,14 @@ int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext,
 
 unsigned prepare_mix32(unsigned seed, unsigned frame, unsigned idx) { return mix32(seed, frame, idx); }
 
-int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, int N, int H, int W, int S, int P,
+int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
                           unsigned char* small_scratch, hipStream_t s) {
   RGBM_REQUIRE(rgb && mask && K && img && choose && Kcrop && window && valid && small_scratch, "prepare_inputs arguments");
   RGBM_REQUIRE(N > 0 && H >= 40 && W >= 40 && S > 0 && P > 0 && S * S <= 65536, "prepare_inputs sizes");
-  hipLaunchKernelGGL(mask_window_kernel, dim3(N), dim3(PRE_THREADS), 0, s, mask, K, H, W, S, window, Kcrop, valid);
+  hipLaunchKernelGGL(mask_window_kernel, dim3(N), dim3(PRE_THREADS), 0, s, mask, K, frame_map, H, W, S, window, Kcrop, valid);
   const long long tot = (long long)N * S * S;
-  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rgb, mask, window, N, H, W, S, img, small_scratch);
+  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rgb, mask, frame_map, window, N, H, W, S, img, small_scratch);
   const size_t lds = (size_t)S * S * sizeof(unsigned short);
   static bool attr_done = false;
   if (!attr_done) {

@@ -97,11 +97,14 @@ def _mix32(seed, frame, idx):
 
 
 class AdaPoseEstimator_v5(BasePoseEstimator):
-    def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0):
+    def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0, net=None):
+        """`net`: an already built `AdaPoseNet` to share (weights + workspace) instead of building one from `state_dict`."""
         super().__init__(env, cfg, logger)
         if not cfg.get("direct_regression", True):
             raise NotImplementedError("only the shipped direct_regression=True branch is implemented (SURVEY.md §2 #8)")
-        if state_dict is None:
+        if net is not None:
+            state_dict = {}
+        elif state_dict is None:
             if cfg.get("load", False):
                 state_dict = torch.load(cfg["checkpoint_path"], map_location="cpu")      # DataParallel keys ("module.")
             else:
@@ -110,7 +113,7 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 if logger is not None:
                     logger.warning("AdaPoseEstimator_v5: cfg.load is False -> synthetic (seeded) weights")
         self.dtype = dtype or cfg.get("hip_dtype", "fp32")
-        self.estimator = AdaPoseNet(state_dict, dtype=self.dtype, device=device)
+        self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device)
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
         self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))
@@ -195,10 +198,24 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         (empty mask) or reject (non-finite box) hold `default_bbox`."""
         S = self.cfg["img_size"]
         dev = self.estimator.device
-        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), torch.as_tensor(K).to(dev), S, 1024,
-                           self.prepare_seed)
-        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), torch.as_tensor(K).to(dev), S, 1024,
-                           self.prepare_seed + 1)
+        Kd = torch.as_tensor(K).to(dev)
+        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), Kd, S, 1024, self.prepare_seed)
+        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), Kd, S, 1024, self.prepare_seed + 1)
+        return self._estimate_prepared(a, b, E1, E2)
+
+    def estimate_device_indexed(self, K, rgb_pool, mask_pool, E1, E2, map1, map2):
+        """`estimate_device` reading the two views of sample i from entries map1[i] / map2[i] of a frame pool
+        (rgb_pool [M,H,W,3] float32, mask_pool [M,H,W] uint8 — e.g. the controller's view queue) instead of from gathered
+        batches; a negative entry means "no such view" (the reference hands an all-zero frame over, which is skipped).
+        K [N,3,3] (both views use it, interface_v5.py:213-227), E1 / E2 [N,4,4]."""
+        S = self.cfg["img_size"]
+        a = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed, frame_map=map1)
+        b = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed + 1, frame_map=map2)
+        return self._estimate_prepared(a, b, E1, E2)
+
+    def _estimate_prepared(self, a, b, E1, E2):
+        S = self.cfg["img_size"]
+        dev = self.estimator.device
         E1d = torch.as_tensor(E1).to(device=dev, dtype=torch.float64)
         E2d = torch.as_tensor(E2).to(device=dev, dtype=torch.float64)
         n = E1d.shape[0]

@@ -128,36 +128,48 @@ class SyntheticMultiVecEnv:
     CUDA tensor.  `cam_move_to` is a reach model: targets farther than `reach` from the shoulder fail and leave the camera
     half way; it returns `[success, period]` like `merge_obs` of the reference's per-env `(bool, int)` tuples."""
 
-    def __init__(self, num_envs: int, device, seed: int = 0, env_id_offset: int = 0, reach: float = 0.55):
+    def __init__(self, num_envs: int, device, seed: int = 0, env_id_offset: int = 0, reach: float = 0.55, episodes: int = 32):
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.env_ids = np.arange(env_id_offset, env_id_offset + self.num_envs) + 100000 * int(seed)
         self.env0 = int(env_id_offset)
         self.reach = float(reach)
         self.lib = _lib.load()
-        self.episode = np.zeros(self.num_envs, dtype=np.int64)
         dev = self.device
-        self._robot = torch.zeros(self.num_envs, 7, dtype=torch.float64, device=dev)
-        self._box = torch.zeros(self.num_envs, 15, dtype=torch.float64, device=dev)
+        # scenes of the first `episodes` episodes of every env, sampled once on the host and kept on the device, so a reset
+        # is an index operation on the GPU (no host->device copy, which would stall the stream); episode e reuses e % episodes
+        self.bank_episodes = int(episodes)
+        scenes = [[sample_scene(i, e) for i in self.env_ids] for e in range(self.bank_episodes)]
+        self._bank_robot = torch.from_numpy(np.stack([[sc[0] for sc in row] for row in scenes])).to(dev)    # [E,N,7]
+        self._bank_box = torch.from_numpy(np.stack([[sc[1] for sc in row] for row in scenes])).to(dev)      # [E,N,15]
+        self.episode = np.zeros(self.num_envs, dtype=np.int64)               # host mirror of the per-env episode counter
+        self._episode = torch.zeros(self.num_envs, dtype=torch.int64, device=dev)
+        self._arange = torch.arange(self.num_envs, device=dev)
         self._cam = torch.zeros(self.num_envs, 7, dtype=torch.float64, device=dev)
         self._cam[:, 2] = 0.7
         self._cam[:, 3] = 1.0
         self._success = torch.zeros(self.num_envs, 1, dtype=torch.float64, device=dev)
         self._shoulder = torch.tensor([0.0, 0.0, 0.6], dtype=torch.float64, device=dev)
-        self._sample(np.arange(self.num_envs))
+        self._load_scenes()
 
-    def _sample(self, idx):
-        robots, boxes = zip(*[sample_scene(self.env_ids[i], self.episode[i]) for i in idx])
-        sel = torch.as_tensor(np.asarray(idx), device=self.device)
-        self._robot[sel] = torch.from_numpy(np.stack(robots)).to(self.device)
-        self._box[sel] = torch.from_numpy(np.stack(boxes)).to(self.device)
-        self._success[sel] = 0
+    def _load_scenes(self):
+        slot = self._episode % self.bank_episodes
+        self._robot = self._bank_robot[slot, self._arange]
+        self._box = self._bank_box[slot, self._arange]
 
     # ---- my_vec_env.py:214
     def reset(self, indices=None):
-        idx = np.arange(self.num_envs) if indices is None else np.atleast_1d(np.asarray(indices))
-        self.episode[idx] += 1
-        self._sample(idx)
+        if indices is None:
+            self.episode += 1
+            self._episode += 1
+            self._success.zero_()
+        else:
+            idx = np.atleast_1d(np.asarray(indices))
+            self.episode[idx] += 1
+            sel = torch.as_tensor(idx, device=self.device)
+            self._episode[sel] += 1
+            self._success[sel] = 0
+        self._load_scenes()
         return None
 
     # ---- my_vec_env.py:382, base_manipulation.py:544
