@@ -97,12 +97,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
                          f"(WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    # RGBM_BENCH_ONE_DEVICE=1 (+ RGBM_DIST_BACKEND=gloo) lets a 1-GPU box rehearse the multi-rank code path: every rank uses cuda:0
+    if os.environ.get("RGBM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("RGBM_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from rgbmanip_amd import _lib, synth
     from rgbmanip_amd.adapose import AdaPoseNet, postprocess
@@ -238,7 +245,7 @@ def main():
             "metric": "adapose_poses_per_sec_batch256", "value": round(value, 3), "unit": "poses/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "adapose_cabinet forward + post-processing, batch=256 poses (512 views of 224x224) per GPU, "
+            "config": {"workload": f"adapose_cabinet forward + post-processing, batch={B} poses ({2 * B} views of 224x224) per GPU, "
                                    "synthetic RGB, random-init weights of the reference architecture",
                        "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}"},
             "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
