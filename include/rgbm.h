@@ -79,6 +79,17 @@ int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, con
                              const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
                              int32_t* valid, void* stream);
 
+/* The `direct_regression: False`, `use_depth: True` tail of predict: back-projected predicted depth vs
+ * predicted NOCS, 128-hypothesis Umeyama RANSAC, final fit over the inliers, bbox to the world frame.
+ * Replaces: interface_v5.py:322-339, 348-374; lib/align.py:10-104 (estimateSimilarityUmeyama / estimateSimilarityTransform)
+ * nocs1 [B,P,3] f32, depth1 [B,P] f32, choose1 [B,P] i32, Kcrop [B,3,3] f64, E1 [B,4,4] f64 (device) ->
+ * bbox_world [B,8,3] f64, srt [B,13] f64 (scale, R row-major, t; scale NaN where the reference returns None), valid [B].
+ * 5 <= P <= 1024.  The 5-point samples are a seeded hash (mix32(seed, 128 b + i, k) mod P) instead of np.random.randint.
+ * The third branch (`use_depth: False`, cv2.solvePnPRansac) is not provided. */
+int rgbm_adapose_postprocess_ransac(int B, int P, int img_size, uint32_t seed, const float* nocs1, const float* depth1,
+                                    const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* srt,
+                                    int32_t* valid, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Batched device-side input preparation.
  * Replaces: AdaPoseEstimator_v5.prepare_model_input   models/pose_estimator/AdaPose/interface_v5.py:58-170

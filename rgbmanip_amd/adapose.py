@@ -147,6 +147,26 @@ def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_
     return bbox, ts, valid
 
 
+def postprocess_ransac(view1_nocs, view1_depth, view1_choose, K_crop, E1, img_size: int = 224, seed: int = 0, stream=None):
+    """Device tail of `predict` for `direct_regression: False`, `use_depth: True` (`interface_v5.py:322-339, 348-374`,
+    `lib/align.py:10-104`): returns (bbox_world [B,8,3] f64, srt [B,13] f64 = scale, R, t, valid [B] i32) CUDA tensors."""
+    lib = _lib.load()
+    dev = view1_nocs.device
+    B, P = view1_depth.shape
+    nocs = view1_nocs.to(torch.float32).contiguous()
+    depth = view1_depth.to(torch.float32).contiguous()
+    ch = torch.as_tensor(view1_choose).to(device=dev, dtype=torch.int32).contiguous()
+    K = torch.as_tensor(K_crop).to(device=dev, dtype=torch.float64).contiguous()
+    E = torch.as_tensor(E1).to(device=dev, dtype=torch.float64).contiguous()
+    bbox = torch.empty(B, 8, 3, dtype=torch.float64, device=dev)
+    srt = torch.empty(B, 13, dtype=torch.float64, device=dev)
+    valid = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.rgbm_adapose_postprocess_ransac(B, P, img_size, int(seed) & 0xFFFFFFFF, _lib.ptr(nocs), _lib.ptr(depth),
+                                                   _lib.ptr(ch), _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(srt),
+                                                   _lib.ptr(valid), _lib.stream_ptr(stream)), "rgbm_adapose_postprocess_ransac")
+    return bbox, srt, valid
+
+
 def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None,
                    frame_map=None):
     """Batched device-side `AdaPoseEstimator_v5.prepare_model_input` (`interface_v5.py:58-170`).

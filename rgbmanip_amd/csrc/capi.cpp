@@ -141,6 +141,12 @@ int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, con
   return launch_postprocess(nocs1, depth1, r1, choose1, Kcrop, E1, bbox_world, ts, valid, B, P, img_size, (hipStream_t)stream);
 }
 
+int rgbm_adapose_postprocess_ransac(int B, int P, int img_size, uint32_t seed, const float* nocs1, const float* depth1,
+                                    const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* srt,
+                                    int32_t* valid, void* stream) {
+  return launch_umeyama_ransac(nocs1, depth1, choose1, Kcrop, E1, bbox_world, srt, valid, B, P, img_size, seed, (hipStream_t)stream);
+}
+
 int rgbm_gae(int T, int N, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
              float gamma, float lam, float* returns, float* adv, double* sums, void* stream) {
   RGBM_REQUIRE(rewards && dones && values && last_values && returns && adv && sums, "gae arguments");

@@ -65,6 +65,9 @@ int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const dou
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
                           unsigned char* small_scratch, hipStream_t s);
 
+int launch_umeyama_ransac(const float* nocs, const float* depth, const int* choose, const double* Kc, const double* E1,
+                          double* bbox, double* srt, int* valid, int B, int P, int img, unsigned seed, hipStream_t s);
+
 int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext, int* count, hipStream_t s);
 
 // postproc.hip

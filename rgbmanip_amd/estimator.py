@@ -17,7 +17,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .adapose import AdaPoseNet, postprocess, prepare_inputs
+from .adapose import AdaPoseNet, postprocess, postprocess_ransac, prepare_inputs
 
 DEFAULT_BBOX = np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]],
                           dtype=np.float64) + 10.0
@@ -100,8 +100,9 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
     def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0, net=None):
         """`net`: an already built `AdaPoseNet` to share (weights + workspace) instead of building one from `state_dict`."""
         super().__init__(env, cfg, logger)
-        if not cfg.get("direct_regression", True):
-            raise NotImplementedError("only the shipped direct_regression=True branch is implemented (SURVEY.md §2 #8)")
+        if not cfg.get("direct_regression", True) and not cfg.get("use_depth", True):
+            raise NotImplementedError("direct_regression=False with use_depth=False is cv2.solvePnPRansac (interface_v5.py:340-346): "
+                                      "needs OpenCV, not provided")
         if net is not None:
             state_dict = {}
         elif state_dict is None:
@@ -187,7 +188,7 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         depths = np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (B, 1))
         ch1 = np.stack(ch1)
         pred = self.estimator(torch.stack(img1), ch1, torch.stack(img2), np.stack(ch2), np.stack(P1), np.stack(P2), depths)
-        bbox, _, _ = postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], ch1, np.stack(K1), np.stack(E1), img_size=S)
+        bbox = self._bbox_tail(pred, ch1, np.stack(K1), np.stack(E1))
         out[np.asarray(rows)] = bbox.cpu().numpy()
         return out
 
@@ -226,9 +227,18 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             return P.to(torch.float32)
         depths = torch.from_numpy(np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (n, 1))).to(dev)
         pred = self.estimator(a["img"], a["choose"], b["img"], b["choose"], proj(a["Kcrop"], E1d), proj(b["Kcrop"], E2d), depths)
-        bbox, _, _ = postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], a["choose"], a["Kcrop"], E1d, img_size=S)
+        bbox = self._bbox_tail(pred, a["choose"], a["Kcrop"], E1d)
         ok = ((a["valid"] != 0) & (b["valid"] != 0)).view(n, 1, 1)
         return torch.where(ok, bbox, torch.from_numpy(DEFAULT_BBOX).to(dev).expand(n, 8, 3))
+
+    def _bbox_tail(self, pred, choose, Kcrop, E1):
+        """interface_v5.py:318-374: scale / translation from the regressed rotation (`direct_regression`, the shipped configs)
+        or Umeyama-RANSAC between predicted NOCS and the back-projected predicted depth (`use_depth`), then the world box."""
+        S = self.cfg["img_size"]
+        if self.cfg.get("direct_regression", True):
+            return postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], choose, Kcrop, E1, img_size=S)[0]
+        return postprocess_ransac(pred["view1_nocs"], pred["view1_depth"], choose, Kcrop, E1, img_size=S,
+                                  seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
 
     def predict(self, camera_intrinsic, rgb1, view1_mask, view1_extrinsic, rgb2, view2_mask, view2_extrinsic):
         return self.estimate([camera_intrinsic], [rgb1], [view1_mask], [view1_extrinsic], [rgb2], [view2_mask],

@@ -343,3 +343,22 @@ class ReplayVecEnv:
     def reset(self, indices=None):
         self.resets += 1
         return None
+
+
+# --------------------------------------------------------------------------- similarity alignment cases
+def align_case(case: int, P: int = 1024):
+    """Seeded (nocs, camera points) pair for the Umeyama-RANSAC tests: points = s R nocs + t + noise, a fraction of outliers.
+    case 3 is pure noise (the reference returns None), case 4 has mirrored points so the SVD's reflection fix is taken."""
+    rng = np.random.default_rng(4200 + case)
+    nocs = rng.uniform(-0.5, 0.5, (P, 3)).astype(np.float32) * np.array([0.9, 0.5, 0.3], dtype=np.float32)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    s, t = rng.uniform(0.15, 0.5), rng.uniform(-0.3, 0.3, 3) + np.array([0, 0, 0.9])
+    pts = s * nocs.astype(np.float64) @ q.T + t + rng.normal(0, 0.002, (P, 3))
+    out_frac = [0.0, 0.2, 0.45, 1.0, 0.1][case % 5]
+    bad = rng.random(P) < out_frac
+    pts[bad] = rng.uniform(-0.5, 0.5, (int(bad.sum()), 3)) + np.array([0, 0, 0.9])
+    if case % 5 == 4:
+        pts[:, 0] = -pts[:, 0]
+    return nocs, pts

@@ -228,3 +228,26 @@ def test_ppo_trains_on_device_control_interface():
     assert torch.isfinite(ppo.actor_critic.flat).all()
     assert not torch.equal(before, ppo.actor_critic.flat)
     assert env.episode.min() >= 3                                   # 16 transitions = 4 episodes of 4 steps
+
+
+def test_rl_manipulation_wrapper_learns_and_plays():
+    """models/manipulation/rl.py: RLManipulation(vec_env, cfg, logger).learn / plan_pathway over the device controller env."""
+    import copy
+    from test_gpu_ppo import CFG
+    from rgbmanip_amd import synthetic_env as se
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.control_interface import ControlInterface
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+    from rgbmanip_amd.manipulation import RLManipulation
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device")
+    est = AdaPoseEstimator_v5(None, cfg, None, state_dict=synth.adapose_state_dict(seed=0, prefix="module."), dtype="bf16")
+    env = se.SyntheticMultiVecEnv(4, "cuda", seed=2)
+    ci = ControlInterface(env, est, se.SyntheticManipulation(env), synth.control_cfg("cabinet"))
+    pcfg = copy.deepcopy(CFG)
+    pcfg["learn"].update(num_transitions_per_env=4, num_transitions_eval=3, num_learning_epochs=1)
+    man = RLManipulation(ci, pcfg, None)
+    man.learn(1, log_interval=1, save_interval=10 ** 9)
+    steps_before = env.episode.copy()
+    man.plan_pathway(None, eval=True)
+    assert torch.isfinite(man.agent.actor_critic.flat).all()
+    assert (env.episode > steps_before).all()                      # play() resets and steps the env

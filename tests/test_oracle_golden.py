@@ -203,3 +203,32 @@ def test_synth_camera_ref_is_geometrically_consistent():
     np.testing.assert_allclose(R @ np.transpose(R, (0, 2, 1)), np.tile(np.eye(3), (N, 1, 1)), atol=1e-12)
     centre = robots[:, :3] + cam[:, :3]
     np.testing.assert_allclose(np.einsum("nij,nj->ni", R, centre) + E[:, :3, 3], 0, atol=1e-12)
+
+
+def test_align_oracle_matches_reference_golden(golden_dir):
+    """oracle/align_ref.py (Umeyama + 128-iteration RANSAC + bbox tail) against lib/align.py::estimateSimilarityTransform itself,
+    run by tools/make_goldens.py under the same np.random seeds: identical sample stream -> identical results, including the
+    pure-noise case where the reference returns None and the mirrored case that takes the SVD reflection fix."""
+    import numpy as np
+    from oracle import align_ref as ar
+    g = np.load(os.path.join(golden_dir, "align.npz"))
+    for case in range(5):
+        nocs, pts = synth.align_case(case)
+        np.random.seed(100 + case)
+        s, R, t, _ = ar.similarity_ransac(nocs, pts)
+        assert (s is not None) == bool(g[f"c{case}_ok"])
+        if s is None:
+            assert case == 3
+            np.testing.assert_array_equal(ar.bbox_from_srt(nocs, None, None, None, np.eye(4)), ar.DEFAULT_BBOX)
+            continue
+        np.testing.assert_allclose(s, g[f"c{case}_s"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(R, g[f"c{case}_R"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(t, g[f"c{case}_t"], rtol=0, atol=1e-15)
+        assert abs(np.linalg.det(R) - 1.0) < 1e-12
+        np.testing.assert_allclose(ar.bbox_from_srt(nocs, s, R, t, np.eye(4)).T, g[f"c{case}_bbox_cam"], rtol=0, atol=1e-15)
+    # the reproducible sampler of the device kernel finds the same model on the clean cases
+    for case in (0, 1, 2):
+        nocs, pts = synth.align_case(case)
+        s, R, t, _ = ar.similarity_ransac(nocs, pts, ar.hash_sampler(3, case))
+        np.testing.assert_allclose(s, g[f"c{case}_s"], rtol=1e-3)
+        np.testing.assert_allclose(R, g[f"c{case}_R"], atol=5e-3)

@@ -445,12 +445,38 @@ def gen_control_step(out_dir):
         os.chdir(cwd)
 
 
+def gen_align(out_dir):
+    """lib/align.py::estimateSimilarityTransform (the reference function itself, global np.random seeded per case) on the
+    seeded cases of rgbmanip_amd.synth.align_case, plus the bbox tail of interface_v5.py:348-374 built from the reference's
+    get_3d_bbox / transform_coordinates_3d."""
+    from rgbmanip_amd import synth
+    from models.pose_estimator.AdaPose.lib.align import estimateSimilarityTransform
+    from models.pose_estimator.AdaPose.lib.utils import get_3d_bbox, transform_coordinates_3d
+    save = {}
+    for case in range(5):
+        nocs, pts = synth.align_case(case)
+        np.random.seed(100 + case)
+        ts, tr, tt, T = estimateSimilarityTransform(nocs, pts)
+        save[f"c{case}_ok"] = np.array(ts is not None)
+        if ts is None:
+            continue
+        save[f"c{case}_s"], save[f"c{case}_R"], save[f"c{case}_t"] = np.array(ts), tr, tt
+        size = 2 * np.max(abs(nocs), axis=0) * ts
+        bbox = get_3d_bbox(size)
+        sRT = np.eye(4).astype(np.float32)
+        sRT[:3, :3] = tr
+        sRT[:3, 3] = tt.flatten()
+        save[f"c{case}_bbox_cam"] = transform_coordinates_3d(bbox, sRT)
+    np.savez_compressed(os.path.join(out_dir, "align.npz"), **save)
+    print("align golden:", {k: np.asarray(v).shape for k, v in save.items()})
+
+
 if __name__ == "__main__":
     install_stubs()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control", "control_step"]
+    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control", "control_step", "align"]
     net_out = inp = None
     if "adapose" in which or "postproc" in which:
         net_out, inp = gen_adapose(out_dir)
@@ -462,4 +488,6 @@ if __name__ == "__main__":
         gen_control(out_dir)
     if "control_step" in which:
         gen_control_step(out_dir)
+    if "align" in which:
+        gen_align(out_dir)
     print("done")
