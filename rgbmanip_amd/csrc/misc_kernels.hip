@@ -105,6 +105,12 @@ __device__ __forceinline__ Lerp lerp_ac(int dst, int in_size, float scale) {
   return l;
 }
 
+// the one interpolation expression of both kernels, with its multiply-adds pinned (no compiler-chosen contraction)
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, const Lerp& lx, const Lerp& ly) {
+  const float top = fmaf(lx.w0, a, lx.w1 * b), bot = fmaf(lx.w0, c, lx.w1 * d);
+  return fmaf(ly.w0, top, ly.w1 * bot);
+}
+
 template <typename T>
 __global__ void resize_bilinear_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int Hs, int Ws, int C,
                                           int Ho, int Wo, int ldo, int ch_off, float sy, float sx) {
@@ -126,8 +132,85 @@ __global__ void resize_bilinear_ac_kernel(const T* __restrict__ in, T* __restric
     unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lx.i1) * C), dd, T());
 #pragma unroll
     for (int e = 0; e < E; ++e)
-      r[e] = ly.w0 * (lx.w0 * a[e] + lx.w1 * b[e]) + ly.w1 * (lx.w0 * c[e] + lx.w1 * dd[e]);
+      r[e] = bilerp(a[e], b[e], c[e], dd[e], lx, ly);
     *reinterpret_cast<uint4*>(out + ((v * Ho + ho) * Wo + wo) * ldo + ch_off + cc * E) = pack_chunk(r, T());
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void st_nt(T* p, const uint4& v) {          // streaming store: the output is far larger than L2 + MALL
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(p));
+}
+
+// Exact x2 case (PSPUpsample, pspnet.py:100-107): one thread produces the 2 x 2 output block of input pixel (i, j).  In the
+// interior the four outputs tap rows {i-1,i | i,i+1} and columns {j-1,j | j,j+1}: 9 chunk loads per 4 outputs instead of 16
+// (the generic kernel is bound by L2 -> CU traffic, 4 x the output bytes; this one moves 2.25 x).  Threads whose taps differ
+// (first row / column, float rounding at the last) take the generic 4-loads-per-output path.  Same weights and the same
+// fused-multiply-add sequence (bilerp) as the generic kernel: identical results.
+template <typename T>
+__global__ __launch_bounds__(256) void resize2x_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int Hs, int Ws, int C,
+                                                            int ldo, int ch_off, float sy, float sx) {
+  constexpr int E = 16 / sizeof(T);
+  const int cpp = C / E, Ho = 2 * Hs, Wo = 2 * Ws;
+  const long long total = (long long)V * Hs * Ws * cpp;
+  // consecutive workgroup ids land on different XCDs (8, each with its own L2): give every XCD one contiguous eighth of the
+  // 256-thread chunks, so that the image rows neighbouring chunks share are fetched into one L2 instead of up to three
+  const long long nchunk = (total + 255) / 256, per_xcd = (nchunk + 7) / 8;
+  for (long long q = blockIdx.x; q < per_xcd * 8; q += gridDim.x) {
+    const long long chunk = (q & 7) * per_xcd + (q >> 3);
+    const long long idx = chunk * 256 + threadIdx.x;
+    if (chunk >= nchunk || idx >= total) continue;
+    // 32-bit index arithmetic (the launcher checks total < 2^31): 64-bit divisions by run-time values cost ~100 instructions each
+    const unsigned u = (unsigned)idx;
+    const unsigned pix = u / (unsigned)cpp;
+    const int cc = (int)(u - pix * (unsigned)cpp);
+    const unsigned row = pix / (unsigned)Ws;
+    const int j = (int)(pix - row * (unsigned)Ws);
+    const unsigned vv = row / (unsigned)Hs;
+    const int i = (int)(row - vv * (unsigned)Hs);
+    const long long v = vv;
+    const T* base = in + v * Hs * Ws * C + cc * E;
+    T* obase = out + (v * Ho * Wo) * ldo + ch_off + cc * E;
+    const Lerp ly0 = lerp_ac(2 * i, Hs, sy), ly1 = lerp_ac(2 * i + 1, Hs, sy);
+    const Lerp lx0 = lerp_ac(2 * j, Ws, sx), lx1 = lerp_ac(2 * j + 1, Ws, sx);
+    const bool fast = ly0.i0 == i - 1 && ly0.i1 == i && ly1.i0 == i && ly1.i1 == i + 1 &&
+                      lx0.i0 == j - 1 && lx0.i1 == j && lx1.i0 == j && lx1.i1 == j + 1;
+    if (fast) {
+      float p[3][3][E];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)(i - 1 + a) * Ws + (j - 1 + b)) * C), p[a][b], T());
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const Lerp ly = dy ? ly1 : ly0;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const Lerp lx = dx ? lx1 : lx0;
+          float r[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) r[e] = bilerp(p[dy][dx][e], p[dy][dx + 1][e], p[dy + 1][dx][e], p[dy + 1][dx + 1][e], lx, ly);
+          st_nt(obase + ((long long)(2 * i + dy) * Wo + 2 * j + dx) * ldo, pack_chunk(r, T()));
+        }
+      }
+    } else {
+      for (int dy = 0; dy < 2; ++dy) {
+        const Lerp ly = dy ? ly1 : ly0;
+        for (int dx = 0; dx < 2; ++dx) {
+          const Lerp lx = dx ? lx1 : lx0;
+          float a[E], b[E], c[E], dd[E], r[E];
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lx.i0) * C), a, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lx.i1) * C), b, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lx.i0) * C), c, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lx.i1) * C), dd, T());
+#pragma unroll
+          for (int e = 0; e < E; ++e) r[e] = bilerp(a[e], b[e], c[e], dd[e], lx, ly);
+          st_nt(obase + ((long long)(2 * i + dy) * Wo + 2 * j + dx) * ldo, pack_chunk(r, T()));
+        }
+      }
+    }
   }
 }
 
@@ -137,6 +220,17 @@ int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int H
   RGBM_REQUIRE(C % E == 0 && ldo % E == 0 && ch_off % E == 0, "resize channel alignment");
   const float sy = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
   const float sx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+  if (Ho == 2 * Hs && Wo == 2 * Ws && Hs >= 2 && Ws >= 2 && (long long)V * Hs * Ws * (C / E) < (1ll << 31) && !(g_debug_flags & 512)) {
+    const long long blocks = (long long)V * Hs * Ws * (C / E);
+    if (dtype == BF16)
+      hipLaunchKernelGGL(resize2x_ac_kernel<unsigned short>, dim3(grid_for(blocks)), dim3(256), 0, s, (const unsigned short*)in,
+                         (unsigned short*)out, V, Hs, Ws, C, ldo, ch_off, sy, sx);
+    else
+      hipLaunchKernelGGL(resize2x_ac_kernel<float>, dim3(grid_for(blocks)), dim3(256), 0, s, (const float*)in, (float*)out, V, Hs,
+                         Ws, C, ldo, ch_off, sy, sx);
+    RGBM_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const long long total = (long long)V * Ho * Wo * (C / E);
   if (dtype == BF16)
     hipLaunchKernelGGL(resize_bilinear_ac_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s,

@@ -373,3 +373,26 @@ def test_conv0_sweep_matches_volume_then_conv(shape):
     assert torch.isnan(y2[1]).any() and torch.isnan(y2[3]).any()
     nan_ref = torch.isnan(ref2)
     assert torch.equal(torch.isnan(y2), nan_ref)
+
+
+@pytest.mark.parametrize("dtype", [_lib.F32, _lib.BF16])
+@pytest.mark.parametrize("shape", [(3, 28, 28, 64), (2, 7, 5, 128), (1, 2, 2, 8)])
+def test_resize_x2_kernel_identical_to_generic(dtype, shape):
+    """The 2x2-block upsample kernel (9 loads per 4 outputs) against the generic bilinear kernel (debug flag 512): bit-identical."""
+    from gpu_util import TORCH_DT
+    lib = _lib.load()
+    V, H, W, Cn = shape
+    if dtype == _lib.F32 and Cn % 4:
+        pytest.skip("channel alignment")
+    x = torch.randn(V, H, W, Cn, generator=torch.Generator().manual_seed(5)).to("cuda", TORCH_DT[dtype]).contiguous()
+    outs = []
+    for flag in (0, 512):
+        _lib.check(lib.rgbm_debug_flags(flag))
+        o = torch.zeros(V, 2 * H, 2 * W, Cn, dtype=TORCH_DT[dtype], device="cuda")
+        _lib.check(lib.rgbm_resize_bilinear_ac(dtype, _lib.ptr(x), _lib.ptr(o), V, H, W, Cn, 2 * H, 2 * W, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(o)
+    _lib.check(lib.rgbm_debug_flags(0))
+    assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8))
+    ref = F.interpolate(x.float().cpu().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert (outs[0].float().cpu() - ref).abs().max() < (1e-5 if dtype == _lib.F32 else 4e-2)
