@@ -55,6 +55,8 @@ template <> struct MmaG<float> {
   }
 };
 
+template <int N> struct IC { static constexpr int value = N; };
+
 __device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
   if (act == ACT_RELU) return v < 0.f ? 0.f : v;          // NaN propagates like torch
   if (act == ACT_PRELU) return v < 0.f ? v * slope : v;
@@ -541,6 +543,15 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     ch_tile = lid - pix_tile * d.n_ch_tiles;
   };
 
+  // Per-channel bias table in LDS behind the ring (launch_ws reserves it): the multiply waves must not wait on vmcnt for
+  // anything they do not need — on gfx9 the counter also covers their own output stores, in order, so a global bias read
+  // after a tile's stores costs a full store round trip (measured: 5 us per tile).
+  float* lbias = reinterpret_cast<float*>(lds3 + 3 * STAGE);
+  const bool bias_lds = d.bias != nullptr && d.bias_stride == 0 && d.Cout <= 2048;
+  if (bias_lds)
+    for (int i = tid; i < d.Cout; i += 768) lbias[i] = d.bias[i];
+  __syncthreads();
+
   if (wave >= 8) {
     // ------------------------------------------------------------------ request waves
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
@@ -659,11 +670,31 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
   int st = 0;
+  auto tile_interior = [&](int pix_tile, int ch_tile) {
+    return (d.bias == nullptr || bias_lds) && (long long)(pix_tile + 1) * BPIX <= d.M && (ch_tile + 1) * BCH <= d.Cout &&
+           d.act != ACT_TANH && !(IG_ABL & 32);
+  };
   for (int k = 0; k < n_my; ++k) {
+    {
+      // interior tile with a per-channel bias (or none): the accumulators start at the bias, and the epilogue below is the
+      // straight-line one.  (Tile coordinates are recomputed in the epilogue: nothing of this block lives across the K loop.)
+      int pt, ct;
+      tile_of(k, pt, ct);
+      if (tile_interior(pt, ct) && d.bias) {
+        const float* bp = lbias + ct * BCH + wch + lg * 16;
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
+        for (int a = 0; a < FM; ++a) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + a * 4);
 #pragma unroll
-      for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int b = 0; b < FN; ++b) acc[a][b] = b4;
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     for (int kt = 0; kt < KT; ++kt) {
       // every fragment read of the previous step has returned before the request waves may refill its stage
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -697,6 +728,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
 #endif
     int pix_tile, ch_tile;
     tile_of(k, pix_tile, ch_tile);
+    const bool interior = tile_interior(pix_tile, ch_tile);
     long long obase[FN];
     int nn[FN];
     bool pok[FN];
@@ -715,9 +747,71 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     const int chL = ch_tile * BCH + wch + lg * 16;
     constexpr int CHK = 16 / (int)sizeof(T);             // channels per 16-byte chunk
     constexpr int NQ = 16 / CHK;                         // chunks per lane and pixel
+    // Interior tiles with a per-channel bias take a straight-line epilogue specialised on (activation, residual mode):
+    // the generic loop below tests pixel / channel bounds, bias, residual mode and activation per 16-byte chunk and
+    // reloads the bias in front of every chunk (behind the previous chunk's store, which may alias it) — ~1000
+    // instructions, ~100 branches and 8 dependent bias round trips per wave and tile, measured as 9 us per tile with
+    // the matrix pipe idle.
+    if (interior) {
+      const float slope = d.slope;
+      auto fast = [&](auto actc, auto resc) {
+        constexpr int ACT = decltype(actc)::value, RES = decltype(resc)::value;
+        // residual reads of the whole tile are requested before the first store (see the vmcnt note above); with 32-bit
+        // elements that would be 64 registers, so those go in two halves
+        constexpr int GRP = sizeof(T) == 2 ? FN : 2;
+#pragma unroll
+        for (int bh = 0; bh < FN; bh += GRP) {
+          uint4 rr[NQ][GRP];
+          if (RES != RES_NONE) {
+#pragma unroll
+            for (int bb = 0; bb < GRP; ++bb)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+                rr[q][bb] = (IG_ABL & 128) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(res + obase[bh + bb] + chL + q * CHK);
+          }
+#pragma unroll
+          for (int bb = 0; bb < GRP; ++bb) {
+            const int b = bh + bb;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              float v[CHK], rv[CHK];
+#pragma unroll
+              for (int e = 0; e < CHK; ++e) v[e] = acc[(q * CHK + e) >> 2][b][(q * CHK + e) & 3];
+              if (RES != RES_NONE) unpack_chunk(rr[q][bb], rv, T());
+              if (RES == RES_PRE_ACT) {
+#pragma unroll
+                for (int e = 0; e < CHK; ++e) v[e] += rv[e];
+              }
+#pragma unroll
+              for (int e = 0; e < CHK; ++e)
+                v[e] = ACT == ACT_RELU ? (v[e] < 0.f ? 0.f : v[e]) : ACT == ACT_PRELU ? (v[e] < 0.f ? v[e] * slope : v[e]) : v[e];
+              if (RES == RES_POST_ACT) {
+#pragma unroll
+                for (int e = 0; e < CHK; ++e) v[e] += rv[e];
+              }
+              const uint4 pk = pack_chunk(v, T());
+              if (!(IG_ABL & 64) || pk.x == 0x12345678u) *reinterpret_cast<uint4*>(out + obase[b] + chL + q * CHK) = pk;
+            }
+          }
+        }
+      };
+      auto by_res = [&](auto actc) {
+        if (d.res_mode == RES_NONE) fast(actc, IC<RES_NONE>{});
+        else if (d.res_mode == RES_PRE_ACT) fast(actc, IC<RES_PRE_ACT>{});
+        else fast(actc, IC<RES_POST_ACT>{});
+      };
+      if (d.act == ACT_RELU) by_res(IC<ACT_RELU>{});
+      else if (d.act == ACT_PRELU) by_res(IC<ACT_PRELU>{});
+      else by_res(IC<ACT_NONE>{});
+      continue;
+    }
 #pragma unroll
     for (int bh = 0; bh < FN; bh += 2) {                 // two pixel fragments (2*NQ residual reads in flight) at a time
       uint4 rr[NQ][2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rr[q][bb] = make_uint4(0u, 0u, 0u, 0u);      // defined on every path: no value carried around the tile loop
       if (d.res_mode != RES_NONE) {
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
@@ -779,7 +873,7 @@ static void make_fastdiv(int dvs, unsigned& m, int& sh) {
 template <typename T>
 static int launch_ws(ConvDesc d, hipStream_t s) {
   constexpr int BCH = 128, BPIX = 256;
-  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4);
+  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4) + 2048 * sizeof(float);      // K-tile ring + per-channel bias table
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long ntiles = (long long)d.n_pix_tiles * d.n_ch_tiles;
