@@ -947,6 +947,12 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
   const int NCC = d.Cin >> 6;                // RH: 64-channel input chunks
   const int KT = RH ? 3 * NCC : d.KT;        // K steps per tile
   if (RH && tid < 8) lds3[NST * STAGE + tid] = make_uint4(0u, 0u, 0u, 0u);      // visible after the first barrier
+  // per-channel bias (zeros if there is none) as an LDS table behind the staging tile: the accumulators start from it, so the
+  // multiply waves issue no global load — and wait on no vmcnt — anywhere (see conv_igemm_ws_kernel)
+  float* lbias = reinterpret_cast<float*>(stg + BPIX * SROW);
+  const bool bias_lds = d.bias == nullptr || d.bias_stride == 0;
+  if (tid < BCH) lbias[tid] = (d.bias && bias_lds && tid < d.Cout) ? d.bias[tid] : 0.f;
+  __syncthreads();
   const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = n_my * KT;               // every wave passes total + 1 barriers
   auto tile_of = [&](int k) {
@@ -1223,9 +1229,11 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
   int st = 0;
   for (int k = 0; k < n_my; ++k) {
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
+    for (int a = 0; a < FM; ++a) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + a * 16 + lg * 4);      // zeros unless bias_lds with a bias
 #pragma unroll
-      for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < FN; ++b) acc[a][b] = b4;
+    }
     if constexpr (RH) {
       // per tile: which lanes lose their left / right neighbour to the image edge (they read the zero row instead)
       const int dil = d.dilw;
@@ -1287,6 +1295,31 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     mma_half(af1, bf1);
     }
     // ---- bias + activation + bf16 pack into the staging tile (the store waves have drained the previous one) ----
+    if (bias_lds && d.act != ACT_TANH) {
+      // the bias is already in the accumulators; activation fixed at compile time per variant: straight-line code
+      const float slope = d.slope;
+      auto pack_tile = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+          const int row = wpix + b * 16 + lr;
+#pragma unroll
+          for (int a = 0; a < FM; ++a) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[a][b][e];
+              v[e] = ACT == ACT_RELU ? (x < 0.f ? 0.f : x) : ACT == ACT_PRELU ? (x < 0.f ? x * slope : x) : x;
+            }
+            *reinterpret_cast<uint2*>(stg + row * SROW + (a * 16 + lg * 4) * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+          }
+        }
+      };
+      if (d.act == ACT_RELU) pack_tile(IC<ACT_RELU>{});
+      else if (d.act == ACT_PRELU) pack_tile(IC<ACT_PRELU>{});
+      else pack_tile(IC<ACT_NONE>{});
+      continue;
+    }
     const int pix_tile = tile_of(k);
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
@@ -1302,7 +1335,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
       for (int a = 0; a < FM; ++a) {
         const int ch = a * 16 + lg * 4;
         float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-        if (d.bias && ch < d.Cout) {
+        if (d.bias && !bias_lds && ch < d.Cout) {
           const float* bp = d.bias + (long long)n * d.bias_stride + ch;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bp[e];
@@ -1327,8 +1360,8 @@ static bool conv_rowhalo_ok(const ConvDesc& d) {
 static int launch_ws64(ConvDesc d, hipStream_t s) {
   constexpr int BCH = 64, BPIX = 256;
   const bool rh = conv_rowhalo_ok(d);
-  const size_t LDS = rh ? 2 * (size_t)(3 * BCH + 264) * 8 * sizeof(uint4) + 128 + (size_t)BPIX * 144
-                        : 3 * (size_t)(BCH + BPIX) * 8 * sizeof(uint4) + (size_t)BPIX * 144;
+  const size_t LDS = (rh ? 2 * (size_t)(3 * BCH + 264) * 8 * sizeof(uint4) + 128 + (size_t)BPIX * 144
+                         : 3 * (size_t)(BCH + BPIX) * 8 * sizeof(uint4) + (size_t)BPIX * 144) + BCH * sizeof(float);   // + bias table
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = 1;
   d.n_tiles = d.n_pix_tiles;
