@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
 
+  float bv[FM][4];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[a][e] = (a * 16 + lg * 4 < d.Cout) ? d.bias[a * 16 + lg * 4 + e] : 0.f;
+
   auto run_pass = [&](auto pc) {
     constexpr int PASS = decltype(pc)::value;
     constexpr int KH = Cfg::kh_of(PASS), KW = Cfg::kw_of(PASS);
@@ -264,17 +270,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
       }
     }
     // ---- epilogue: bias (folded BN), ReLU, post-activation skip add, 4-channel vector store ----
+    // All skip reads of the pass are requested before its first store, and the bias sits in registers (bv, loaded once per
+    // kernel): on gfx9 a load issued after a store waits, through the shared in-order vmcnt, for that store's round trip.
     constexpr int pd = TR ? (PASS >> 2) & 1 : 0, ph = TR ? (PASS >> 1) & 1 : 0, pw = TR ? PASS & 1 : 0;
     constexpr int OS = TR ? 2 : 1;
+    long long opix[NF];
+    bool fok[NF];
+    float rv[NF][FM][4];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      if (qd_[f] >= d.Dq || qh_[f] >= d.Hq || qw_[f] >= d.Wq) continue;
+      fok[f] = !(qd_[f] >= d.Dq || qh_[f] >= d.Hq || qw_[f] >= d.Wq);
       // class-major output (transposed convs whose consumer gathers sparsely): the 8 sub-pixel classes become 8 dense
       // volumes, so a fragment row is one full 128-byte line instead of eight 16-byte pieces of eight lines
-      const long long opix = (TR && d.out_classmajor)
-          ? ((((long long)PASS * d.N + n) * d.Dq + qd_[f]) * d.Hq + qh_[f]) * d.Wq + qw_[f]
-          : (((long long)n * d.Do + (qd_[f] * OS + pd)) * d.Ho + (qh_[f] * OS + ph)) * d.Wo + (qw_[f] * OS + pw);
       const long long rpix = (((long long)n * d.Do + (qd_[f] * OS + pd)) * d.Ho + (qh_[f] * OS + ph)) * d.Wo + (qw_[f] * OS + pw);
+      opix[f] = (TR && d.out_classmajor) ? ((((long long)PASS * d.N + n) * d.Dq + qd_[f]) * d.Hq + qh_[f]) * d.Wq + qw_[f] : rpix;
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        const int ch = a * 16 + lg * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[f][a][e] = 0.f;
+        if (res && fok[f] && ch < d.Cout) load4(res + rpix * d.Cout + ch, rv[f][a]);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (!fok[f]) continue;
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
         const int ch = a * 16 + lg * 4;
@@ -282,17 +302,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
         float v[4] = {acc[a][f][0], acc[a][f][1], acc[a][f][2], acc[a][f][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] += d.bias[ch + e];
+          v[e] += bv[a][e];
           if (d.relu) v[e] = v[e] < 0.f ? 0.f : v[e];      // NaN propagates, like torch.relu
+          v[e] += rv[f][a][e];
         }
-        const long long o = opix * d.Cout + ch;
-        if (res) {
-          float rv[4];
-          load4(res + rpix * d.Cout + ch, rv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rv[e];
-        }
-        store4(out + o, v);
+        store4(out + opix[f] * d.Cout + ch, v);
       }
     }
   };
