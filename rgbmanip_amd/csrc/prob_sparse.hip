@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
   const int pix = active ? d.choose[o] : 0;
   const int y = pix / W, x = pix - y * W;
   float* Uw = U[wave];
-  for (int i = lane; i < D * 72; i += 64) Uw[i] = 0.f;                  // neighbours outside the image / volume: zero padding
+  for (int i = lane * 4; i < D * 72; i += 256)                          // neighbours outside the image / volume: zero padding
+    *reinterpret_cast<f32x4*>(Uw + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   const uint4* wq = reinterpret_cast<const uint4*>(d.w11);
@@ -98,14 +99,14 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
         const bool pad = hi ? (t1 >= NT) : false;
         const int iz = qd + td, iy = qh + th, ix = qw + tw;
         const bool inb = valid && !pad && iz < Dq && iy < Hq && ix < Wq;  // beyond the input grid: the conv's zero halo
-        const long long off = inb ? ((((long long)iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8) : 0ll;
+        const int off = inb ? (((iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8) : 0;       // per-view offsets fit 32 bits (launcher checks)
         const uint4 t = *reinterpret_cast<const uint4*>(u9v + off);
         bv[s] = inb ? t : make_uint4(0u, 0u, 0u, 0u);
       }
       const bool wr = valid && lg < 2;
       const int ch = (lg & 1) * 4;
       float cv[4];
-      load4(c0v + (wr ? ((((long long)oz * H + yy) * W + xx) * 8 + ch) : 0ll), cv);
+      load4(c0v + (wr ? (((oz * H + yy) * W + xx) * 8 + ch) : 0), cv);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc = mma16(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
@@ -126,21 +127,26 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
   __syncthreads();
 
   // ---- prob conv at the D depths of this pixel (lane = depth), then softmax and depth regression across the wave ----
+  // lanes 0..D-1 take the first half of every tap plane's 72 values, lanes 32..32+D-1 the second half; one shuffle adds them
   float logit = -INFINITY;
-  if (lane < D) {
+  {
+    const int dz = lane & 31, half = lane >> 5;
     float acc = 0.f;
-    for (int kd = 0; kd < 3; ++kd) {
-      const int zz = lane + kd - 1;
-      if ((unsigned)zz >= (unsigned)D) continue;
-      const float* up = Uw + zz * 72;
-      const float* ww = wp + kd * 72;
+    if (dz < D) {
+      for (int kd = 0; kd < 3; ++kd) {
+        const int zz = dz + kd - 1;
+        if ((unsigned)zz >= (unsigned)D) continue;
+        const float* up = Uw + zz * 72 + half * 36;
+        const float* ww = wp + kd * 72 + half * 36;
 #pragma unroll
-      for (int i = 0; i < 72; i += 4) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(up + i);
-        acc += u[0] * ww[i] + u[1] * ww[i + 1] + u[2] * ww[i + 2] + u[3] * ww[i + 3];
+        for (int i = 0; i < 36; i += 4) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(up + i);
+          acc += u[0] * ww[i] + u[1] * ww[i + 1] + u[2] * ww[i + 2] + u[3] * ww[i + 3];
+        }
       }
     }
-    logit = acc;
+    acc += __shfl_xor(acc, 32);
+    if (lane < D) logit = acc;
   }
   float m = logit;
 #pragma unroll
@@ -169,6 +175,7 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
                        int D, int H, int W, hipStream_t s) {
   RGBM_REQUIRE(u9 && c0 && w11_packed && bias11 && wprob && choose && depths && prob && depth_out, "prob_sparse arguments");
   RGBM_REQUIRE(D <= PS_DMAX && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0, "prob_sparse supports even D <= 24 and even H, W");
+  RGBM_REQUIRE((long long)D * H * W * 8 < (1ll << 31), "prob_sparse view too large for 32-bit offsets");
   ProbSparseDesc d;
   d.u9 = reinterpret_cast<const unsigned short*>(u9);
   d.c0 = reinterpret_cast<const unsigned short*>(c0);
