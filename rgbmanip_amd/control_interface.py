@@ -303,3 +303,38 @@ class ControlInterface:
         self.reset_queue()
         self.reset_robot()
         return self.get_observation()
+
+
+class RLPoseController:
+    """`RLPoseController` (`models/controller/rl_pose.py:464-516`): the control interface plus its PPO agent.
+
+    `train_controller` runs PPO over `ControlInterface.step`; `run` rolls the trained policy out deterministically
+    (`act_inference`) until the episode ends or `controller.early_stop` steps, then hands the last estimate to
+    `call_manipulation`."""
+
+    def __init__(self, vec_env, pose_estimator, manipulation, cfg: dict, logger=None, process_group=None):
+        from .ppo import PPO
+        self.env, self.estimator, self.manipulation, self.cfg, self.logger = vec_env, pose_estimator, manipulation, cfg, logger
+        self.control_interface = ControlInterface(vec_env, pose_estimator, manipulation, cfg)
+        self.controller = PPO(self.control_interface, cfg, process_group=process_group)
+
+    def train_controller(self, steps, log_interval=1, save_interval=1):
+        if self.logger is not None:
+            self.logger.info("Training controller model...")
+        self.controller.run(steps, log_interval, save_interval)
+
+    def run(self, eval=False):
+        from .ppo import prepare_obs
+        ci = self.control_interface
+        current_obs = prepare_obs(ci.reset(reset_env=False))[0].to(self.controller.device)
+        cur_step, max_step = 0, self.cfg["controller"]["early_stop"]
+        while True:
+            cur_step += 1
+            actions = self.controller.actor_critic.act_inference(current_obs)
+            next_obs, rews, dones, infos = ci.step(actions, eval=True)
+            current_obs = prepare_obs(next_obs)[0].to(self.controller.device)
+            if bool(dones.any()) or cur_step >= max_step:
+                break
+        estimation = ci.pred_bbox[cur_step]
+        ci.call_manipulation(estimation, eval)
+        return estimation

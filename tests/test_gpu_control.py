@@ -251,3 +251,31 @@ def test_rl_manipulation_wrapper_learns_and_plays():
     man.plan_pathway(None, eval=True)
     assert torch.isfinite(man.agent.actor_critic.flat).all()
     assert (env.episode > steps_before).all()                      # play() resets and steps the env
+
+
+def test_rl_pose_controller_train_and_run():
+    """rl_pose.py:464-516: RLPoseController.train_controller (PPO over the device ControlInterface) and run (deterministic
+    roll-out to the end of the episode, last estimate handed to the manipulation planner)."""
+    import copy
+    from test_gpu_ppo import CFG
+    from rgbmanip_amd import synthetic_env as se
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.control_interface import RLPoseController
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+    ecfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device")
+    est = AdaPoseEstimator_v5(None, ecfg, None, state_dict=synth.adapose_state_dict(seed=0, prefix="module."), dtype="bf16")
+    env = se.SyntheticMultiVecEnv(4, "cuda", seed=5)
+    calls = []
+
+    class Plan:
+        def plan_pathway(self, center, direction, eval):
+            calls.append((center.cpu().numpy(), direction.cpu().numpy(), eval))
+    cfg = copy.deepcopy(CFG)
+    cfg["learn"].update(num_transitions_per_env=4, num_learning_epochs=1)
+    cfg.update(synth.control_cfg("cabinet"))
+    ctl = RLPoseController(env, est, Plan(), cfg, None)
+    ctl.train_controller(1, log_interval=1, save_interval=10 ** 9)
+    est_box = ctl.run(eval=True)
+    assert est_box.shape == (4, 8, 3) and len(calls) == 1 and calls[0][2] is True
+    assert np.isfinite(calls[0][0]).all() and np.isfinite(calls[0][1]).all()
+    assert ctl.control_interface.accumulate_steps == ctl.control_interface.max_steps          # ran to the end of the episode
