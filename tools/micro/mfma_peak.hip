@@ -4,14 +4,31 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_peak tools/micro/mfma_peak.hip ; run: ./mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+static int g_iters = 20000;          // argv[1]: iterations per timed launch (200000 = ~0.1 s per line: shows clock throttling)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// data pattern: 0 = every element 1.0 (few bits toggle: the matrix pipe draws little power), 1 = pseudo-random bf16 in (-2, 2)
+__device__ int g_random = 0;
+__device__ __forceinline__ uint4 fill_value(int i) {
+  if (!g_random) return make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  unsigned h = (unsigned)i * 2654435761u;
+  uint4 v;
+  unsigned* p = &v.x;
+  for (int k = 0; k < 4; ++k) {
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+    // two bf16 with exponent 0x3f (values in [1,2)) or 0x3e, random sign and mantissa
+    p[k] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+  }
+  return v;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(float* out, int iters) {
   __shared__ uint4 lds[6144];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 6144; i += blockDim.x) lds[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  for (int i = tid; i < 6144; i += blockDim.x) lds[i] = fill_value(i);
   __syncthreads();
   f32x4 acc[16];
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -43,7 +60,7 @@ __device__ __forceinline__ void lds_read16(u32x4& dst, unsigned addr) {
 __global__ __launch_bounds__(768) void k3(float* out, int iters, int barrier) {
   __shared__ uint4 lds[6144];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 6144; i += blockDim.x) lds[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  for (int i = tid; i < 6144; i += blockDim.x) lds[i] = fill_value(i);
   __syncthreads();
   f32x4 acc[16];
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -73,7 +90,7 @@ __global__ __launch_bounds__(768) void k3(float* out, int iters, int barrier) {
 
 void run3(int waves, int barrier, const char* name) {
   float* out; hipMalloc(&out, 256 * 1024 * 4);
-  const int iters = 20000;
+  const int iters = g_iters;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k3, dim3(256), dim3(64 * waves), 0, 0, out, 100, barrier);
   hipEventRecord(e0);
@@ -89,7 +106,7 @@ void run3(int waves, int barrier, const char* name) {
 template <int MODE>
 void run(int waves, const char* name) {
   float* out; hipMalloc(&out, 256 * 1024 * 4);
-  const int iters = 20000;
+  const int iters = g_iters;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(64 * waves), 0, 0, out, 100);
   hipEventRecord(e0);
@@ -102,11 +119,16 @@ void run(int waves, const char* name) {
   hipFree(out);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_iters = atoi(argv[1]);
+  for (int rnd = 0; rnd < 2; ++rnd) {
+  hipMemcpyToSymbol(HIP_SYMBOL(g_random), &rnd, sizeof(int));
+  printf("---- operand data: %s ----\n", rnd ? "pseudo-random bf16" : "all 1.0");
   for (int w : {4, 8, 12}) run<0>(w, "MFMA only");
   for (int w : {4, 8, 12}) run<1>(w, "MFMA + 16 ds_read_b128 / 32");
   for (int w : {4, 8, 12}) run<2>(w, "+ barrier per 32 MFMAs");
   for (int w : {4, 8, 12}) run3(w, 0, "asm reads, 1 wait per 16 MFMAs");
   for (int w : {4, 8, 12}) run3(w, 1, "asm reads, 1 wait, + barrier");
+  }
   return 0;
 }
