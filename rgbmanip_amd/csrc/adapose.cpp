@@ -326,9 +326,12 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
   last_f_index = xi;
   RGBM_REQUIRE(H == S / 8 && W == S / 8, "feature stride");
   if (int rc = launch_copy_channels(dtype, f, bf.cat, (long long)V * H * W, 512, 1024, 0, s)) return rc;
+  {
+    void* outs[4] = {bf.pooled[0], bf.pooled[1], bf.pooled[2], bf.pooled[3]};
+    if (int rc = launch_adaptive_avgpool_multi(dtype, f, outs, kPspBins, 4, V, H, W, 512, s)) return rc;     // all four bin sizes, one launch
+  }
   for (int i = 0; i < 4; ++i) {
     const int Sb = kPspBins[i];
-    if (int rc = launch_adaptive_avgpool(dtype, f, bf.pooled[i], V, H, W, 512, Sb, s)) return rc;
     if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, Sb, Sb, 128, nullptr, 0, nullptr, 0, s)) return rc;
     if (int rc = launch_resize_bilinear_ac(dtype, bf.stage[i], bf.cat, V, Sb, Sb, 128, H, W, 1024, 512 + 128 * i, s)) return rc;
   }

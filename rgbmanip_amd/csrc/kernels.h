@@ -13,6 +13,8 @@ int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int H
                               int ch_off, hipStream_t s);
 int launch_copy_channels(int dtype, const void* in, void* out, long long npix, int C, int ldo, int ch_off, hipStream_t s);
 int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s);
+int launch_adaptive_avgpool_multi(int dtype, const void* in, void* const* outs, const int* bins, int nb, int V, int H, int W, int C,
+                                  hipStream_t s);
 int launch_homography(const float* P_views, float* out, int V, int B, hipStream_t s);
 int launch_build_volume(int dtype, const void* feat, const float* homog, const float* depths, void* vol, int v0, int Vc, int V,
                         int B, int D, int H, int W, hipStream_t s);

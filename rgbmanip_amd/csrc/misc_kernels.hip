@@ -271,46 +271,86 @@ int launch_copy_channels(int dtype, const void* in, void* out, long long npix, i
 
 // ---------------------------------------------------------------- adaptive average pool (pspnet.py:83)
 // window of output cell i over an axis of length L with S bins: [floor(i*L/S), ceil((i+1)*L/S))
+// One launch pools every bin size of the pyramid (pspnet.py:83-94: bins 1, 2, 3, 6): block = (view, cell of one of the
+// grids), 8 pixel lanes x C/E channel chunks; the window's pixels are split over the pixel lanes and reduced through LDS.
+// (Four launches with one 64-thread block per cell walked up to 784 pixels serially: 0.17 ms each, 512 blocks for S = 1.)
+struct PoolBins { void* out[4]; int S[4]; int first[5]; int n; };      // first[i]: index of grid i's first cell, first[n] = total
+
 template <typename T>
-__global__ void adaptive_avgpool_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int H, int W, int C, int S) {
-  // grid: (V*S*S), block: C/E threads x up to 256; one thread = one 16-byte channel chunk
+__global__ __launch_bounds__(512) void adaptive_avgpool_kernel(const T* __restrict__ in, const PoolBins pb, int V, int H, int W, int C) {
   constexpr int E = 16 / sizeof(T);
-  const int cell = blockIdx.x % (S * S);
-  const long long v = blockIdx.x / (S * S);
+  constexpr int PL = 8;                                   // pixel lanes
+  __shared__ float red[PL][64][E];
+  const int ncell = pb.first[pb.n];
+  const int cell_all = blockIdx.x % ncell;
+  const long long v = blockIdx.x / ncell;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < pb.n && cell_all >= pb.first[i]) g = i;
+  const int S = pb.S[g], cell = cell_all - pb.first[g];
   const int sy = cell / S, sx = cell % S;
   const int h0 = (sy * H) / S, h1 = ((sy + 1) * H + S - 1) / S;
   const int w0 = (sx * W) / S, w1 = ((sx + 1) * W + S - 1) / S;
-  const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
-  for (int cc = threadIdx.x; cc < C / E; cc += blockDim.x) {
+  const int ww = w1 - w0, npx = (h1 - h0) * ww;
+  const float inv = 1.0f / (float)npx;
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  T* __restrict__ out = reinterpret_cast<T*>(pb.out[g]);
+  for (int c0 = 0; c0 < C / E; c0 += 64) {
+    const int cc = c0 + cl;
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    for (int h = h0; h < h1; ++h)
-      for (int w = w0; w < w1; ++w) {
+    if (cc < C / E)
+      for (int p = pl; p < npx; p += PL) {
+        const int h = h0 + p / ww, w = w0 + p % ww;
         float x[E];
         unpack_chunk(*reinterpret_cast<const uint4*>(in + ((v * H + h) * W + w) * C + cc * E), x, T());
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += x[e];
       }
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] *= inv;
-    *reinterpret_cast<uint4*>(out + ((long long)blockIdx.x) * C + cc * E) = pack_chunk(acc, T());
+    for (int e = 0; e < E; ++e) red[pl][cl][e] = acc[e];
+    __syncthreads();
+    if (pl == 0 && cc < C / E) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float t = red[0][cl][e];
+#pragma unroll
+        for (int q = 1; q < PL; ++q) t += red[q][cl][e];
+        acc[e] = t * inv;
+      }
+      *reinterpret_cast<uint4*>(out + ((long long)v * S * S + cell) * C + cc * E) = pack_chunk(acc, T());
+    }
+    __syncthreads();
   }
 }
 
-int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s) {
+int launch_adaptive_avgpool_multi(int dtype, const void* in, void* const* outs, const int* bins, int nb, int V, int H, int W, int C,
+                                  hipStream_t s) {
   const int E = dtype == BF16 ? 8 : 4;
-  RGBM_REQUIRE(C % E == 0, "avgpool channels");
-  int threads = C / E;
-  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  RGBM_REQUIRE(C % E == 0 && nb >= 1 && nb <= 4, "avgpool channel alignment / bin count");
+  PoolBins pb;
+  pb.n = nb;
+  pb.first[0] = 0;
+  for (int i = 0; i < 4; ++i) {
+    pb.out[i] = i < nb ? outs[i] : nullptr;
+    pb.S[i] = i < nb ? bins[i] : 1;
+    pb.first[i + 1] = pb.first[i] + (i < nb ? bins[i] * bins[i] : 0);
+  }
+  pb.first[nb] = pb.first[nb];
+  const long long blocks = (long long)V * pb.first[nb];
+  RGBM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "avgpool grid");
   if (dtype == BF16)
-    hipLaunchKernelGGL(adaptive_avgpool_kernel<unsigned short>, dim3(V * S * S), dim3(threads), 0, s,
-                       (const unsigned short*)in, (unsigned short*)out, V, H, W, C, S);
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<unsigned short>, dim3((unsigned)blocks), dim3(512), 0, s, (const unsigned short*)in, pb, V, H, W, C);
   else
-    hipLaunchKernelGGL(adaptive_avgpool_kernel<float>, dim3(V * S * S), dim3(threads), 0, s, (const float*)in, (float*)out, V,
-                       H, W, C, S);
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<float>, dim3((unsigned)blocks), dim3(512), 0, s, (const float*)in, pb, V, H, W, C);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s) {
+  void* outs[1] = {out};
+  return launch_adaptive_avgpool_multi(dtype, in, outs, &S, 1, V, H, W, C, s);
 }
 
 // ---------------------------------------------------------------- plane-sweep homography (network_v5.py:390-392)
