@@ -22,7 +22,7 @@ struct AdaPose {
   int dtype = F32;
   int img = 224, n_pts = 1024, n_depth = 24;
   int img_cpad = 4;
-  int max_chunk = 128;           // views per cost-volume chunk (bounds the workspace: ~80 MB per view in bf16)
+  int max_chunk = 512;           // views per cost-volume chunk (bounds the workspace: ~80 MB per view in bf16; 512 = batch 256 in one chunk)
 
   struct Block { ConvLayer c1, c2, ds; bool has_ds = false; int stride = 1, planes = 0; };
   ConvLayer conv1;

@@ -390,3 +390,14 @@ def test_bf16_batch_invariance_across_kernel_selection():
         for k in OUT_KEYS:
             assert np.isfinite(out9[k][b]).all(), (b, k)
             assert _rel(out9[k][b:b + 1], o1[k]) < 2e-2, (b, k, _rel(out9[k][b:b + 1], o1[k]))
+
+
+def test_bf16_batch256_one_chunk_identical_to_128_view_chunks():
+    """BASELINE size: batch 256 with all 512 views in ONE cost-volume chunk (the default; c0 alone is 4.9e9 elements, past 32-bit
+    indices) gives bit-identical outputs to 128-view chunks."""
+    inp = synth.adapose_inputs(256, seed=0)
+    a = _run(_net("bf16"), inp)
+    b = _run(_net("bf16", max_chunk_views=128), inp)
+    for k in OUT_KEYS:
+        assert np.isfinite(a[k]).all(), k
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
