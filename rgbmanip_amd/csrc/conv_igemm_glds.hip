@@ -9,7 +9,8 @@
 #include "prof.h"
 
 #ifndef IG_ABL
-#define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too, 8 = no DMA
+#define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too,
+                      // 8 = no DMA; ws kernel: 16 = no epilogue, 32 = generic epilogue only, 64 = no output stores, 128 = no residual reads
 #endif
 
 namespace rgbm {
