@@ -83,3 +83,47 @@ def test_ppo_rejects_non_spaces():
         action_space = spaces.Box(-1, 1, (12,))
     with pytest.raises(TypeError, match="observation_space must be a gym Space"):
         PPO(Bad(), config.rl_cfg(device="cpu"))
+
+
+def test_synthetic_vec_env_partitions_are_slices_of_the_global_env():
+    """rank r owns envs [r*N, (r+1)*N) — the per-rank SyntheticMultiVecEnv scenes (seed 1000 + global env id,
+    per episode) are exactly the slices of one big env, resets advance only the selected envs, cam_move_to's reach model and
+    the handle corner order (open_cabinet.py:153-158) behave as documented.  Host logic only (no kernel is launched)."""
+    import numpy as np
+    import torch
+    from rgbmanip_amd import synthetic_env as se
+    whole = se.SyntheticMultiVecEnv(8, "cpu", seed=0, episodes=4)
+    parts = [se.SyntheticMultiVecEnv(4, "cpu", seed=0, env_id_offset=4 * r, episodes=4) for r in range(2)]
+    assert torch.equal(torch.cat([p._box for p in parts]), whole._box)
+    assert torch.equal(torch.cat([p._robot for p in parts]), whole._robot)
+    r0, b0 = se.sample_scene(5, 0)
+    np.testing.assert_array_equal(whole._box[5].numpy(), b0)
+    np.testing.assert_array_equal(whole._robot[5].numpy(), r0)
+    # reset of a subset
+    before = whole._box.clone()
+    whole.reset([1, 6])
+    assert whole.episode.tolist() == [0, 1, 0, 0, 0, 0, 1, 0]
+    changed = (whole._box != before).any(dim=1)
+    assert changed.tolist() == [False, True, False, False, False, False, True, False]
+    np.testing.assert_array_equal(whole._box[6].numpy(), se.sample_scene(6, 1)[1])
+    whole.reset()
+    assert whole.episode.tolist() == [1, 2, 1, 1, 1, 1, 2, 1]
+    # handle corners: centre (b0+b6)/2, axes b1-b0, b0-b2, b4-b0 along the box axes
+    c = se.box_corners(whole._box)
+    box = whole._box
+    torch.testing.assert_close((c[:, 0] + c[:, 6]) / 2, box[:, 0:3])
+    for k, (i, j) in enumerate(((1, 0), (0, 2), (4, 0))):
+        d = c[:, i] - c[:, j]
+        torch.testing.assert_close(d, 2 * box[:, 12 + k:13 + k] * box[:, 3 + 3 * k:6 + 3 * k])
+    # reach model: a target inside the reach is taken, one outside leaves the camera half way
+    env = parts[0]
+    start = env.camera_pose(robot_frame=True)[:, :3].clone()
+    near = torch.tensor([0.1, 0.0, 0.7, 1.0, 0, 0, 0], dtype=torch.float64)
+    far = torch.tensor([2.0, 0.0, 0.7, 1.0, 0, 0, 0], dtype=torch.float64)
+    ok, _ = env.cam_move_to(near.numpy(), robot_frame=True)
+    assert ok.all() and torch.allclose(env.camera_pose(robot_frame=True)[:, :3], near[:3].expand(4, 3))
+    ok, period = env.cam_move_to(far.numpy(), robot_frame=True)
+    assert (~ok).all() and torch.allclose(env.camera_pose(robot_frame=True)[:, :3], (near[:3] + 0.5 * (far[:3] - near[:3])).expand(4, 3))
+    assert (period > 1).all() and start.shape == (4, 3)
+    world = env.camera_pose(robot_frame=False)[:, :3]
+    assert torch.allclose(world, env.camera_pose(robot_frame=True)[:, :3] + env.robot_pose()[:, :3])
