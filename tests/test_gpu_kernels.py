@@ -52,6 +52,10 @@ CONV2D_CASES = [
     ("ws64_rowhalo_dil2", 3, 64, 150, 151, 64, 3, 1, 2, 2, True, 1, 0),
     ("ws64_rowhalo_dil4_cin256", 2, 256, 190, 187, 56, 3, 1, 4, 4, False, 2, 0),
     ("ws64_narrow_rows", 40, 64, 200, 9, 64, 3, 1, 1, 1, True, 1, 0),
+    # 64-channel layers with a residual (ResNet layer1's identity adds; post-activation adds), ragged Cout
+    ("ws64_rowhalo_res_pre", 3, 64, 150, 151, 64, 3, 1, 1, 1, False, 1, 1),
+    ("ws64_1x1_res_post_prelu", 5, 128, 120, 121, 64, 1, 1, 0, 1, True, 2, 2),
+    ("ws64_cout48_res_pre", 3, 128, 149, 150, 48, 3, 1, 1, 1, True, 1, 1),
 ]
 
 
@@ -73,6 +77,8 @@ def test_conv2d(case, dtype):
     if res_mode == 1:
         ref = ref + res
     ref = _act(ref, act, 0.25)
+    if res_mode == 2:
+        ref = ref + res
     y = conv_nd(dtype, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25)
     assert y.shape == ref.shape
     assert torch.isfinite(y).all()
