@@ -162,43 +162,49 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
     load4(feat + (((long long)v * H + y) * W + x) * C + c4 * 4, ref);
     const T* src = feat + (long long)partner * H * W * C + c4 * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // The 8 lanes of a point share the projection: lane j projects depths j, j+8, j+16, ... and the others fetch the
+    // coordinates by shuffle.  Corner reads are unconditional (clamped address, weight 0 outside the image: grid_sample's
+    // zero padding): four independent reads per depth instead of four dependent branches.
+    const int lane = threadIdx.x & 63, grp = lane & ~7;
+    float cix[3], ciy[3];                                   // D <= 24
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int dz = q * 8 + c4;
+      cix[q] = ciy[q] = 0.f;
+      if (dz < D) warp_coords_h(homog + (long long)v * 12, (float)x, (float)y, depths[b * D + dz], H, W, cix[q], ciy[q]);
+    }
     for (int dz = 0; dz < D; ++dz) {
-      float ix, iy;
-      warp_coords_h(homog + (long long)v * 12, (float)x, (float)y, depths[b * D + dz], H, W, ix, iy);
-      float wv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!(isfinite(ix) && isfinite(iy))) {
-        wv[0] = wv[1] = wv[2] = wv[3] = __builtin_nanf("");
-      } else {
-        ix = fminf(fmaxf(ix, -4.f), 1.0e6f);
-        iy = fminf(fmaxf(iy, -4.f), 1.0e6f);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x0 = (int)fx, y0 = (int)fy;
-        const float tx = ix - fx, ty = iy - fy;
-        float sv[4];
-        if ((unsigned)x0 < (unsigned)W && (unsigned)y0 < (unsigned)H) {
-          load4(src + ((long long)y0 * W + x0) * C, sv);
-          const float wgt = (1.f - tx) * (1.f - ty);
-          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
-        }
-        if ((unsigned)(x0 + 1) < (unsigned)W && (unsigned)y0 < (unsigned)H) {
-          load4(src + ((long long)y0 * W + x0 + 1) * C, sv);
-          const float wgt = tx * (1.f - ty);
-          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
-        }
-        if ((unsigned)x0 < (unsigned)W && (unsigned)(y0 + 1) < (unsigned)H) {
-          load4(src + ((long long)(y0 + 1) * W + x0) * C, sv);
-          const float wgt = (1.f - tx) * ty;
-          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
-        }
-        if ((unsigned)(x0 + 1) < (unsigned)W && (unsigned)(y0 + 1) < (unsigned)H) {
-          load4(src + ((long long)(y0 + 1) * W + x0 + 1) * C, sv);
-          const float wgt = tx * ty;
-          for (int e = 0; e < 4; ++e) wv[e] += sv[e] * wgt;
-        }
-      }
+      const int q = dz >> 3, srcl = grp + (dz & 7);
+      float ix = __shfl(q == 0 ? cix[0] : (q == 1 ? cix[1] : cix[2]), srcl);
+      float iy = __shfl(q == 0 ? ciy[0] : (q == 1 ? ciy[1] : ciy[2]), srcl);
+      const bool fin = isfinite(ix) && isfinite(iy);
+      ix = fminf(fmaxf(fin ? ix : 0.f, -4.f), 1.0e6f);
+      iy = fminf(fmaxf(fin ? iy : 0.f, -4.f), 1.0e6f);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+      float s00[4], s01[4], s10[4], s11[4];
+      load4(src + ((long long)yc0 * W + xc0) * C, s00);
+      load4(src + ((long long)yc0 * W + xc1) * C, s01);
+      load4(src + ((long long)yc1 * W + xc0) * C, s10);
+      load4(src + ((long long)yc1 * W + xc1) * C, s11);
+      const float w00 = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f, w01 = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
+      const float w10 = (xin0 && yin1) ? (1.f - tx) * ty : 0.f, w11 = (xin1 && yin1) ? tx * ty : 0.f;
       const float pr = prob[vp * D + dz];
+#pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float f = ref[e] + wv[e];
+        // same accumulation order as the branchy version: corners 00, 01, 10, 11 (an absent corner adds nothing)
+        float wv = 0.f;
+        if (xin0 && yin0) wv += s00[e] * w00;
+        if (xin1 && yin0) wv += s01[e] * w01;
+        if (xin0 && yin1) wv += s10[e] * w10;
+        if (xin1 && yin1) wv += s11[e] * w11;
+        if (!fin) wv = __builtin_nanf("");
+        float f = ref[e] + wv;
         if (ROUND_BF16) f = bf16_to_f32(f32_to_bf16(f));   // the volume the cost net saw was stored in bf16
         acc[e] += f * pr;
       }
@@ -211,6 +217,7 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
                        const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
                        hipStream_t s) {
   const long long total = (long long)V * P * 8;
+  RGBM_REQUIRE(D >= 1 && D <= 24 && total > 0 && (total + 255) / 256 < (1ll << 31), "fuse_points supports up to 24 depth planes");
   const unsigned g = (unsigned)((total + 255) / 256);
   if (dtype == BF16)
     hipLaunchKernelGGL((fuse_points_kernel<unsigned short, true>), dim3(g), dim3(256), 0, s, (const unsigned short*)feat,
