@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--ppo-env", default="full", choices=["full", "bank"],
                     help="full: ControlInterface over the synthetic MultiVecEnv (480x640 frames); bank: pre-cropped 224x224 view bank")
     ap.add_argument("--no-prepare", action="store_true", help="skip the device-side prepare_model_input leg")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-object (4 heads) leg")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()
@@ -182,6 +183,37 @@ def main():
                     "note": "480x640x3 f32 frame + mask -> 224x224 normalised crop, 1024 choose indices, cropped intrinsics (interface_v5.py:58-170)"}
         del frames, masks
 
+    # ---- configs[4] leg (not part of `value`): mixed-object batch, 4 heads, sorted by head and sharded over the ranks ----
+    mixed_res = None
+    if not args.no_mixed:
+        from rgbmanip_amd.mixed import HEADS, MixedObjectNet, shard_by_head
+        heads_global = np.arange(world * B) % 4                        # interleaved heads, like requests arriving in any order
+        idx = shard_by_head(heads_global, rank, world)
+        my_heads = heads_global[idx]
+        mnet = MixedObjectNet({h: synth.adapose_state_dict(seed=h) for h in np.unique(my_heads).tolist()}, dtype=args.dtype,
+                              device=local_rank, max_chunk_views=args.chunk or None)
+        margs = (d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
+
+        def mstep():
+            o = mnet(my_heads, *margs)
+            return postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"])
+        mstep()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            mstep()
+        barrier()
+        mdt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([mdt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mdt = float(tt.item())
+        mixed_res = {"poses_per_sec": round(world * B * 3 / mdt, 1), "heads": list(HEADS), "batch_total": world * B,
+                     "heads_on_rank0": sorted(set(int(h) for h in my_heads)),
+                     "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head "
+                             "(bf16 where the config says fp16: no fp16 storage mode)"}
+        del mnet
+
     # ---- PPO leg: AdaPose-in-the-loop rollout (synthetic vec-env stand-in) + HIP learn phase, cfg/controller/rl.yaml ----
     ppo_res = None
     if args.ppo_envs > 0:
@@ -257,6 +289,8 @@ def main():
             res["ppo"] = ppo_res
         if prep_res is not None:
             res["prepare_model_input"] = prep_res
+        if mixed_res is not None:
+            res["mixed_object"] = mixed_res
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -43,6 +43,11 @@ def _net(dtype, **kw):
     return AdaPoseNet(synth.adapose_state_dict(seed=0, prefix="module."), dtype=dtype, **kw)
 
 
+def _net_sd(sd, dtype, **kw):
+    from rgbmanip_amd.adapose import AdaPoseNet
+    return AdaPoseNet(sd, dtype=dtype, **kw)
+
+
 def _run(net, inp, **kw):
     out = net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"], **kw)
     torch.cuda.synchronize()
@@ -401,3 +406,27 @@ def test_bf16_batch256_one_chunk_identical_to_128_view_chunks():
     for k in OUT_KEYS:
         assert np.isfinite(a[k]).all(), k
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_mixed_object_batch_equals_per_head_runs():
+    """BASELINE configs[4] (mixed cabinet / drawer / mug / pot batch): four weight sets (independent seeds), a
+    shuffled batch routed by head — every pose's outputs are bit-identical to running its head's estimator on that head's
+    samples alone, and the rank shards reassemble the batch."""
+    from rgbmanip_amd.mixed import MixedObjectNet, shard_by_head
+    sds = {h: synth.adapose_state_dict(seed=10 + h, prefix="module.") for h in range(4)}
+    inp = synth.adapose_inputs(8, seed=21)
+    heads = np.array([2, 0, 3, 1, 0, 2, 1, 3])
+    mixed = MixedObjectNet(sds, dtype="bf16")
+    keys = ("img1", "choose1", "img2", "choose2", "P1", "P2", "depths")
+    got = {k: v.cpu().numpy() for k, v in mixed(heads, *[inp[k] for k in keys]).items()}
+    for h in range(4):
+        sel = np.nonzero(heads == h)[0]
+        alone = _run(_net_sd(sds[h], "bf16"), {k: inp[k][sel] for k in inp})
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(got[k][sel], alone[k], err_msg=f"head {h} {k}")
+    # two "ranks": each runs its shard, together they cover the batch with identical numbers
+    for r in range(2):
+        idx = shard_by_head(heads, r, 2)
+        part = MixedObjectNet(sds, dtype="bf16")(heads[idx], *[inp[k][idx] for k in keys])
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(part[k].cpu().numpy(), got[k][idx], err_msg=f"rank {r} {k}")

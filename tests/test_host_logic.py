@@ -127,3 +127,23 @@ def test_synthetic_vec_env_partitions_are_slices_of_the_global_env():
     assert (period > 1).all() and start.shape == (4, 3)
     world = env.camera_pose(robot_frame=False)[:, :3]
     assert torch.allclose(world, env.camera_pose(robot_frame=True)[:, :3] + env.robot_pose()[:, :3])
+
+
+def test_mixed_object_batches_shard_by_head():
+    """BASELINE configs[4]: 2048 poses = 4 heads x 512 over 8 ranks -> every pose on exactly one rank, one head per rank;
+    uneven mixes stay contiguous in head order."""
+    import numpy as np
+    from rgbmanip_amd.mixed import shard_by_head
+    heads = np.repeat(np.arange(4), 512)
+    np.random.default_rng(0).shuffle(heads)
+    seen = np.zeros(2048, dtype=int)
+    for r in range(8):
+        idx = shard_by_head(heads, r, 8)
+        assert len(idx) == 256 and len(np.unique(heads[idx])) == 1
+        seen[idx] += 1
+    assert (seen == 1).all()
+    heads = np.array([3, 0, 0, 2, 1, 0, 3, 3, 3, 2])
+    parts = [shard_by_head(heads, r, 3) for r in range(3)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(10))
+    assert all((np.diff(heads[p]) >= 0).all() for p in parts) and heads[parts[0]].max() <= heads[parts[1]].min() <= heads[parts[2]].min()
+    assert all(len(np.unique(heads[p])) <= 3 for p in parts)
