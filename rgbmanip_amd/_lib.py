@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBM_HIP_LIB selects another build of the same library (kernel ablation builds made by tools/abl_sweep.sh)
 LIB_PATH = os.environ.get("RGBM_HIP_LIB") or os.path.join(_HERE, "librgbm_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 

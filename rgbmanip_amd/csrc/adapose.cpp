@@ -73,7 +73,7 @@ static int init_linear(ConvLayer& L, const StateDict& sd, const std::string& p, 
 
 int AdaPose::create(const StateDict& sd, int dtype_) {
   dtype = dtype_;
-  const int E = dtype == BF16 ? 8 : 4;
+  const int E = dtype == F32 ? 4 : 8;
   img_cpad = E;                              // RGB padded to one 16-byte chunk
   const std::string fe = "img_extractor.feats.";
   if (int rc = init_conv2d(conv1, dtype, sd, fe + "conv1.weight", nullptr, 3, 64, 7, 2, 3, 1, ACT_RELU, 0.f, img_cpad)) return rc;
@@ -128,33 +128,14 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
       const int coutp = cout[i] < 16 ? 16 : cout[i];
       conv3d_tile_pack(w->data, scale.data(), cin[i], cout[i], coutp, i >= 7, dtype, packed);
       t3d[i].Cin = cin[i]; t3d[i].Cout = cout[i];
-      if (dtype == BF16) {
-        std::vector<unsigned short> h(packed.size());
-        for (size_t k = 0; k < packed.size(); ++k) {
-          unsigned u; memcpy(&u, &packed[k], 4);
-          u += 0x7fffu + ((u >> 16) & 1u);
-          h[k] = (unsigned short)(u >> 16);
-        }
-        RGBM_CHECK_HIP(hipMalloc(&t3d[i].w, h.size() * 2));
-        RGBM_CHECK_HIP(hipMemcpy(t3d[i].w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-      } else {
-        RGBM_CHECK_HIP(hipMalloc(&t3d[i].w, packed.size() * 4));
-        RGBM_CHECK_HIP(hipMemcpy(t3d[i].w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-      }
+      if (upload_packed(packed, dtype, &t3d[i].w)) return -2;
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
       if (i == 0 && dtype == BF16) {
         // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip)
         conv0_sweep_pack(w->data, scale.data(), packed);
-        std::vector<unsigned short> h(packed.size());
-        for (size_t k = 0; k < packed.size(); ++k) {
-          unsigned u; memcpy(&u, &packed[k], 4);
-          u += 0x7fffu + ((u >> 16) & 1u);
-          h[k] = (unsigned short)(u >> 16);
-        }
-        RGBM_CHECK_HIP(hipMalloc(&sweep_w, h.size() * 2));
-        RGBM_CHECK_HIP(hipMemcpy(sweep_w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        if (upload_packed(packed, BF16, &sweep_w)) return -2;
       }
     }
   }
@@ -361,7 +342,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
     d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
     // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
-    d.prof_variant = layer == 10 ? 10 + (dtype == BF16 ? 1 : 0) : (dtype == BF16 ? 16 + layer : 8);
+    d.prof_variant = layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);

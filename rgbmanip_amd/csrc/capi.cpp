@@ -24,7 +24,7 @@ const char* rgbm_last_error(void) { return last_error_cstr(); }
 
 int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode) {
   RGBM_REQUIRE(h != nullptr && w != nullptr && n_w > 0, "create arguments");
-  RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16, "dtype must be 0 (fp32) or 1 (bf16)");
+  RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16 || dtype == RGBM_F16, "dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
   RGBM_REQUIRE(norm_mode == 0, "only eval-mode (folded) BatchNorm is implemented");
   RGBM_CHECK_HIP(hipSetDevice(device));
   StateDict sd;
@@ -215,15 +215,7 @@ extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N,
   std::vector<float> packed;
   conv3d_tile_pack(w_host, bn_scale_host, cin[layer], cout[layer], coutp, tr, dtype, packed);
   void* wdev = nullptr; float* bdev = nullptr;
-  if (dtype == BF16) {
-    std::vector<unsigned short> h(packed.size());
-    for (size_t k = 0; k < packed.size(); ++k) { unsigned u; memcpy(&u, &packed[k], 4); u += 0x7fffu + ((u >> 16) & 1u); h[k] = (unsigned short)(u >> 16); }
-    RGBM_CHECK_HIP(hipMalloc(&wdev, h.size() * 2));
-    RGBM_CHECK_HIP(hipMemcpy(wdev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-  } else {
-    RGBM_CHECK_HIP(hipMalloc(&wdev, packed.size() * 4));
-    RGBM_CHECK_HIP(hipMemcpy(wdev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-  }
+  if (upload_packed(packed, dtype, &wdev)) return -2;
   std::vector<float> bpad(coutp, 0.f);
   for (int o = 0; o < cout[layer]; ++o) bpad[o] = bn_shift_host[o];
   if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;

@@ -7,11 +7,15 @@
 
 namespace rgbm {
 
-enum DType { F32 = 0, BF16 = 1 };
+enum DType { F32 = 0, BF16 = 1, F16 = 2 };      // storage type of activations / weights; accumulation is always fp32
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2, ACT_TANH = 3 };
 enum ResMode { RES_NONE = 0, RES_PRE_ACT = 1, RES_POST_ACT = 2 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16_t;                                     // IEEE half storage (dtype F16); bf16 storage is `unsigned short`
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void set_error(const std::string& s);
@@ -34,7 +38,7 @@ int fail(const char* what, const char* file, int line);
     }                                                                                    \
   } while (0)
 
-static inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 2; }
 static inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -69,6 +73,15 @@ template <> struct Elem<unsigned short> {
   __device__ static __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
 };
 
+template <> struct Elem<f16_t> {
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)(v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f)); }
+};
+// fp16 stores saturate at +-65504 instead of overflowing to inf (NaN stays NaN: fminf/fmaxf return the other operand for a NaN
+// input, so NaN is routed explicitly)
+__device__ __forceinline__ float sat_f16(float v) { return v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f); }
+
 // load/store 4 consecutive elements as floats
 __device__ __forceinline__ void load4(const float* p, float v[4]) {
   float4 t = *reinterpret_cast<const float4*>(p);
@@ -78,6 +91,15 @@ __device__ __forceinline__ void load4(const unsigned short* p, float v[4]) {
   uint2 t = *reinterpret_cast<const uint2*>(p);
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load4(const f16_t* p, float v[4]) {
+  const f16x4 t = *reinterpret_cast<const f16x4*>(p);
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+__device__ __forceinline__ void store4(f16_t* p, const float v[4]) {
+  f16x4 t;
+  t[0] = (f16_t)sat_f16(v[0]); t[1] = (f16_t)sat_f16(v[1]); t[2] = (f16_t)sat_f16(v[2]); t[3] = (f16_t)sat_f16(v[3]);
+  *reinterpret_cast<f16x4*>(p) = t;
 }
 __device__ __forceinline__ void store4(float* p, const float v[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -97,6 +119,17 @@ __device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, unsigned 
   v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
   v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
   v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, f16_t /*tag*/) {
+  const f16x8 h = __builtin_bit_cast(f16x8, c);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+}
+__device__ __forceinline__ uint4 pack_chunk(const float* v, f16_t /*tag*/) {
+  f16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (f16_t)sat_f16(v[e]);
+  return __builtin_bit_cast(uint4, h);
 }
 __device__ __forceinline__ uint4 pack_chunk(const float* v, float /*tag*/) {
   return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));

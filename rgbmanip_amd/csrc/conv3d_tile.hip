@@ -25,6 +25,11 @@ template <> struct Mma3<unsigned short> {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
+template <> struct Mma3<f16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
 template <> struct Mma3<float> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -327,7 +332,7 @@ static inline int c3_steps(int ntaps, int bpt) { return bpt >= 64 ? ntaps * (bpt
 // w: conv [Cout][Cin][27]; transposed [Cin][Cout][27].  Returns fp32 values (converted to the dtype by the caller).
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed) {
-  const int E = dtype == BF16 ? 8 : 4;
+  const int E = dtype == F32 ? 4 : 8;
   const int bpt = Cin * (int)dtype_size(dtype);
   const int spt = bpt >= 64 ? bpt / 64 : 1, tps = bpt >= 64 ? 1 : 64 / bpt;
   const int npass = transposed ? 8 : 1;
@@ -393,8 +398,9 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s) {
 #define C3_CASE(L, CIN, COUTP, TDB, THB, TWB, TDF, THF, TWF, STRIDE, TR, WARP)                                     \
   case L:                                                                                                          \
-    return dtype == BF16 ? launch_c3<unsigned short, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)            \
-                         : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s);
+    return dtype == BF16  ? launch_c3<unsigned short, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)           \
+           : dtype == F16 ? launch_c3<f16_t, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)                    \
+                          : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s);
   switch (layer) {
     //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp
     C3_CASE(0, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, false)

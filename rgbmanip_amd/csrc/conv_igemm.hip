@@ -31,6 +31,11 @@ template <> struct Mma<unsigned short> {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
     // lane-group g, element e of the 16-byte chunk is k = g*4+e; the same map is used for A and B,
@@ -246,7 +251,7 @@ int conv_ch_tile(int Cout) {
   if (Cout <= 64) return 64;
   return 128;
 }
-int conv_bk(int dtype) { return dtype == BF16 ? 64 : 32; }
+int conv_bk(int dtype) { return dtype == F32 ? 32 : 64; }
 
 template <typename T, int BCH, int BPIX>
 static int launch_one(ConvDesc d, hipStream_t s) {
@@ -276,7 +281,7 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
   RGBM_REQUIRE(d.M > 0 && d.M < (1ll << 31), "conv M out of range");
   RGBM_REQUIRE(d.Cout % 4 == 0 && d.ldo % 4 == 0, "conv Cout/ldo must be multiples of 4");
   RGBM_REQUIRE(d.KT > 0 && d.Kpad == d.KT * conv_bk(dtype), "conv K padding mismatch");
-  const int E = dtype == BF16 ? 8 : 4;
+  const int E = dtype == F32 ? 4 : 8;
   RGBM_REQUIRE(d.Cin % E == 0, "conv Cin must be a multiple of the 16-byte chunk");
   if (d.lcin >= 0) {
     RGBM_REQUIRE((1 << d.lcin) == d.Cin, "conv lcin mismatch");
@@ -284,7 +289,7 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
     RGBM_REQUIRE(d.ntaps == 1, "linear-K mode needs a single tap");
   }
   if (!(g_debug_flags & 4)) return launch_conv_glds(d, dtype, s);      // default: LDS-DMA variant (conv_igemm_glds.hip)
-  return dtype == BF16 ? launch_t<unsigned short>(d, s) : launch_t<float>(d, s);
+  return dtype == BF16 ? launch_t<unsigned short>(d, s) : dtype == F16 ? launch_t<f16_t>(d, s) : launch_t<float>(d, s);
 }
 
 }  // namespace rgbm

@@ -47,6 +47,14 @@ template <> struct MmaG<unsigned short> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
+template <> struct MmaG<f16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x4 run2(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
 template <> struct MmaG<float> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -1455,7 +1463,7 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
   // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel
-  if (sizeof(T) == 2 && conv_ws64_eligible(d, BF16)) return launch_ws64(d, s);
+  if (std::is_same<T, unsigned short>::value && conv_ws64_eligible(d, BF16)) return launch_ws64(d, s);
   RGBM_REQUIRE(d.w2 == nullptr, "a fused 1x1 needs the ws64 kernel (check conv_ws64_eligible first)");
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
 }
@@ -1469,7 +1477,7 @@ bool conv_ws64_eligible(const ConvDesc& d, int dtype) {
 }
 
 int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
-  return dtype == BF16 ? launch_dtype_g<unsigned short>(d, s) : launch_dtype_g<float>(d, s);
+  return dtype == BF16 ? launch_dtype_g<unsigned short>(d, s) : dtype == F16 ? launch_dtype_g<f16_t>(d, s) : launch_dtype_g<float>(d, s);
 }
 
 }  // namespace rgbm

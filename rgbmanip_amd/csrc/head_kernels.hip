@@ -35,6 +35,9 @@ int launch_gather_points(int dtype, const void* feat, const int* choose, float* 
   if (dtype == BF16)
     hipLaunchKernelGGL(gather_points_kernel<unsigned short>, dim3(g), dim3(256), 0, s, (const unsigned short*)feat, choose,
                        out, V, P, HW, C);
+  else if (dtype == F16)
+    hipLaunchKernelGGL(gather_points_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)feat, choose,
+                       out, V, P, HW, C);
   else
     hipLaunchKernelGGL(gather_points_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)feat, choose, out, V, P, HW, C);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -120,6 +123,9 @@ int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, co
   if (dtype == BF16)
     hipLaunchKernelGGL(prob_softmax_depth_kernel<unsigned short>, dim3(g), dim3(256), 0, s, (const unsigned short*)u11, wprob,
                        choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
+  else if (dtype == F16)
+    hipLaunchKernelGGL(prob_softmax_depth_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)u11, wprob,
+                       choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
   else
     hipLaunchKernelGGL(prob_softmax_depth_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)u11, wprob, choose, depths,
                        prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
@@ -142,6 +148,10 @@ __device__ __forceinline__ void warp_coords_h(const float* __restrict__ hm, floa
   ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
   iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
 }
+
+template <typename T> __device__ __forceinline__ float round_through(float f) { return f; }
+template <> __device__ __forceinline__ float round_through<unsigned short>(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+template <> __device__ __forceinline__ float round_through<f16_t>(float f) { return (float)(f16_t)sat_f16(f); }
 
 template <typename T, bool ROUND_BF16>
 __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __restrict__ homog, const float* __restrict__ depths,
@@ -205,7 +215,7 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
         if (xin1 && yin1) wv += s11[e] * w11;
         if (!fin) wv = __builtin_nanf("");
         float f = ref[e] + wv;
-        if (ROUND_BF16) f = bf16_to_f32(f32_to_bf16(f));   // the volume the cost net saw was stored in bf16
+        if (ROUND_BF16) f = round_through<T>(f);           // the volume the cost net saw was stored in the 16-bit type
         acc[e] += f * pr;
       }
     }
@@ -221,6 +231,9 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
   const unsigned g = (unsigned)((total + 255) / 256);
   if (dtype == BF16)
     hipLaunchKernelGGL((fuse_points_kernel<unsigned short, true>), dim3(g), dim3(256), 0, s, (const unsigned short*)feat,
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+  else if (dtype == F16)
+    hipLaunchKernelGGL((fuse_points_kernel<f16_t, true>), dim3(g), dim3(256), 0, s, (const f16_t*)feat,
                        homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
   else
     hipLaunchKernelGGL((fuse_points_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)feat, homog, depths,

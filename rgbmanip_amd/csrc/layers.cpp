@@ -24,10 +24,18 @@ int upload_f32(const float* host, size_t n, float** dev) {
   return 0;
 }
 
-static int upload_packed(const std::vector<float>& w, int dtype, void** dev) {
-  if (dtype == BF16) {
+static inline unsigned short host_f32_to_f16(float f) {
+  const _Float16 h = (_Float16)(f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f));      // round to nearest even, saturating
+  unsigned short u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+
+// host fp32 values -> device array in the storage type `dtype`
+int upload_packed(const std::vector<float>& w, int dtype, void** dev) {
+  if (dtype == BF16 || dtype == F16) {
     std::vector<unsigned short> h(w.size());
-    for (size_t i = 0; i < w.size(); ++i) h[i] = host_f32_to_bf16(w[i]);
+    for (size_t i = 0; i < w.size(); ++i) h[i] = dtype == BF16 ? host_f32_to_bf16(w[i]) : host_f32_to_f16(w[i]);
     RGBM_CHECK_HIP(hipMalloc(dev, h.size() * 2));
     RGBM_CHECK_HIP(hipMemcpy(*dev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   } else {
@@ -43,7 +51,7 @@ int ConvLayer::init(int dtype_, const ConvGeom& g_, const float* w, const float*
   dtype = dtype_;
   Cin_pad = Cin_pad_;
   Cout_pad = Cout_pad_;
-  const int E = dtype == BF16 ? 8 : 4;
+  const int E = dtype == F32 ? 4 : 8;
   const int BK = conv_bk(dtype);
   RGBM_REQUIRE(Cin_pad % E == 0 && Cin_pad >= g.Cin, "Cin_pad");
   RGBM_REQUIRE(Cout_pad % 4 == 0 && Cout_pad >= g.Cout, "Cout_pad");

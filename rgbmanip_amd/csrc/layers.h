@@ -62,6 +62,7 @@ struct ConvLayer {
 };
 
 // device upload helpers
+int upload_packed(const std::vector<float>& w, int dtype, void** dev);      // host fp32 -> device array in storage type dtype
 int upload_f32(const float* host, size_t n, float** dev);
 
 }  // namespace rgbm

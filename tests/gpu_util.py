@@ -6,7 +6,7 @@ import torch
 
 from rgbmanip_amd import _lib
 
-TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
 
 
 def rel_err(a, b):
@@ -66,7 +66,7 @@ def conv_nd(dtype, x, w, *, stride=1, stride_d=None, pad=0, pad_d=None, dil=1, t
         Do = (D + 2 * pd - (KD - 1) - 1) // sd + 1
         Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-    E = 8 if dtype == _lib.BF16 else 4
+    E = 4 if dtype == _lib.F32 else 8
     cin_pad = cin_pad or (Cin + E - 1) // E * E
     cout_pad = cout_pad or (Cout + 3) // 4 * 4
     xd = to_channels_last(x, dtype, cin_pad)

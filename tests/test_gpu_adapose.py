@@ -141,6 +141,19 @@ def test_bf16_close_to_golden(inputs, golden_dir, cost_impl):
     assert errs["view1_depth"] < 3e-2 and errs["view1_nocs"] < 1e-1 and errs["view1_r"] < 1.5e-1, errs
 
 
+@pytest.mark.parametrize("cost_impl", [3, 0])
+def test_fp16_close_to_golden(inputs, golden_dir, cost_impl):
+    """fp16 storage (saturating stores) / fp32 accumulate through the generic kernels (BASELINE configs[4] names fp16): 11-bit
+    mantissas, so it must sit well inside the bf16 bounds and stay finite (layer4 activations reach 650)."""
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    out = _run(_net("fp16", cost_impl=cost_impl), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print(f"fp16 (cost_impl={cost_impl}) vs reference golden:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+    assert errs["view1_depth"] < 5e-3 and errs["view1_nocs"] < 2e-2 and errs["view1_r"] < 2e-2, errs
+
+
 def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
     """cost_impl 3 (depth-sweeping conv0, conv0_sweep.hip) vs 2 (halo-tile conv0): same bf16 features and weights, fp32
     accumulation in a different order, so c0 may differ by one bf16 rounding at most; both stay close to the oracle."""

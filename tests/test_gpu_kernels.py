@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 from rgbmanip_amd import _lib  # noqa: E402
 
-TOL = {_lib.F32: 2e-5, _lib.BF16: 2.5e-2}
-DTYPES = [_lib.F32, _lib.BF16]
+TOL = {_lib.F32: 2e-5, _lib.BF16: 2.5e-2, _lib.F16: 4e-3}
+DTYPES = [_lib.F32, _lib.BF16, _lib.F16]
+QDT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
 
 
 def _act(y, act, slope):
@@ -70,9 +71,9 @@ def test_conv2d(case, dtype):
     b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
     ref = F.conv2d(x, w, b, stride, pad, dil)
     res = torch.randn(ref.shape, generator=g) if res_mode else None
-    if dtype == _lib.BF16:       # compare against the same rounded operands
-        x, w = x.bfloat16().float(), w.bfloat16().float()
-        res = res.bfloat16().float() if res is not None else None
+    if dtype != _lib.F32:       # compare against the same rounded operands
+        x, w = x.to(QDT[dtype]).float(), w.to(QDT[dtype]).float()
+        res = res.to(QDT[dtype]).float() if res is not None else None
         ref = F.conv2d(x, w, b, stride, pad, dil)
     if res_mode == 1:
         ref = ref + res
@@ -114,11 +115,11 @@ def test_conv3d_bn_relu(case, dtype):
         w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(Cin * 27)
     scale = torch.rand(Cout, generator=g) + 0.5
     shift = torch.randn(Cout, generator=g) * 0.1
-    if dtype == _lib.BF16:
-        x = x.bfloat16().float()
+    if dtype != _lib.F32:
+        x = x.to(QDT[dtype]).float()
     wf = w * (scale.view(1, -1, 1, 1, 1) if transposed else scale.view(-1, 1, 1, 1, 1))
-    if dtype == _lib.BF16:
-        wf = wf.bfloat16().float()
+    if dtype != _lib.F32:
+        wf = wf.to(QDT[dtype]).float()
     if transposed:
         ref = F.conv_transpose3d(x, wf, None, 2, 1, 1)
     else:
@@ -127,8 +128,8 @@ def test_conv3d_bn_relu(case, dtype):
     res = None
     if transposed:
         res = torch.randn(ref.shape, generator=g)
-        if dtype == _lib.BF16:
-            res = res.bfloat16().float()
+        if dtype != _lib.F32:
+            res = res.to(QDT[dtype]).float()
         ref = ref + res                      # post-activation skip add (network_v5.py:287-289)
     y = conv_nd(dtype, x, w, stride=stride, pad=1, transposed=transposed, bn_scale=scale, bn_shift=shift, res=res,
                 res_mode=2 if transposed else 0, act=1)
@@ -159,8 +160,8 @@ def test_pool_resize_avgpool(dtype):
     lib = _lib.load()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 64, 18, 18, generator=g)
-    if dtype == _lib.BF16:
-        x = x.bfloat16().float()
+    if dtype != _lib.F32:
+        x = x.to(QDT[dtype]).float()
     xd = to_channels_last(x, dtype)
     # max-pool 3x3 s2 p1 (pspnet.py:39)
     out = torch.empty(2, 9, 9, 64, dtype=TORCH_DT[dtype], device="cuda")
@@ -175,8 +176,8 @@ def test_pool_resize_avgpool(dtype):
     assert rel_err(from_channels_last(out), ref) < (1e-5 if dtype == _lib.F32 else 1e-2)
     # adaptive avg pool with overlapping windows (28 -> 1,2,3,6)
     x = torch.randn(2, 64, 28, 28, generator=g)
-    if dtype == _lib.BF16:
-        x = x.bfloat16().float()
+    if dtype != _lib.F32:
+        x = x.to(QDT[dtype]).float()
     xd = to_channels_last(x, dtype)
     for S in (1, 2, 3, 6):
         out = torch.empty(2, S, S, 64, dtype=TORCH_DT[dtype], device="cuda")
@@ -276,18 +277,18 @@ def test_conv3d_tile_layers(layer, dtype):
     w = (torch.randn(Cin, Cout, 3, 3, 3, generator=g) if tr else torch.randn(Cout, Cin, 3, 3, 3, generator=g)) / np.sqrt(Cin * 27)
     scale = torch.rand(Cout, generator=g) + 0.5
     shift = torch.randn(Cout, generator=g) * 0.1
-    if dtype == _lib.BF16:
-        x = x.bfloat16().float()
+    if dtype != _lib.F32:
+        x = x.to(QDT[dtype]).float()
     wf = w * (scale.view(1, -1, 1, 1, 1) if tr else scale.view(-1, 1, 1, 1, 1))
-    if dtype == _lib.BF16:
-        wf = wf.bfloat16().float()
+    if dtype != _lib.F32:
+        wf = wf.to(QDT[dtype]).float()
     ref = F.conv_transpose3d(x, wf, None, 2, 1, 1) if tr else F.conv3d(x, wf, None, stride, 1)
     ref = F.relu(ref + shift.view(1, -1, 1, 1, 1))
     res = None
     if tr:
         res = torch.randn(ref.shape, generator=g)
-        if dtype == _lib.BF16:
-            res = res.bfloat16().float()
+        if dtype != _lib.F32:
+            res = res.to(QDT[dtype]).float()
         ref = ref + res
     xd = to_channels_last(x, dtype)
     rd = to_channels_last(res, dtype) if res is not None else None
