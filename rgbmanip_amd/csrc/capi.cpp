@@ -259,7 +259,7 @@ extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, 
   d.N = V; d.Di = D; d.Hi = H; d.Wi = W; d.Do = D; d.Ho = H; d.Wo = W; d.Dq = D; d.Hq = H; d.Wq = W;
   d.Cout = 8; d.relu = 1; d.prof_variant = -1;
   d.feat = feat_dev; d.homog = homog_scratch; d.depths = depths_dev; d.v0 = 0; d.V = V; d.B = B;
-  int rc = launch_conv0_sweep(d, (hipStream_t)stream);
+  int rc = launch_conv0_sweep(d, BF16, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;

@@ -63,30 +63,45 @@ struct Corner {                     // everything the blend of one plane needs b
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;     // native vector: usable as a tied inline-asm operand
 
+template <typename T> struct Sw16;                                   // the two 16-bit storage types of this kernel
+template <> struct Sw16<unsigned short> {                            // bf16: a dword's halves are the high halves of two floats
+  __device__ static __forceinline__ f32x2 unpack(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+  __device__ static __forceinline__ unsigned pack(f32x2 v) { return pack2_bf16(v.x, v.y); }
+  __device__ static __forceinline__ f32x4 mma(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Sw16<f16_t> {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  __device__ static __forceinline__ f32x2 unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(h2, u), f32x2); }
+  __device__ static __forceinline__ unsigned pack(f32x2 v) {
+    const h2 h = {(f16_t)sat_f16(v.x), (f16_t)sat_f16(v.y)};
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ f32x4 mma(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
 __device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
                                              const float* w) {
   const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
   const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
   unsigned o[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {       // one dword = two bf16 channels -> one packed-f32 lane pair
-    const f32x2 fr = {__uint_as_float(rr[q] << 16), __uint_as_float(rr[q] & 0xffff0000u)};
-    const f32x2 fa = {__uint_as_float(aa[q] << 16), __uint_as_float(aa[q] & 0xffff0000u)};
-    const f32x2 fb = {__uint_as_float(bb[q] << 16), __uint_as_float(bb[q] & 0xffff0000u)};
-    const f32x2 fc = {__uint_as_float(cc[q] << 16), __uint_as_float(cc[q] & 0xffff0000u)};
-    const f32x2 fe = {__uint_as_float(ee[q] << 16), __uint_as_float(ee[q] & 0xffff0000u)};
+  for (int q = 0; q < 4; ++q) {       // one dword = two 16-bit channels -> one packed-f32 lane pair
+    const f32x2 fr = Sw16<T>::unpack(rr[q]), fa = Sw16<T>::unpack(aa[q]), fb = Sw16<T>::unpack(bb[q]);
+    const f32x2 fc = Sw16<T>::unpack(cc[q]), fe = Sw16<T>::unpack(ee[q]);
     const f32x2 v = fr + (((fa * w[0] + fb * w[1]) + fc * w[2]) + fe * w[3]);
-    o[q] = pack2_bf16(v.x, v.y);
+    o[q] = Sw16<T>::pack(v);
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-__device__ __forceinline__ f32x4 mma_bf16(const uint4& a, const uint4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 }  // namespace
 
+template <typename T>
 __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,7 +200,10 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 #define SW_GATHER(K, Q, OFF) do { (void)(OFF); } while (0)
 #endif
 #define SW_GATHER4(K, C) do { SW_GATHER(K, 0, (C).off[0]); SW_GATHER(K, 1, (C).off[1]); SW_GATHER(K, 2, (C).off[2]); SW_GATHER(K, 3, (C).off[3]); } while (0)
-#define SW_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+#ifndef SW_WAITSTR
+#define SW_WAITSTR "s_waitcnt vmcnt(12)"
+#endif
+#define SW_WAIT12(K) asm volatile(SW_WAITSTR : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     if (act) {
       corners(0, cur);
       SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
@@ -196,22 +214,22 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
         unsigned char* dst = dst0 + (z & 1) * SW_SLOT;
         SW_WAIT12(0);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst) = blend_chunk(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
+        *reinterpret_cast<uint4*>(dst) = blend_chunk<T>(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
         SW_GATHER4(0, nxt);
         SW_WAIT12(1);
 #endif
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 16) = blend_chunk(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 16) = blend_chunk<T>(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur.w);
 #endif
         SW_GATHER4(1, nxt);
         SW_WAIT12(2);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 32) = blend_chunk(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 32) = blend_chunk<T>(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur.w);
 #endif
         SW_GATHER4(2, nxt);
         SW_WAIT12(3);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 48) = blend_chunk(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 48) = blend_chunk<T>(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur.w);
 #endif
         SW_GATHER4(3, nxt);
         cur = nxt;
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
             v[r] = (hi[r] + Lp[pr][r]) + bias[r];
             if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
           }
-          store4(d.out + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
+          store4(reinterpret_cast<T*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
         }
         Lp[pr] = lo;
       }
@@ -291,15 +309,20 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 #pragma unroll
           for (int f = 0; f < 4; ++f) {
             const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
-            Xn[f] = mma_bf16(A01[tp], b, Xn[f]);
-            Xp[f] = mma_bf16(A2[tp], b, Xp[f]);
+            Xn[f] = Sw16<T>::mma(A01[tp], b, Xn[f]);
+            Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
           }
         }
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
       }
+      // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
+      // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
+      // with a memory clobber pins every LDS access to its side of the barrier.
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
   }
@@ -324,7 +347,8 @@ void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& pa
     }
 }
 
-int launch_conv0_sweep(const Conv3dTileDesc& t, hipStream_t s) {
+int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
+  RGBM_REQUIRE(dtype == BF16 || dtype == F16, "conv0 sweep: 16-bit storage types only");
   SweepDesc d;
   d.feat = reinterpret_cast<const unsigned short*>(t.feat);
   d.wgt = reinterpret_cast<const unsigned short*>(t.wgt);
@@ -338,11 +362,13 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, hipStream_t s) {
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
   static bool attr_done = false;
   if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
     attr_done = true;
   }
   prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
-  hipLaunchKernelGGL(conv0_sweep_kernel, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  if (dtype == BF16) hipLaunchKernelGGL(conv0_sweep_kernel<unsigned short>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  else hipLaunchKernelGGL(conv0_sweep_kernel<f16_t>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

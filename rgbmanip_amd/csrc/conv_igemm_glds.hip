@@ -931,9 +931,8 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
 // neighbour falls off the image row read a zero row instead), with the 3 x 64 weight rows of that kernel row beside it.
 // Per tile the L2->LDS traffic drops 2.1x (3 x 57 KB instead of 9 x 40 KB for Cin = 64) and the barriers 3x; a step holds
 // 96 MFMAs per wave.  Two 57 KB stages (plain double buffering) + the staging tile fit the 160 KB LDS.
-template <bool RH>
+template <bool RH, typename T>      // T: unsigned short (bf16) or f16_t
 __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) {
-  typedef unsigned short T;
   constexpr int BCH = 64, BPIX = 256;
   constexpr int E = 8, BK = 64;
   constexpr int XR = BPIX / 32;              // 8 gathered rows per request thread
@@ -1021,7 +1020,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     const int perf = (4 + (KT - 1) - 1) / (KT - 1);       // fused: 16-pixel fragments per K step (4 per wave and tile)
     auto flush_fused = [&](int k, int j0, int j1) {
       const int pix_tile = tile_of(k);
-      unsigned short* out2 = reinterpret_cast<unsigned short*>(d.out2);
+      T* out2 = reinterpret_cast<T*>(d.out2);
       for (int j = j0; j < j1 && j < 4; ++j) {
         const int r = sw * 64 + j * 16 + lr;
         const long long m = (long long)pix_tile * BPIX + r;
@@ -1320,7 +1319,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
               const float x = acc[a][b][e];
               v[e] = ACT == ACT_RELU ? (x < 0.f ? 0.f : x) : ACT == ACT_PRELU ? (x < 0.f ? x * slope : x) : x;
             }
-            *reinterpret_cast<uint2*>(stg + row * SROW + (a * 16 + lg * 4) * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+            store4(reinterpret_cast<T*>(stg + row * SROW + (a * 16 + lg * 4) * 2), v);
           }
         }
       };
@@ -1351,7 +1350,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
-        *reinterpret_cast<uint2*>(stg + row * SROW + ch * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+        store4(reinterpret_cast<T*>(stg + row * SROW + ch * 2), v);
       }
     }
   }
@@ -1366,6 +1365,7 @@ static bool conv_rowhalo_ok(const ConvDesc& d) {
          d.lcin >= 6 && d.Hq == d.Hi && d.Wq == d.Wi && d.Wi > 2 * d.dilw && d.osh == 1 && d.osw == 1 && !(g_debug_flags & 256);
 }
 
+template <typename T>
 static int launch_ws64(ConvDesc d, hipStream_t s) {
   constexpr int BCH = 64, BPIX = 256;
   const bool rh = conv_rowhalo_ok(d);
@@ -1380,8 +1380,8 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   static int n_cu = 0;
   static bool attr_done = false;
   if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   if (n_cu == 0) {
@@ -1393,8 +1393,8 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   }
   const int grid = d.n_tiles < n_cu ? d.n_tiles : n_cu;
   prof_begin_launch(s, 15, d.algo_flops, d.algo_bytes);
-  if (rh) hipLaunchKernelGGL(conv_igemm_ws64_kernel<true>, dim3((unsigned)grid), dim3(768), LDS, s, d);
-  else hipLaunchKernelGGL(conv_igemm_ws64_kernel<false>, dim3((unsigned)grid), dim3(768), LDS, s, d);
+  if (rh) hipLaunchKernelGGL((conv_igemm_ws64_kernel<true, T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
+  else hipLaunchKernelGGL((conv_igemm_ws64_kernel<false, T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1463,13 +1463,16 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
   // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel
-  if (std::is_same<T, unsigned short>::value && conv_ws64_eligible(d, BF16)) return launch_ws64(d, s);
+  // 33..64 output channels, 16-bit storage: the three-role persistent kernel
+  if constexpr (sizeof(T) == 2) {
+    if (conv_ws64_eligible(d, BF16)) return launch_ws64<T>(d, s);
+  }
   RGBM_REQUIRE(d.w2 == nullptr, "a fused 1x1 needs the ws64 kernel (check conv_ws64_eligible first)");
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
 }
 
 bool conv_ws64_eligible(const ConvDesc& d, int dtype) {
-  if (dtype != BF16 || (g_debug_flags & (4 | 16 | 128))) return false;
+  if ((dtype != BF16 && dtype != F16) || (g_debug_flags & (4 | 16 | 128))) return false;
   if (!conv_uniform_taps(d, 64) || conv_ch_tile(d.Cout) != 64 || d.res_mode != RES_NONE || d.KT < 2) return false;
   if (d.M < 256 * 256 || d.M >= (1ll << 31)) return false;
   if (d.w2) return d.Cout == 64 && d.kpad2 == 64 && (d.cout2 == 16 || d.cout2 == 32) && d.ldo2 % 4 == 0;

@@ -55,12 +55,12 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
 
 // conv0_sweep.hip — conv0 + fused plane sweep, depth-sweeping producer/consumer kernel (bf16 only)
 void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& packed);
-int launch_conv0_sweep(const Conv3dTileDesc& d, hipStream_t s);
+int launch_conv0_sweep(const Conv3dTileDesc& d, int dtype, hipStream_t s);      // dtype BF16 or F16
 
 // prob_sparse.hip — conv11 + skip + prob conv + softmax + depth on the neighbourhoods of the chosen pixels (bf16)
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
-                       int D, int H, int W, hipStream_t s);
+                       int D, int H, int W, int dtype, hipStream_t s);
 
 // prepare.hip — batched device-side AdaPoseEstimator_v5.prepare_model_input
 int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,

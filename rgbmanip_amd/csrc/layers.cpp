@@ -200,7 +200,7 @@ int ConvLayer::run_then_1x1(const ConvLayer& next, const void* in, void* mid, in
   const ConvGeom& ng = next.g;
   const bool is1x1 = !ng.transposed && ng.KD == 1 && ng.KH == 1 && ng.KW == 1 && ng.sd == 1 && ng.sh == 1 && ng.sw == 1 &&
                      ng.pd == 0 && ng.ph == 0 && ng.pw == 0 && next.packs.size() == 1;
-  if (allow_fuse && is1x1 && !g.transposed && dtype == BF16 && next.dtype == BF16 && next.Cin_pad == Cout_pad) {
+  if (allow_fuse && is1x1 && !g.transposed && dtype != F32 && next.dtype == dtype && next.Cin_pad == Cout_pad) {
     ConvDesc d;
     if (int rc = build_desc(d, in, mid, N, Di, Hi, Wi, ldmid, nullptr, RES_NONE, nullptr, 0, 0)) return rc;
     d.w2 = next.packs[0].w; d.bias2 = next.bias; d.out2 = out2; d.ldo2 = ldo2; d.cout2 = next.Cout_pad;

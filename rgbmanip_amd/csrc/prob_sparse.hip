@@ -36,12 +36,17 @@ struct ProbSparseDesc {
 
 template <int N> struct PC { static constexpr int value = N; };
 
-__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
+template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c);
+template <> __device__ __forceinline__ f32x4 mma16<unsigned short>(const uint4& a, const uint4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 }  // namespace
 
+template <typename T>
 __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d) {
   __shared__ __attribute__((aligned(16))) float U[4][PS_DMAX * 9 * 8];      // u11 on the 3x3xD neighbourhood, per wave
   __shared__ float wp[27 * 8];
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
       const bool wr = valid && lg < 2;
       const int ch = (lg & 1) * 4;
       float cv[4];
-      load4(c0v + (wr ? (((oz * H + yy) * W + xx) * 8 + ch) : 0), cv);
+      load4(reinterpret_cast<const T*>(c0v) + (wr ? (((oz * H + yy) * W + xx) * 8 + ch) : 0), cv);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc = mma16(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
+      for (int s = 0; s < NS; ++s) acc = mma16<T>(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
       if (wr) {
         f32x4 r;
 #pragma unroll
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
 
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
-                       int D, int H, int W, hipStream_t s) {
+                       int D, int H, int W, int dtype, hipStream_t s) {
+  RGBM_REQUIRE(dtype == BF16 || dtype == F16, "prob_sparse: 16-bit storage types only");
   RGBM_REQUIRE(u9 && c0 && w11_packed && bias11 && wprob && choose && depths && prob && depth_out, "prob_sparse arguments");
   RGBM_REQUIRE(D <= PS_DMAX && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0, "prob_sparse supports even D <= 24 and even H, W");
   RGBM_REQUIRE((long long)D * H * W * 8 < (1ll << 31), "prob_sparse view too large for 32-bit offsets");
@@ -184,7 +190,8 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
   d.v0 = v0; d.Vc = Vc; d.B = B; d.P = P; d.D = D; d.H = H; d.W = W;
   const long long npts = (long long)Vc * P;
   RGBM_REQUIRE(npts > 0 && (npts + 3) / 4 < (1ll << 31), "prob_sparse grid out of range");
-  hipLaunchKernelGGL(prob_sparse_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
+  if (dtype == BF16) hipLaunchKernelGGL(prob_sparse_kernel<unsigned short>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(prob_sparse_kernel<f16_t>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
