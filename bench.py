@@ -87,6 +87,7 @@ def main():
                     help="full: ControlInterface over the synthetic MultiVecEnv (480x640 frames); bank: pre-cropped 224x224 view bank")
     ap.add_argument("--no-prepare", action="store_true", help="skip the device-side prepare_model_input leg")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-object (4 heads) leg")
+    ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32"], help="storage type of the mixed-object leg (configs[4] names fp16)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()
@@ -190,7 +191,7 @@ def main():
         heads_global = np.arange(world * B) % 4                        # interleaved heads, like requests arriving in any order
         idx = shard_by_head(heads_global, rank, world)
         my_heads = heads_global[idx]
-        mnet = MixedObjectNet({h: synth.adapose_state_dict(seed=h) for h in np.unique(my_heads).tolist()}, dtype=args.dtype,
+        mnet = MixedObjectNet({h: synth.adapose_state_dict(seed=h) for h in np.unique(my_heads).tolist()}, dtype=args.mixed_dtype,
                               device=local_rank, max_chunk_views=args.chunk or None)
         margs = (d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
 
@@ -210,8 +211,8 @@ def main():
             mdt = float(tt.item())
         mixed_res = {"poses_per_sec": round(world * B * 3 / mdt, 1), "heads": list(HEADS), "batch_total": world * B,
                      "heads_on_rank0": sorted(set(int(h) for h in my_heads)),
-                     "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head "
-                             "(bf16 where the config says fp16: no fp16 storage mode)"}
+                     "dtype": args.mixed_dtype,
+                     "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head"}
         del mnet
 
     # ---- PPO leg: AdaPose-in-the-loop rollout (synthetic vec-env stand-in) + HIP learn phase, cfg/controller/rl.yaml ----
