@@ -50,10 +50,11 @@ typedef struct rgbm_adapose_out {   /* device fp32, shapes of the reference's ou
   float *view1_s, *view2_s;         /* [B,3]      */
 } rgbm_adapose_out;
 
-/* norm_mode: 0 = eval-mode BatchNorm3d folded into the convs (the parity oracle). */
+/* dtype: RGBM_F32 (parity mode), RGBM_BF16 (throughput mode) or RGBM_F16.
+ * norm_mode: 0 = eval-mode BatchNorm3d folded into the convs (the parity oracle). */
 int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode);
 int rgbm_adapose_destroy(rgbm_adapose_t* h);
-/* views per cost-volume chunk (default 128); bounds the workspace */
+/* views per cost-volume chunk (default 512 = batch 256 in one chunk); bounds the workspace */
 int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
 /* options: "max_chunk" (views per cost-volume chunk), "fuse_final" (bf16 only; 1 [default] = PSPNet's final 1x1 runs inside
  * up_3's kernel and the 64-channel up_3 output is never written; 0 = two launches), "sparse_tail" (bf16 + cost_impl 3 only; 1 [default] = conv11, the
