@@ -23,7 +23,7 @@ extern "C" {
 #define RGBM_VERSION 100
 #define RGBM_F32 0
 #define RGBM_BF16 1
-#define RGBM_F16 2       /* IEEE half storage (saturating stores), fp32 accumulation; every kernel except the conv0 sweep */
+#define RGBM_F16 2       /* IEEE half storage (saturating stores), fp32 accumulation; same kernels as RGBM_BF16 */
 
 int rgbm_version(void);
 const char* rgbm_last_error(void);

@@ -346,9 +346,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);
-    // (the f16_t instantiation of the sweep exists but is not selected: its outputs vary from run to run, a race not yet found;
-    //  fp16 nets take the halo-tile conv0 with the fused plane sweep instead)
-    if (layer == 10 && cost_impl == 3 && (dtype == BF16 || (dtype == F16 && (g_debug_flags & 4096))) && sweep_w) {
+    if (layer == 10 && cost_impl == 3 && dtype != F32 && sweep_w && !(dtype == F16 && (g_debug_flags & 4096))) {
       d.wgt = sweep_w;
       return launch_conv0_sweep(d, dtype, s);
     }

@@ -18,6 +18,7 @@
 //     The two row halves sit in lanes 0-31 / 32-63 of the accumulator: v_permlane32_swap pairs two fragments so the
 //     final add, bias, ReLU and the 8-byte stores run on all 64 lanes.
 // One s_barrier per plane hands slot z&1 from the producers to the consumers; producers fill the other slot meanwhile.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -211,6 +212,12 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
     for (int z = 0; z <= D; ++z) {
       if (act && z < D) {
         corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
+        if (sizeof(T) == 2 && !std::is_same<T, unsigned short>::value) {
+          // f16_t: keep the reference feature packed (hipcc otherwise hoists its 32 conversions out of the plane loop:
+          // 170 VGPRs instead of 164)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ref[k].x), "+v"(ref[k].y), "+v"(ref[k].z), "+v"(ref[k].w));
+        }
         unsigned char* dst = dst0 + (z & 1) * SW_SLOT;
         SW_WAIT12(0);
 #if !(SW_ABL & 1)

@@ -443,3 +443,27 @@ def test_mixed_object_batch_equals_per_head_runs():
         part = MixedObjectNet(sds, dtype="bf16")(heads[idx], *[inp[k][idx] for k in keys])
         for k in OUT_KEYS:
             np.testing.assert_array_equal(part[k].cpu().numpy(), got[k][idx], err_msg=f"rank {r} {k}")
+
+
+def test_fp16_sweep_conv0_stable_and_matches_tile_conv0(inputs):
+    """The f16_t instantiation of the depth-sweeping conv0: bit-identical over repeated runs (an earlier build, in which hipcc
+    had hoisted the reference-feature conversions out of the plane loop, varied from run to run) and within fp16 rounding of
+    the halo-tile conv0 (debug flag 4096 selects the tile kernel for fp16 nets)."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+
+    def c0(flag):
+        _lib.check(lib.rgbm_debug_flags(flag))
+        try:
+            net = _net("fp16", cost_impl=3)
+            _run(net, inputs, stop_after=2)
+            return net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).view(4, 24, 224, 224, 8).float().cpu().numpy()
+        finally:
+            _lib.check(lib.rgbm_debug_flags(0))
+    runs = [c0(0) for _ in range(4)]
+    for r in runs[1:]:
+        np.testing.assert_array_equal(runs[0], r)
+    tile = c0(4096)
+    scale = np.abs(tile).max()
+    assert np.abs(runs[0] - tile).max() / scale < 2e-3
+    assert np.abs(runs[0] - tile).mean() / np.abs(tile).mean() < 1e-4
