@@ -244,6 +244,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
       // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
     }
 #undef SW_GATHER
 #undef SW_GATHER4

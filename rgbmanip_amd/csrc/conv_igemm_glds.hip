@@ -38,6 +38,10 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
 }
 
+// s_barrier with the LDS accesses pinned to their side of it: the builtin alone is IntrNoMem for the compiler, which may hoist a
+// later ds_read above it (seen in conv0_sweep.hip's ISA) — a read of a stage another wave has not finished filling
+#define RGBM_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 template <typename T> struct MmaG;
 template <> struct MmaG<unsigned short> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
   for (int kt = 0; kt < d.KT; ++kt) {
     // tile kt has landed for every wave (vmcnt(0) + barrier); every wave has also finished reading the other stage
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    RGBM_BARRIER();
     if (kt + 1 < d.KT) issue(kt + 1, cur ^ 1);
     const uint4* W = lds + cur * STAGE;
     const uint4* X = W + BCH * 8;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
   for (int kt = 0; kt < d.KT; ++kt) {
     if (kt + 1 < d.KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // tile kt landed; tile kt+1 may still fly
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();              // every wave's share of tile kt is in LDS; stage of tile kt-1 is free
+    RGBM_BARRIER();              // every wave's share of tile kt is in LDS; stage of tile kt-1 is free
     const int nst = st == 0 ? 2 : st - 1;
     const bool more = kt + 2 < d.KT;
     if (issue_first && more) issue(kt + 2, nst);       // one copy of compute(): two copies made hipcc shuffle the
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     for (int g = 0; g < total; ++g) {
       if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step g landed; step g+1 may still fly
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // step g is complete in LDS; the stage of step g-1 is free
+      RGBM_BARRIER();            // step g is complete in LDS; the stage of step g-1 is free
       if (g + 2 < total) issue(st == 0 ? 2 : st - 1);
       st = st == 2 ? 0 : st + 1;
     }
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     for (int kt = 0; kt < KT; ++kt) {
       // every fragment read of the previous step has returned before the request waves may refill its stage
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      RGBM_BARRIER();
       load_half(st, 0, af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt > 0) mma_half(af1, bf1);                  // second half of K tile kt-1
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     int g = 0;
     for (int k = 0; k < n_my; ++k)
       for (int kt = 0; kt < KT; ++kt, ++g) {
-        __builtin_amdgcn_s_barrier();
+        RGBM_BARRIER();
         // the staged tile k-1 was published by barrier (k, 0); it must be drained before barrier (k, KT-1), after which
         // the multiply waves overwrite it
         if (k > 0 && kt < KT - 1) {
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
           else flush(k - 1, kt * per, (kt + 1) * per);
         }
       }
-    __builtin_amdgcn_s_barrier();             // publishes the last staged tile
+    RGBM_BARRIER();             // publishes the last staged tile
     if (d.w2) flush_fused(n_my - 1, 0, 4);
     else flush(n_my - 1, 0, 8);
     return;
@@ -1121,10 +1125,10 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
       if (total > 0) issue(0);
       for (int g = 0; g < total; ++g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // step g landed (double buffering: nothing else is in flight)
-        __builtin_amdgcn_s_barrier();                        // ... and every wave is done with the other stage
+        RGBM_BARRIER();                        // ... and every wave is done with the other stage
         if (g + 1 < total) issue((g + 1) & 1);
       }
-      __builtin_amdgcn_s_barrier();
+      RGBM_BARRIER();
       return;
     }
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
@@ -1200,11 +1204,11 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     for (int g = 0; g < total; ++g) {
       if (g + 1 < total) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      RGBM_BARRIER();
       if (g + 2 < total) issue(st == 0 ? 2 : st - 1);
       st = st == 2 ? 0 : st + 1;
     }
-    __builtin_amdgcn_s_barrier();
+    RGBM_BARRIER();
     return;
   }
 
@@ -1257,7 +1261,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
       }
       for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        RGBM_BARRIER();
         const uint4* W = lds3 + (st & 1) * STAGE;
         const uint4* X = W + HWROWS * 8;
 #pragma unroll
@@ -1289,7 +1293,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     } else {
     for (int kt = 0; kt < KT; ++kt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads returned, staged tile written
-      __builtin_amdgcn_s_barrier();
+      RGBM_BARRIER();
       load_half(st, 0, af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt > 0) mma_half(af1, bf1);
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  RGBM_BARRIER();
 }
 
 // row-halo variant of the 64-channel kernel: 2-D 3x3, stride 1, "same" padding, Cin a multiple of 64
