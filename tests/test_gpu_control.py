@@ -279,3 +279,27 @@ def test_rl_pose_controller_train_and_run():
     assert est_box.shape == (4, 8, 3) and len(calls) == 1 and calls[0][2] is True
     assert np.isfinite(calls[0][0]).all() and np.isfinite(calls[0][1]).all()
     assert ctl.control_interface.accumulate_steps == ctl.control_interface.max_steps          # ran to the end of the episode
+
+
+def test_fp16_estimator_in_the_control_loop():
+    """configs[4]'s storage type through the whole device loop: ControlInterface.step over the synthetic env with an fp16
+    estimator stays finite and agrees with the fp32 estimator's boxes to fp16 accuracy on the same frames."""
+    from rgbmanip_amd import synthetic_env as se
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.control_interface import ControlInterface
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device", hip_prepare_seed=1)
+    sd = synth.adapose_state_dict(seed=0, prefix="module.")
+    boxes = {}
+    for dt in ("fp32", "fp16"):
+        est = AdaPoseEstimator_v5(None, cfg, None, state_dict=sd, dtype=dt)
+        env = se.SyntheticMultiVecEnv(4, "cuda", seed=3)
+        ci = ControlInterface(env, est, se.SyntheticManipulation(env), synth.control_cfg("cabinet"))
+        out = []
+        for s in range(3):
+            obs, rew, done, info = ci.step(torch.from_numpy(synth.control_actions(4, s, 9) * 0.3).cuda())
+            assert torch.isfinite(rew).all()
+            out.append(ci.pred_bbox[ci.accumulate_steps - 1].cpu().numpy())
+        boxes[dt] = np.stack(out)
+    scale = np.abs(boxes["fp32"]).max()
+    assert np.abs(boxes["fp16"] - boxes["fp32"]).max() / scale < 2e-2
