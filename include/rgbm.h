@@ -253,6 +253,10 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
                      const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
                      int V, int B, int D, int H, int W, void* stream);
+/* the same kernel for either 16-bit storage type (dtype = RGBM_BF16 or RGBM_F16; feat / out in that type) */
+int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                        const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
+                        int V, int B, int D, int H, int W, void* stream);
 /* debugging access to a named intermediate of the last rgbm_adapose_forward on (h, B, workspace):
  * converts it to fp32 into out_dev (elems = capacity in floats); *n_elems returns its size.  Intermediates of the
  * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first. */

@@ -237,19 +237,17 @@ extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N,
 }
 
 // Kernel-level entry for the depth-sweeping conv0 + fused plane sweep (tests): bf16 features [V][H][W][32] -> [V][D][H][W][8].
-extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
-                                const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
-                                int V, int B, int D, int H, int W, void* stream) {
+extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev,
+                                   float* homog_scratch, const float* w_host, const float* bn_scale_host, const float* bn_shift_host,
+                                   void* out_dev, int V, int B, int D, int H, int W, void* stream) {
   RGBM_REQUIRE(feat_dev && P_views_dev && depths_dev && homog_scratch && w_host && bn_scale_host && bn_shift_host && out_dev,
                "conv0_sweep arguments");
+  RGBM_REQUIRE(dtype == BF16 || dtype == F16, "conv0_sweep: 16-bit storage types only");
   if (int rc = launch_homography(P_views_dev, homog_scratch, V, B, (hipStream_t)stream)) return rc;
   std::vector<float> packed;
   conv0_sweep_pack(w_host, bn_scale_host, packed);
-  std::vector<unsigned short> h(packed.size());
-  for (size_t k = 0; k < packed.size(); ++k) { unsigned u; memcpy(&u, &packed[k], 4); u += 0x7fffu + ((u >> 16) & 1u); h[k] = (unsigned short)(u >> 16); }
   void* wdev = nullptr; float* bdev = nullptr;
-  RGBM_CHECK_HIP(hipMalloc(&wdev, h.size() * 2));
-  RGBM_CHECK_HIP(hipMemcpy(wdev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  if (upload_packed(packed, dtype, &wdev)) return -2;
   std::vector<float> bpad(16, 0.f);
   for (int o = 0; o < 8; ++o) bpad[o] = bn_shift_host[o];
   if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;
@@ -259,10 +257,17 @@ extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, 
   d.N = V; d.Di = D; d.Hi = H; d.Wi = W; d.Do = D; d.Ho = H; d.Wo = W; d.Dq = D; d.Hq = H; d.Wq = W;
   d.Cout = 8; d.relu = 1; d.prof_variant = -1;
   d.feat = feat_dev; d.homog = homog_scratch; d.depths = depths_dev; d.v0 = 0; d.V = V; d.B = B;
-  int rc = launch_conv0_sweep(d, BF16, (hipStream_t)stream);
+  int rc = launch_conv0_sweep(d, dtype, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;
+}
+
+extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                                const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
+                                int V, int B, int D, int H, int W, void* stream) {
+  return rgbm_conv0_sweep_dt(BF16, feat_dev, P_views_dev, depths_dev, homog_scratch, w_host, bn_scale_host, bn_shift_host, out_dev,
+                             V, B, D, H, W, stream);
 }
 
 // Batched device-side prepare_model_input (interface_v5.py:58-170); see include/rgbm.h.

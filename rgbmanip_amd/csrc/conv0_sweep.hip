@@ -8,7 +8,7 @@
 //     feature of its pixel in registers for the whole sweep; per plane it projects the pixel with that plane's depth,
 //     gathers the 4 bilinear corners of the partner view's feature map (corners outside the image get weight 0:
 //     grid_sample padding_mode="zeros"), blends in fp32, rounds to bf16 and writes the 64-byte voxel into one of
-//     two LDS plane slots.  The corner loads of plane z+1 are issued before plane z is blended (two register sets), so
+//     three LDS plane slots.  The corner loads of plane z+1 are issued before plane z is blended (two register sets), so
 //     gather latency is covered by VALU work.  Halo redundancy is 252/192 = 1.31x (the 4x8x8 tile: 2.34x).
 //   * consumer waves (3): MFMA 16x16x32 bf16, input-plane stationary.  Cout = 8 fills only half of the 16 MFMA rows,
 //     so two depth taps share one instruction: A01[t] = rows 0-7 W(kd=0,t), rows 8-15 W(kd=1,t); A2[t] = rows 8-15
@@ -17,7 +17,7 @@
 //     18 MFMAs per 16-voxel fragment and plane instead of 27, one LDS read per two MFMAs, weights live in registers.
 //     The two row halves sit in lanes 0-31 / 32-63 of the accumulator: v_permlane32_swap pairs two fragments so the
 //     final add, bias, ReLU and the 8-byte stores run on all 64 lanes.
-// One s_barrier per plane hands slot z&1 from the producers to the consumers; producers fill the other slot meanwhile.
+// One s_barrier per plane hands slot z%3 from the producers to the consumers; producers fill the next slot meanwhile.
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -43,7 +43,16 @@ constexpr int SW_SLOT = SW_NV * SW_VS;           // 20160
 constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
 constexpr int SW_NCW = SW_TH / 4;                // 3 consumer waves, 4 fragments (rows) each
 constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
-constexpr int SW_LDS = 2 * SW_SLOT;
+// Plane ring of THREE slots.  Two are what the barrier protocol needs on paper (producers fill slot z&1 while the consumers
+// read the other one), and the bf16 build never showed a problem with two — but the f16_t build with the shorter
+// v_fma_mix blend did: about one workgroup in a thousand delivered one consumer wave's rows of three consecutive output
+// planes differently from run to run (= one input plane read while it was being overwritten), under every variation tried
+// of wait counts, s_nops behind the LDS stores, volatile blend asm and FP16_OVFL on/off; any build whose producers were
+// slower (explicit saturation code in the pack) was stable, and so is the third slot, which gives every plane one more
+// barrier interval before its slot is reused (tools/f16_sweep_check.py 256).  60 KB per workgroup; occupancy is set by
+// the VGPRs, not by LDS.
+constexpr int SW_NSLOT = 3;
+constexpr int SW_LDS = SW_NSLOT * SW_SLOT;
 static_assert(SW_TH % 4 == 0, "a consumer wave owns 4 rows");
 
 struct SweepDesc {
@@ -100,10 +109,43 @@ __device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, con
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// f16_t: the same sum with v_fma_mix_f32, which reads the f16 half of a dword directly (no v_cvt per operand): 5
+// instructions per channel instead of 10 conversions + 5 packed operations per channel pair.  The caller has set
+// MODE.FP16_OVFL, so the final v_cvt_pk_f16_f32 saturates at +-65504 by itself (NaN stays NaN) — sat_f16() in front of it
+// costs 6 more instructions per dword.
+#define SW_MIX(HI, D, H, W, C) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(D) : "v"(H), "v"(W), "v"(C))
+template <>
+__device__ __forceinline__ uint4 blend_chunk<f16_t>(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
+                                                    const float* w) {
+  typedef Sw16<f16_t>::h2 h2;
+  // (element copies: indexing the u32x4 references with the unrolled loop counter made hipcc use element 0 for all four)
+  const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
+  const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
+  unsigned o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lo, hi;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(aa[q]), "v"(w[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(aa[q]), "v"(w[0]));
+    SW_MIX(0, lo, bb[q], w[1], lo); SW_MIX(1, hi, bb[q], w[1], hi);
+    SW_MIX(0, lo, cc[q], w[2], lo); SW_MIX(1, hi, cc[q], w[2], hi);
+    SW_MIX(0, lo, ee[q], w[3], lo); SW_MIX(1, hi, ee[q], w[3], hi);
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(rr[q]), "v"(lo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(rr[q]), "v"(hi));
+    const h2 h = {(f16_t)lo, (f16_t)hi};
+    o[q] = __builtin_bit_cast(unsigned, h);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+#undef SW_MIX
+
 }  // namespace
 
+// min 3 waves per SIMD (<= 168 VGPRs): the hardware then starts the next workgroup's producers while this one's consumers
+// finish (12 wave slots per CU for 7-wave workgroups).  The bf16 instantiation needs 164 anyway; uncapped, the f16_t one
+// took 170 and lost that overlap.
 template <typename T>
-__global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc d) {
+__global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -120,6 +162,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 
   if (wave < SW_NPW) {
     // ------------------------------------------------------------------ producers
+    if (std::is_same<T, f16_t>::value) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);      // MODE.FP16_OVFL = 1 (see blend_chunk<f16_t>)
     const int pv = tid;                                  // voxel of the (TH+2) x 18 plane
     const bool act = pv < SW_NV;
     const int hh = pv / SW_HW, hw = pv - hh * SW_HW;
@@ -218,7 +261,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
 #pragma unroll
           for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ref[k].x), "+v"(ref[k].y), "+v"(ref[k].z), "+v"(ref[k].w));
         }
-        unsigned char* dst = dst0 + (z & 1) * SW_SLOT;
+        unsigned char* dst = dst0 + (z % SW_NSLOT) * SW_SLOT;
         SW_WAIT12(0);
 #if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst) = blend_chunk<T>(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
@@ -308,7 +351,7 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
     for (int z = 0; z <= D; ++z) {
       if (z >= 1) {
         const int p = z - 1;
-        const unsigned char* slot = planes + (p & 1) * SW_SLOT + boff;
+        const unsigned char* slot = planes + (p % SW_NSLOT) * SW_SLOT + boff;
         f32x4 Xn[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -327,8 +370,11 @@ __global__ __launch_bounds__(SW_THREADS) void conv0_sweep_kernel(const SweepDesc
       }
       // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
       // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
-      // with a memory clobber pins every LDS access to its side of the barrier.
-      asm volatile("" ::: "memory");
+      // with a memory clobber pins every LDS access to its side of the barrier.  The lgkmcnt(0) covers the other direction:
+      // MFMAs are not memory operations, so hipcc may sink a plane's last ds_read/MFMA pairs below the barrier (seen in
+      // the peeled first iteration of an experimental build) — the read would then still be queued when the producers
+      // start to overwrite the slot.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
