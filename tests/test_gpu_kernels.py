@@ -86,6 +86,33 @@ def test_conv2d(case, dtype):
     assert rel_err(y, ref) < TOL[dtype], name
 
 
+@pytest.mark.parametrize("name", ["l2_3x3_s2", "up_prelu", "ws128_res_pre", "ws128_1x1_s1", "ws64_prelu_bias", "ws64_rowhalo_dil2",
+                                  "ws64_1x1_res_post_prelu"])
+def test_conv2d_fp16_stores_saturate(name):
+    """fp16 storage: results beyond +-65504 are stored as +-65504, not inf, for every kernel variant the dispatcher can pick."""
+    from gpu_util import conv_nd
+    case = [c for c in CONV2D_CASES if c[0] == name][0]
+    _, N, Cin, H, W, Cout, k, stride, pad, dil, has_bias, act, res_mode = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 2000.0).half().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 40.0 / np.sqrt(Cin * k * k)).half().float()
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    res = (torch.randn(N, Cout, (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1,
+                       generator=g) * 3e4).half().float() if res_mode else None
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    if res_mode == 1:
+        ref = ref + res
+    ref = _act(ref, act, 0.25)
+    if res_mode == 2:
+        ref = ref + res
+    assert float((ref.abs() > 65504.0).float().mean()) > 0.02, "the case must overflow fp16"
+    ref = ref.clamp(-65504.0, 65504.0)
+    y = conv_nd(_lib.F16, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25)
+    assert torch.isfinite(y).all()
+    assert float((y.abs() == 65504.0).float().mean()) > 0.02
+    assert float((y - ref).abs().max()) / 65504.0 < 2e-3
+
+
 CONV3D_CASES = [
     # name, Cin, Cout, stride, transposed, (D,H,W)
     ("c0_32_8", 32, 8, 1, False, (8, 12, 12)),
@@ -313,6 +340,42 @@ def test_conv3d_tile_layers(layer, dtype):
     y2 = from_channels_last(out2)
     assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
     assert torch.isnan(y2[1]).any()
+
+
+@pytest.mark.parametrize("layer", [1, 2, 8])
+def test_conv3d_tile_fp16_stores_saturate(layer):
+    """Halo-tile 3-D convs, fp16 storage: overflowing results land on +-65504, never on inf."""
+    from gpu_util import to_channels_last, from_channels_last, host_f32
+    lib = _lib.load()
+    Cin, Cout, stride, tr = C3T[layer]
+    g = torch.Generator().manual_seed(200 + layer)
+    N, D, H, W = 2, 6, 20, 12
+    x = (torch.randn(N, Cin, D, H, W, generator=g) * 3000.0).half().float()
+    w = (torch.randn(Cin, Cout, 3, 3, 3, generator=g) if tr else torch.randn(Cout, Cin, 3, 3, 3, generator=g)) * 30.0 / np.sqrt(Cin * 27)
+    scale = torch.ones(Cout)
+    shift = torch.zeros(Cout)
+    wf = w.half().float()
+    ref = F.conv_transpose3d(x, wf, None, 2, 1, 1) if tr else F.conv3d(x, wf, None, stride, 1)
+    ref = F.relu(ref)
+    res = None
+    if tr:
+        res = (torch.randn(ref.shape, generator=g) * 100.0).half().float()
+        ref = ref + res
+    assert float((ref > 65504.0).float().mean()) > 0.005
+    ref = ref.clamp(-65504.0, 65504.0)
+    xd = to_channels_last(x, _lib.F16)
+    rd = to_channels_last(res, _lib.F16) if res is not None else None
+    out = torch.full(tuple(ref.permute(0, 2, 3, 4, 1).shape), float("nan"), dtype=torch.float16, device="cuda")
+    wa, wp = host_f32(w)
+    sa, sp = host_f32(scale)
+    ha, hp = host_f32(shift)
+    _lib.check(lib.rgbm_conv3d_tile(layer, _lib.F16, _lib.ptr(xd), N, D, H, W, wp, sp, hp, _lib.ptr(rd), _lib.ptr(out),
+                                    _lib.stream_ptr()), "rgbm_conv3d_tile")
+    torch.cuda.synchronize()
+    y = from_channels_last(out)
+    assert torch.isfinite(y).all()
+    assert float((y == 65504.0).float().mean()) > 0.005
+    assert float((y - ref).abs().max()) / 65504.0 < 2e-3
 
 
 def _sweep_case(B, D, H, W, seed, singular_pose=None):
