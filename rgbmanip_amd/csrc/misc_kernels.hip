@@ -152,19 +152,19 @@ __device__ __forceinline__ void st_nt(T* p, const uint4& v) {          // stream
   __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(p));
 }
 
-// Exact x2 case (PSPUpsample, pspnet.py:100-107): one thread produces the 2 x 4 output block of the input pixel pair (i, j),
-// (i, j+1).  In the interior its eight outputs tap rows i-1..i+1 and columns j-1..j+2: 12 chunk loads per 8 outputs instead
-// of 32 (the generic kernel is bound by L2 -> CU traffic, 4 x the output bytes; the 2 x 2 block of the first version moved
-// 2.25 x, this one 1.5 x).  Pairs whose taps differ (first row / column, float rounding at the last, odd width) take the
-// generic 4-loads-per-output path.  Same weights and the same fused-multiply-add sequence (bilerp) as the generic kernel:
-// identical results.
+// Exact x2 case (PSPUpsample, pspnet.py:100-107): one thread produces the 4 x 4 output block of the 2 x 2 input pixels
+// (i..i+1, j..j+1).  In the interior its sixteen outputs tap rows i-1..i+2 and columns j-1..j+2: 16 chunk loads per 16
+// outputs instead of 64 (the generic kernel is bound by L2 -> CU traffic, 4 x the output bytes; a 2 x 2 block per thread
+// moved 2.25 x, 2 x 4 moved 1.5 x, this one 1 x).  Blocks whose taps differ (first row / column, float rounding at the last,
+// odd height or width) take the generic 4-loads-per-output path.  Same weights and the same fused-multiply-add sequence
+// (bilerp) as the generic kernel: identical results.
 template <typename T>
 __global__ __launch_bounds__(256) void resize2x_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int V, int Hs, int Ws, int C,
                                                             int ldo, int ch_off, float sy, float sx) {
   constexpr int E = 16 / sizeof(T);
   const int cpp = C / E, Ho = 2 * Hs, Wo = 2 * Ws;
-  const int Wp = (Ws + 1) >> 1;                                  // pixel pairs per input row
-  const long long total = (long long)V * Hs * Wp * cpp;
+  const int Hp = (Hs + 1) >> 1, Wp = (Ws + 1) >> 1;              // 2 x 2 input blocks per column / row
+  const long long total = (long long)V * Hp * Wp * cpp;
   // consecutive workgroup ids land on different XCDs (8, each with its own L2): give every XCD one contiguous eighth of the
   // 256-thread chunks, so that the image rows neighbouring chunks share are fetched into one L2 instead of up to three
   const long long nchunk = (total + 255) / 256, per_xcd = (nchunk + 7) / 8;
@@ -178,55 +178,59 @@ __global__ __launch_bounds__(256) void resize2x_ac_kernel(const T* __restrict__ 
     const int cc = (int)(u - pp * (unsigned)cpp);
     const unsigned row = pp / (unsigned)Wp;
     const int j = 2 * (int)(pp - row * (unsigned)Wp);
-    const unsigned vv = row / (unsigned)Hs;
-    const int i = (int)(row - vv * (unsigned)Hs);
+    const unsigned vv = row / (unsigned)Hp;
+    const int i = 2 * (int)(row - vv * (unsigned)Hp);
     const long long v = vv;
     const T* base = in + v * Hs * Ws * C + cc * E;
     T* obase = out + (v * Ho * Wo) * ldo + ch_off + cc * E;
-    const int npx = j + 1 < Ws ? 2 : 1;                            // odd width: the last pair holds one pixel
-    const Lerp ly0 = lerp_ac(2 * i, Hs, sy), ly1 = lerp_ac(2 * i + 1, Hs, sy);
-    Lerp lx[4];
+    const int nrow = i + 1 < Hs ? 4 : 2, ncol = j + 1 < Ws ? 4 : 2;   // odd size: the last block holds one input row / column
+    Lerp ly[4], lx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lx[k] = lerp_ac(min(2 * j + k, Wo - 1), Ws, sx);
-    bool fast = npx == 2 && ly0.i0 == i - 1 && ly0.i1 == i && ly1.i0 == i && ly1.i1 == i + 1;
+    for (int k = 0; k < 4; ++k) {
+      ly[k] = lerp_ac(min(2 * i + k, Ho - 1), Hs, sy);
+      lx[k] = lerp_ac(min(2 * j + k, Wo - 1), Ws, sx);
+    }
+    bool fast = nrow == 4 && ncol == 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) fast = fast && lx[k].i0 == j - 1 + ((k + 1) >> 1) && lx[k].i1 == j + ((k + 1) >> 1);
+    for (int k = 0; k < 4; ++k)
+      fast = fast && ly[k].i0 == i - 1 + ((k + 1) >> 1) && ly[k].i1 == i + ((k + 1) >> 1) &&
+             lx[k].i0 == j - 1 + ((k + 1) >> 1) && lx[k].i1 == j + ((k + 1) >> 1);
     if (fast) {
-      uint4 p[3][4];
+      uint4 p[4][4];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           p[a][b] = *reinterpret_cast<const uint4*>(base + ((long long)(i - 1 + a) * Ws + (j - 1 + b)) * C);
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const Lerp ly = dy ? ly1 : ly0;
+      for (int m = 0; m < 4; ++m) {
+        const int r0 = (m + 1) >> 1;                                 // upper tap row of output row 2i+m, relative to i-1
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int c0 = (k + 1) >> 1;                               // left tap column of output column 2j+k, relative to j-1
           float ta[E], tb[E], tc[E], td[E], r[E];
-          unpack_chunk(p[dy][c0], ta, T());
-          unpack_chunk(p[dy][c0 + 1], tb, T());
-          unpack_chunk(p[dy + 1][c0], tc, T());
-          unpack_chunk(p[dy + 1][c0 + 1], td, T());
+          unpack_chunk(p[r0][c0], ta, T());
+          unpack_chunk(p[r0][c0 + 1], tb, T());
+          unpack_chunk(p[r0 + 1][c0], tc, T());
+          unpack_chunk(p[r0 + 1][c0 + 1], td, T());
 #pragma unroll
-          for (int e = 0; e < E; ++e) r[e] = bilerp(ta[e], tb[e], tc[e], td[e], lx[k], ly);
-          st_nt(obase + ((long long)(2 * i + dy) * Wo + 2 * j + k) * ldo, pack_chunk(r, T()));
+          for (int e = 0; e < E; ++e) r[e] = bilerp(ta[e], tb[e], tc[e], td[e], lx[k], ly[m]);
+          st_nt(obase + ((long long)(2 * i + m) * Wo + 2 * j + k) * ldo, pack_chunk(r, T()));
         }
       }
     } else {
-      for (int dy = 0; dy < 2; ++dy) {
-        const Lerp ly = dy ? ly1 : ly0;
-        for (int k = 0; k < 2 * npx; ++k) {
+      for (int m = 0; m < nrow; ++m) {
+        const Lerp lym = lerp_ac(2 * i + m, Hs, sy);
+        for (int k = 0; k < ncol; ++k) {
           const Lerp lxk = lerp_ac(2 * j + k, Ws, sx);
           float a[E], b[E], c[E], dd[E], r[E];
-          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lxk.i0) * C), a, T());
-          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * Ws + lxk.i1) * C), b, T());
-          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lxk.i0) * C), c, T());
-          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * Ws + lxk.i1) * C), dd, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)lym.i0 * Ws + lxk.i0) * C), a, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)lym.i0 * Ws + lxk.i1) * C), b, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)lym.i1 * Ws + lxk.i0) * C), c, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)lym.i1 * Ws + lxk.i1) * C), dd, T());
 #pragma unroll
-          for (int e = 0; e < E; ++e) r[e] = bilerp(a[e], b[e], c[e], dd[e], lxk, ly);
-          st_nt(obase + ((long long)(2 * i + dy) * Wo + 2 * j + k) * ldo, pack_chunk(r, T()));
+          for (int e = 0; e < E; ++e) r[e] = bilerp(a[e], b[e], c[e], dd[e], lxk, lym);
+          st_nt(obase + ((long long)(2 * i + m) * Wo + 2 * j + k) * ldo, pack_chunk(r, T()));
         }
       }
     }
@@ -240,7 +244,7 @@ int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int H
   const float sy = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
   const float sx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
   if (Ho == 2 * Hs && Wo == 2 * Ws && Hs >= 2 && Ws >= 2 && (long long)V * Hs * Ws * (C / E) < (1ll << 31) && !(g_debug_flags & 512)) {
-    const long long blocks = (long long)V * Hs * ((Ws + 1) / 2) * (C / E);      // one thread per input pixel pair and 16-byte chunk
+    const long long blocks = (long long)V * ((Hs + 1) / 2) * ((Ws + 1) / 2) * (C / E);      // one thread per 2 x 2 input block and 16-byte chunk
     if (dtype == BF16)
       hipLaunchKernelGGL(resize2x_ac_kernel<unsigned short>, dim3(grid_for(blocks)), dim3(256), 0, s, (const unsigned short*)in,
                          (unsigned short*)out, V, Hs, Ws, C, ldo, ch_off, sy, sx);

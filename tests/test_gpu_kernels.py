@@ -486,7 +486,7 @@ def test_conv0_sweep_fp16_blend_saturates():
 @pytest.mark.parametrize("dtype", [_lib.F32, _lib.BF16])
 @pytest.mark.parametrize("shape", [(3, 28, 28, 64), (2, 7, 5, 128), (1, 2, 2, 8)])
 def test_resize_x2_kernel_identical_to_generic(dtype, shape):
-    """The 2x4-block upsample kernel (12 loads per 8 outputs) against the generic bilinear kernel (debug flag 512): bit-identical."""
+    """The 4x4-block upsample kernel (16 loads per 16 outputs) against the generic bilinear kernel (debug flag 512): bit-identical."""
     from gpu_util import TORCH_DT
     lib = _lib.load()
     V, H, W, Cn = shape
