@@ -64,11 +64,11 @@ static int init_conv3d_bn(ConvLayer& L, int dtype, const StateDict& sd, const st
 }
 
 static int init_linear(ConvLayer& L, const StateDict& sd, const std::string& p, int Cin, int Cout, int act, int Cin_pad,
-                       int Cout_pad, const float* w_override = nullptr) {
+                       int Cout_pad, const float* w_override = nullptr, int ldtype = F32) {
   GET(w, p + ".weight"); GET(b, p + ".bias");
   ConvGeom g;
   g.Cin = Cin; g.Cout = Cout; g.act = act;
-  return L.init(F32, g, w_override ? w_override : w->data, b->data, nullptr, nullptr, Cin_pad, Cout_pad);
+  return L.init(ldtype, g, w_override ? w_override : w->data, b->data, nullptr, nullptr, Cin_pad, Cout_pad);
 }
 
 int AdaPose::create(const StateDict& sd, int dtype_) {
@@ -153,19 +153,19 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
   if (int rc = init_linear(nh[2], sd, "nocs_head.4", 64, 3, ACT_TANH, 64, 4)) return rc;
   if (int rc = init_linear(npm[0], sd, "nocs_pts_mlp.0", 3, 32, ACT_RELU, 4, 32)) return rc;
   if (int rc = init_linear(npm[1], sd, "nocs_pts_mlp.2", 32, 64, ACT_RELU, 32, 64)) return rc;
-  if (int rc = init_linear(pm1[0], sd, "pose_mlp1.0", 96, 128, ACT_RELU, 96, 128)) return rc;
-  if (int rc = init_linear(pm1[1], sd, "pose_mlp1.2", 128, 128, ACT_RELU, 128, 128)) return rc;
+  if (int rc = init_linear(pm1[0], sd, "pose_mlp1.0", 96, 128, ACT_RELU, 96, 128, nullptr, pose_dtype())) return rc;
+  if (int rc = init_linear(pm1[1], sd, "pose_mlp1.2", 128, 128, ACT_RELU, 128, 128, nullptr, pose_dtype())) return rc;
   {
     // pose_mlp2.0 sees cat(point feature[128], global mean[128]); the global half becomes a per-view bias
     GET(w, "pose_mlp2.0.weight"); GET(b, "pose_mlp2.0.bias");
     RGBM_REQUIRE(w->numel() == 256 * 256, "pose_mlp2.0 shape");
     std::vector<float> wl(256 * 128);
     for (int o = 0; o < 256; ++o) for (int i = 0; i < 128; ++i) wl[o * 128 + i] = w->data[o * 256 + i];
-    if (int rc = init_linear(pm2[0], sd, "pose_mlp2.0", 128, 256, ACT_RELU, 128, 256, wl.data())) return rc;
+    if (int rc = init_linear(pm2[0], sd, "pose_mlp2.0", 128, 256, ACT_RELU, 128, 256, wl.data(), pose_dtype())) return rc;
     if (upload_f32(w->data, 256 * 256, &pm2_0_wfull)) return -2;
     if (upload_f32(b->data, 256, &pm2_0_bias)) return -2;
   }
-  if (int rc = init_linear(pm2[1], sd, "pose_mlp2.2", 256, 256, ACT_RELU, 256, 256)) return rc;
+  if (int rc = init_linear(pm2[1], sd, "pose_mlp2.2", 256, 256, ACT_RELU, 256, 256, nullptr, pose_dtype())) return rc;
   const char* hn[3] = {"rotation_estimator", "translation_estimator", "size_estimator"};
   const int hout[3] = {6, 3, 3};
   for (int h = 0; h < 3; ++h) {
@@ -220,6 +220,7 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   bf.nocs4 = (float*)A.alloc(VP * 4 * 4);
   bf.N32 = (float*)A.alloc(VP * 32 * 4);
   bf.PF96 = (float*)A.alloc(VP * 96 * 4);
+  bf.PF96h = pose_dtype() == F16 ? A.alloc(VP * 96 * 2) : nullptr;
   bf.prob = (float*)A.alloc(VP * n_depth * 4);
   bf.depth = (float*)A.alloc(VP * 4);
   bf.Q128a = (float*)A.alloc(VP * 128 * 4);
@@ -443,13 +444,21 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
 
   // ---- depth-guided fusion + pose regression (network_v5.py:457-508) ----
   if (int rc = launch_fuse_points(dtype, bf.feat, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s)) return rc;
-  if (int rc = pm1[0].run(bf.PF96, bf.Q128a, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  // bf16 nets: the four big per-point layers of the pose MLP run in fp16 storage (fp32 they took 1.8 ms per 512 views at
+  // 78 TFLOP/s on the fp32 matrix path); PF96 is produced in fp32 by its two writers and converted once
+  const int pdt = pose_dtype();
+  const void* pf_in = bf.PF96;
+  if (pdt == F16) {
+    if (int rc = launch_f32_to_f16(bf.PF96, bf.PF96h, (long long)VP * 96, s)) return rc;
+    pf_in = bf.PF96h;
+  }
+  if (int rc = pm1[0].run(pf_in, bf.Q128a, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(bf.Q128b, bf.glob, V, P, 128, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, V, P, 128, s)) return rc;
   if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, V, 128, 256, 256, 128, 0, s)) return rc;
   if (int rc = pm2[0].run(bf.Q128b, bf.G256a, V, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
   if (int rc = pm2[1].run(bf.G256a, bf.G256b, V, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(bf.G256b, bf.pf2, V, P, 256, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, V, P, 256, s)) return rc;
   float* hout[3] = {bf.r6, bf.tv, bf.sv};
   const int hdim[3] = {6, 3, 3};
   for (int h = 0; h < 3; ++h) {

@@ -20,6 +20,11 @@ struct Arena {
 
 struct AdaPose {
   int dtype = F32;
+  // storage type of the pose MLP (pose_mlp1 / pose_mlp2, network_v5.py:470-494): fp16 for the bf16 throughput mode (its
+  // activations are O(1); fp16 per-point features keep 11 mantissa bits, the means over points stay fp32, and the rotation
+  // error stays at the 2e-3 the bf16 backbone sets), fp32 for fp32 nets and for the fp16 accuracy mode (where fp16 here would
+  // raise the rotation error from 4e-5 to 3e-4)
+  int pose_dtype() const { return dtype == BF16 ? F16 : F32; }
   int img = 224, n_pts = 1024, n_depth = 24;
   int img_cpad = 4;
   int max_chunk = 512;           // views per cost-volume chunk (bounds the workspace: ~80 MB per view in bf16; 512 = batch 256 in one chunk)
@@ -48,6 +53,7 @@ struct AdaPose {
   struct Buffers {
     float *Pviews, *homog; int* choose; void* feat;
     float *X0, *X1, *H128, *H64, *nocs4, *N32, *PF96, *prob, *depth, *Q128a, *Q128b, *G256a, *G256b;
+    void* PF96h;                       // fp16 copy of PF96 (pose MLP input of 16-bit nets)
     float *glob, *vbias, *pf2, *h1, *h2, *r6, *R, *tv, *sv;
     void *imgpad, *c1, *lb[4], *pooled[4], *stage[4], *cat, *ups, *u1, *u2, *u3;
     void *vol, *c[7], *u7, *u9, *u11;

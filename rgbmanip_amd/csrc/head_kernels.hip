@@ -243,21 +243,27 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
 }
 
 // ---------------------------------------------------------------- mean over the P points of each view
-// in [V*P][C] fp32 -> out [V][C].  grid = V x ceil(C/64) blocks of 256 threads (64 channels x 4 point slices).
-__global__ __launch_bounds__(256) void mean_points_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int C) {
+// in [V*P][C] (fp32, or fp16 for the pose MLP of 16-bit nets) -> out [V][C] fp32.  grid = V x ceil(C/64) blocks of 256
+// threads (64 channels x 4 point slices).
+template <typename TI>
+__global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__ in, float* __restrict__ out, int P, int C) {
   __shared__ float part[4][64];
   const int v = blockIdx.x, cb = blockIdx.y * 64;
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
   float acc = 0.f;
   if (cb + c < C)
-    for (int p = sl; p < P; p += 4) acc += in[((long long)v * P + p) * C + cb + c];
+    for (int p = sl; p < P; p += 4) acc += Elem<TI>::ld(in + ((long long)v * P + p) * C + cb + c);
   part[sl][c] = acc;
   __syncthreads();
   if (sl == 0 && cb + c < C) out[(long long)v * C + cb + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)P;
 }
 
-int launch_mean_points(const float* in, float* out, int V, int P, int C, hipStream_t s) {
-  hipLaunchKernelGGL(mean_points_kernel, dim3(V, (C + 63) / 64), dim3(256), 0, s, in, out, P, C);
+int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s) {
+  RGBM_REQUIRE(dtype == F32 || dtype == F16, "mean_points: fp32 or fp16 input");
+  if (dtype == F16)
+    hipLaunchKernelGGL(mean_points_kernel<f16_t>, dim3(V, (C + 63) / 64), dim3(256), 0, s, (const f16_t*)in, out, P, C);
+  else
+    hipLaunchKernelGGL(mean_points_kernel<float>, dim3(V, (C + 63) / 64), dim3(256), 0, s, (const float*)in, out, P, C);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

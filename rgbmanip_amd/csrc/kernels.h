@@ -29,7 +29,8 @@ int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, co
 int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
                        const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
                        hipStream_t s);
-int launch_mean_points(const float* in, float* out, int V, int P, int C, hipStream_t s);
+int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s);      // dtype of `in`: F32 or F16
+int launch_f32_to_f16(const float* in, void* out, long long n, hipStream_t s);
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);

@@ -544,4 +544,20 @@ int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_
   return 0;
 }
 
+// ---------------------------------------------------------------- fp32 -> fp16 copy (input of the fp16 pose MLP), 8 elements per thread
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ in, f16_t* __restrict__ out, long long n8) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(in + i * 8), b = *reinterpret_cast<const float4*>(in + i * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(out + i * 8) = pack_chunk(v, f16_t());
+  }
+}
+
+int launch_f32_to_f16(const float* in, void* out, long long n, hipStream_t s) {
+  RGBM_REQUIRE(n % 8 == 0, "f32_to_f16: element count must be a multiple of 8");
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, in, (f16_t*)out, n / 8);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace rgbm
