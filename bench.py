@@ -24,7 +24,9 @@ import numpy as np
 import torch
 
 GFLOP_PER_POSE = 163.68          # hooks on the reference module, 2*MAC, full 10-output forward
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks (the profiler rows of the 16-bit kernels are labelled bf16)
+# MI355X_MICROARCH.md dense MFMA peaks (the profiler rows of the 16-bit kernels are labelled bf16).  bf16x3 spends three bf16
+# MFMAs per algorithmic multiply-add (hi*hi + lo*hi + hi*lo), so its ceiling for ALGORITHMIC flops is a third of the bf16 peak
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 
 
 
@@ -79,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
     ap.add_argument("--ppo-envs", type=int, default=512, help="envs per GPU for the PPO leg (0 = skip it)")
@@ -87,7 +89,7 @@ def main():
                     help="full: ControlInterface over the synthetic MultiVecEnv (480x640 frames); bank: pre-cropped 224x224 view bank")
     ap.add_argument("--no-prepare", action="store_true", help="skip the device-side prepare_model_input leg")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-object (4 heads) leg")
-    ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32"], help="storage type of the mixed-object leg (configs[4] names fp16)")
+    ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32", "bf16x3"], help="storage type of the mixed-object leg (configs[4] names fp16)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     args = ap.parse_args()

@@ -24,6 +24,9 @@ extern "C" {
 #define RGBM_F32 0
 #define RGBM_BF16 1
 #define RGBM_F16 2       /* IEEE half storage (saturating stores), fp32 accumulation; same kernels as RGBM_BF16 */
+#define RGBM_BF16X3 3    /* split pairs: every value kept as bf16 hi + bf16 lo (16 significand bits, 4 bytes, fp32 tensor layout with
+                            each 16-byte chunk of 4 channels holding {hi01, hi23, lo01, lo23}); products hi*hi + lo*hi + hi*lo on
+                            the bf16 matrix pipe, fp32 accumulation: fp32-level results (1e-4 gate) at 3 MFMAs per product */
 
 int rgbm_version(void);
 const char* rgbm_last_error(void);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBM_HIP_LIB selects another build of the same library (kernel ablation builds made by tools/abl_sweep.sh)
 LIB_PATH = os.environ.get("RGBM_HIP_LIB") or os.path.join(_HERE, "librgbm_hip.so")
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
@@ -39,7 +39,8 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<unsigned short, 64, 32, 1, 8, 8, 1, true, false> (conv7)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 2, 8, 8, 1, true, false> (conv9)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, true, false> (conv11)", "bf16"),
-] + [("unused", "bf16")] * 6
+] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
+     ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<bx3_t>", "bf16x3"), ("unused", "bf16x3"), ("unused", "bf16x3")]
 
 
 class RgbmError(RuntimeError):

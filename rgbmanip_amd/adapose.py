@@ -17,7 +17,7 @@ import torch
 from . import _lib
 
 _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16,
-           "fp16": _lib.F16, "f16": _lib.F16, "float16": _lib.F16}
+           "fp16": _lib.F16, "f16": _lib.F16, "float16": _lib.F16, "bf16x3": _lib.BF16X3}
 
 
 class AdaPoseNet:

@@ -73,7 +73,7 @@ static int init_linear(ConvLayer& L, const StateDict& sd, const std::string& p, 
 
 int AdaPose::create(const StateDict& sd, int dtype_) {
   dtype = dtype_;
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   img_cpad = E;                              // RGB padded to one 16-byte chunk
   const std::string fe = "img_extractor.feats.";
   if (int rc = init_conv2d(conv1, dtype, sd, fe + "conv1.weight", nullptr, 3, 64, 7, 2, 3, 1, ACT_RELU, 0.f, img_cpad)) return rc;
@@ -132,7 +132,7 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
-      if (i == 0 && dtype != F32) {
+      if (i == 0 && dtype_size(dtype) == 2) {
         // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip)
         conv0_sweep_pack(w->data, scale.data(), packed);
         if (upload_packed(packed, dtype, &sweep_w)) return -2;
@@ -330,6 +330,7 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
 int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const {
   const int S = img, D = n_depth, P = n_pts;
   const int Vc0 = chunk_views(V);
+  const bool b16 = dtype_size(dtype) == 2;      // 16-bit storage: the depth-sweeping conv0, implicit-GEMM conv6 and the sparse tail exist for these
   // halo-tiled path (cost_impl >= 1): one launch per layer; conv0 optionally builds its input on the fly
   auto tile = [&](int layer, const void* in, void* out, const void* res, int Vc, int Di, int Hi, int Wi, int Do, int Ho,
                   int Wo, bool transposed, int v0) -> int {
@@ -343,11 +344,11 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
     d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
     // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
-    d.prof_variant = layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
+    d.prof_variant = dtype == BF16X3 ? (layer == 10 ? 28 : 27) : layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
     d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
                    (double)dtype_size(dtype);
-    if (layer == 10 && cost_impl == 3 && dtype != F32 && sweep_w && !(dtype == F16 && (g_debug_flags & 4096))) {
+    if (layer == 10 && cost_impl == 3 && b16 && sweep_w && !(dtype == F16 && (g_debug_flags & 4096))) {
       d.wgt = sweep_w;
       return launch_conv0_sweep(d, dtype, s);
     }
@@ -366,7 +367,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0)) return rc;
-    if (cost_impl == 3 && dtype != F32 && igemm_conv6) {
+    if (cost_impl == 3 && b16 && igemm_conv6) {
       // conv6 (64 -> 64, K = 27 x 64): a plain GEMM shape, 2.7x faster on the role-specialised implicit-GEMM kernel
       if (int rc = c3d[6].run(bf.c[5], bf.c[6], Vc, D / 8, S / 8, S / 8, 64, nullptr, RES_NONE, nullptr, 0, s)) return rc;
     } else {
@@ -374,7 +375,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     }
     if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
     if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
-    if (cost_impl == 3 && dtype != F32 && sparse_tail) {
+    if (cost_impl == 3 && b16 && sparse_tail) {
       // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
       if (int rc = launch_prob_sparse(bf.u9, bf.c[0], t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc,
                                       B, P, D, S, S, dtype, s)) return rc;

@@ -24,7 +24,7 @@ const char* rgbm_last_error(void) { return last_error_cstr(); }
 
 int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode) {
   RGBM_REQUIRE(h != nullptr && w != nullptr && n_w > 0, "create arguments");
-  RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16 || dtype == RGBM_F16, "dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16 || dtype == RGBM_F16 || dtype == RGBM_BF16X3, "dtype must be 0 (fp32), 1 (bf16), 2 (fp16) or 3 (bf16x3)");
   RGBM_REQUIRE(norm_mode == 0, "only eval-mode (folded) BatchNorm is implemented");
   RGBM_CHECK_HIP(hipSetDevice(device));
   StateDict sd;

@@ -7,7 +7,10 @@
 
 namespace rgbm {
 
-enum DType { F32 = 0, BF16 = 1, F16 = 2 };      // storage type of activations / weights; accumulation is always fp32
+// storage type of activations / weights; accumulation is always fp32.  BF16X3: a 4-byte slot per value holding the value
+// as a bf16 pair hi + lo (16 significand bits), multiplied as hi*hi + lo*hi + hi*lo on the bf16 matrix pipe — the mode that
+// meets the reference's fp32 results to 1e-4 at 3 MFMAs per product instead of the 16x slower fp32 MFMA (see bx3_t below)
+enum DType { F32 = 0, BF16 = 1, F16 = 2, BF16X3 = 3 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2, ACT_TANH = 3 };
 enum ResMode { RES_NONE = 0, RES_PRE_ACT = 1, RES_POST_ACT = 2 };
 
@@ -38,7 +41,8 @@ int fail(const char* what, const char* file, int line);
     }                                                                                    \
   } while (0)
 
-static inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 2; }
+static inline size_t dtype_size(int dt) { return (dt == F32 || dt == BF16X3) ? 4 : 2; }
+static inline int dtype_chunk(int dt) { return 16 / (int)dtype_size(dt); }      // elements per 16-byte chunk
 static inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -78,6 +82,51 @@ template <> struct Elem<f16_t> {
   __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
   __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)(v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f)); }
 };
+// ---- BF16X3 ("split pair") storage -------------------------------------------------------------------------
+// Tensor layout, strides and indexing are those of fp32 (4 bytes per element, 4 elements per 16-byte chunk), but a chunk
+// of channels c0..c3 holds   dword0 = hi(c0) | hi(c1) << 16,  dword1 = hi(c2) | hi(c3) << 16,
+//                            dword2 = lo(c0) | lo(c1) << 16,  dword3 = lo(c2) | lo(c3) << 16
+// with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): x is kept to 16 significand bits (relative error
+// <= 2^-17) in the fp32 exponent range (no saturation, no denormal issue).  The first 8 bytes of a chunk are directly a
+// K=4-per-lane bf16 MFMA operand of the hi parts, the second 8 bytes the same for the lo parts; two chunks give the
+// K=8-per-lane operands of the 16x16x32 instruction.  A product of two such values on the matrix pipe is
+// hi*hi + lo*hi + hi*lo (the lo*lo term, <= 2^-18 relative, is dropped); accumulation is fp32.
+struct bx3_t { unsigned raw; };      // one 4-byte slot; never read or written alone except through Elem<bx3_t>
+
+// fp32 -> split chunk and back (4 values)
+__device__ __forceinline__ uint4 bx3_split4(float a, float b, float c, float d) {
+  uint4 o;
+  o.x = pack2_bf16(a, b);
+  o.y = pack2_bf16(c, d);
+  o.z = pack2_bf16(a - __uint_as_float(o.x << 16), b - __uint_as_float(o.x & 0xffff0000u));     // the differences are exact
+  o.w = pack2_bf16(c - __uint_as_float(o.y << 16), d - __uint_as_float(o.y & 0xffff0000u));
+  return o;
+}
+__device__ __forceinline__ void bx3_join4(const uint4& c, float* v) {
+  v[0] = __uint_as_float(c.x << 16) + __uint_as_float(c.z << 16);
+  v[1] = __uint_as_float(c.x & 0xffff0000u) + __uint_as_float(c.z & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16) + __uint_as_float(c.w << 16);
+  v[3] = __uint_as_float(c.y & 0xffff0000u) + __uint_as_float(c.w & 0xffff0000u);
+}
+template <> struct Elem<bx3_t> {
+  static constexpr int kPerChunk = 4;
+  // single element (debug / fetch paths only): halves e of dword pair (e>>1, 2 + (e>>1)) of the element's chunk
+  __device__ static __forceinline__ float ld(const bx3_t* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned short* ch = reinterpret_cast<const unsigned short*>(a & ~15ull);
+    const int e = (int)((a >> 2) & 3);
+    return bf16_to_f32(ch[e]) + bf16_to_f32(ch[4 + e]);
+  }
+  __device__ static __forceinline__ void st(bx3_t* p, float v) {
+    const unsigned long long a = (unsigned long long)p;
+    unsigned short* ch = reinterpret_cast<unsigned short*>(a & ~15ull);
+    const int e = (int)((a >> 2) & 3);
+    const unsigned short h = f32_to_bf16(v);
+    ch[e] = h;
+    ch[4 + e] = f32_to_bf16(v - bf16_to_f32(h));
+  }
+};
+
 // fp16 stores saturate at +-65504 instead of overflowing to inf (NaN stays NaN: fminf/fmaxf return the other operand for a NaN
 // input, so NaN is routed explicitly)
 __device__ __forceinline__ float sat_f16(float v) { return v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f); }
@@ -110,6 +159,10 @@ __device__ __forceinline__ void store4(unsigned short* p, const float v[4]) {
   t.y = pack2_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
+__device__ __forceinline__ void load4(const bx3_t* p, float v[4]) { bx3_join4(*reinterpret_cast<const uint4*>(p), v); }      // p: chunk-aligned
+__device__ __forceinline__ void store4(bx3_t* p, const float v[4]) { *reinterpret_cast<uint4*>(p) = bx3_split4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, bx3_t /*tag*/) { bx3_join4(c, v); }
+__device__ __forceinline__ uint4 pack_chunk(const float* v, bx3_t /*tag*/) { return bx3_split4(v[0], v[1], v[2], v[3]); }
 // unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
 __device__ __forceinline__ void unpack_chunk(const uint4& c, float* v, float /*tag*/) {
   v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y); v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
@@ -141,6 +194,25 @@ __device__ __forceinline__ uint4 pack_chunk(const float* v, unsigned short /*tag
   c.z = pack2_bf16(v[4], v[5]);
   c.w = pack2_bf16(v[6], v[7]);
   return c;
+}
+
+// One 16-byte bx3 chunk per lane on each side (4 k values, hi + lo): c += a*b as hi*hi + lo*hi + hi*lo on
+// v_mfma_f32_16x16x16_bf16 (small terms first).  Lane group g of the MFMA holds k = 4g..4g+3 = the 4 channels of its chunk,
+// for A and B alike.
+typedef __attribute__((ext_vector_type(4))) short rgbm_s16x4;
+__device__ __forceinline__ f32x4 mma_bx3_k16(const uint4& a, const uint4& b, f32x4 c) {
+  const rgbm_s16x4 ah = __builtin_bit_cast(rgbm_s16x4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(rgbm_s16x4, make_uint2(a.z, a.w));
+  const rgbm_s16x4 bh = __builtin_bit_cast(rgbm_s16x4, make_uint2(b.x, b.y)), bl = __builtin_bit_cast(rgbm_s16x4, make_uint2(b.z, b.w));
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+  return c;
+}
+// Two chunks per lane and side (8 k values): the full-rate 16x16x32 instruction.  (a0, a1) and (b0, b1) must pair the same
+// two chunks of the K tile on both sides.
+__device__ __forceinline__ void bx3_pair(const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+  hi = make_uint4(c0.x, c0.y, c1.x, c1.y);
+  lo = make_uint4(c0.z, c0.w, c1.z, c1.w);
 }
 
 // ---- generic implicit-GEMM convolution descriptor (conv_igemm.hip) -------------------

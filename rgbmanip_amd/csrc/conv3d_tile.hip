@@ -39,6 +39,10 @@ template <> struct Mma3<float> {
   }
 };
 
+template <> struct Mma3<bx3_t> {      // split pairs (common.h): one chunk = 4 k values, hi*hi + lo*hi + hi*lo
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) { c = mma_bx3_k16(a, b, c); }
+};
+
 template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR>
 struct C3Cfg {
   static constexpr int E = 16 / sizeof(T);
@@ -332,7 +336,7 @@ static inline int c3_steps(int ntaps, int bpt) { return bpt >= 64 ? ntaps * (bpt
 // w: conv [Cout][Cin][27]; transposed [Cin][Cout][27].  Returns fp32 values (converted to the dtype by the caller).
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed) {
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   const int bpt = Cin * (int)dtype_size(dtype);
   const int spt = bpt >= 64 ? bpt / 64 : 1, tps = bpt >= 64 ? 1 : 64 / bpt;
   const int npass = transposed ? 8 : 1;
@@ -400,6 +404,7 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
   case L:                                                                                                          \
     return dtype == BF16  ? launch_c3<unsigned short, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)           \
            : dtype == F16 ? launch_c3<f16_t, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)                    \
+           : dtype == BF16X3 ? launch_c3<bx3_t, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s)                 \
                           : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s);
   switch (layer) {
     //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp

@@ -17,6 +17,7 @@
 // LDS rows are 128 B with a 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7) so that the 16 rows a
 // ds_read_b128 lane group touches land on 16 distinct 16-B bank slots.
 // bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); f32: v_mfma_f32_16x16x4_f32 (exact fp32).
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -45,6 +46,10 @@ template <> struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   }
+};
+
+template <> struct Mma<bx3_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) { c = mma_bx3_k16(a, b, c); }
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -251,7 +256,7 @@ int conv_ch_tile(int Cout) {
   if (Cout <= 64) return 64;
   return 128;
 }
-int conv_bk(int dtype) { return dtype == F32 ? 32 : 64; }
+int conv_bk(int dtype) { return 8 * dtype_chunk(dtype); }      // 128 bytes per row
 
 template <typename T, int BCH, int BPIX>
 static int launch_one(ConvDesc d, hipStream_t s) {
@@ -259,7 +264,7 @@ static int launch_one(ConvDesc d, hipStream_t s) {
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  const int variant = (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
+  const int variant = std::is_same<T, bx3_t>::value ? 26 : (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
   prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_kernel<T, BCH, BPIX>), dim3((unsigned)nblk), dim3(256), 0, s, d);
   prof_end_launch(s);
@@ -281,7 +286,7 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
   RGBM_REQUIRE(d.M > 0 && d.M < (1ll << 31), "conv M out of range");
   RGBM_REQUIRE(d.Cout % 4 == 0 && d.ldo % 4 == 0, "conv Cout/ldo must be multiples of 4");
   RGBM_REQUIRE(d.KT > 0 && d.Kpad == d.KT * conv_bk(dtype), "conv K padding mismatch");
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   RGBM_REQUIRE(d.Cin % E == 0, "conv Cin must be a multiple of the 16-byte chunk");
   if (d.lcin >= 0) {
     RGBM_REQUIRE((1 << d.lcin) == d.Cin, "conv lcin mismatch");
@@ -289,7 +294,8 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
     RGBM_REQUIRE(d.ntaps == 1, "linear-K mode needs a single tap");
   }
   if (!(g_debug_flags & 4)) return launch_conv_glds(d, dtype, s);      // default: LDS-DMA variant (conv_igemm_glds.hip)
-  return dtype == BF16 ? launch_t<unsigned short>(d, s) : dtype == F16 ? launch_t<f16_t>(d, s) : launch_t<float>(d, s);
+  return dtype == BF16 ? launch_t<unsigned short>(d, s) : dtype == F16 ? launch_t<f16_t>(d, s)
+         : dtype == BF16X3 ? launch_t<bx3_t>(d, s) : launch_t<float>(d, s);
 }
 
 }  // namespace rgbm

@@ -68,6 +68,15 @@ template <> struct MmaG<float> {
   }
 };
 
+template <> struct MmaG<bx3_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) { c = mma_bx3_k16(a, b, c); }
+};
+// profiler rows (prof.h) of the type-generic kernels
+template <typename T> constexpr int prof_row_generic(int bch) {
+  return std::is_same<T, bx3_t>::value ? 26 : (sizeof(T) == 2 ? 4 : 0) + (bch == 16 ? 0 : bch == 32 ? 1 : bch == 64 ? 2 : 3);
+}
+template <typename T> constexpr int prof_row_ws() { return std::is_same<T, bx3_t>::value ? 29 : sizeof(T) == 2 ? 13 : 12; }
+
 template <int N> struct IC { static constexpr int value = N; };
 
 __device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
@@ -708,6 +717,35 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
           for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if constexpr (std::is_same<T, bx3_t>::value) {
+      // split pairs: the two half-tile chunks of a lane (channels 4*lg.. and 16 + 4*lg..) together are the 8 k values of
+      // one 16x16x32 operand — hi parts and lo parts separately — so a K tile (32 channels) is 16 x 3 full-rate MFMAs
+      // (lo*hi, hi*lo, hi*hi; 16 independent accumulators between two uses of the same one)
+      for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RGBM_BARRIER();
+        load_half(st, 0, af0, bf0);
+        load_half(st, 1, af1, bf1);
+        uint4 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+        for (int a = 0; a < FM; ++a) bx3_pair(af0[a], af1[a], ah[a], al[a]);
+#pragma unroll
+        for (int b = 0; b < FN; ++b) bx3_pair(bf0[b], bf1[b], bh[b], bl[b]);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al[a], bh[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
+        st = st == 2 ? 0 : st + 1;
+      }
+    } else {
     for (int kt = 0; kt < KT; ++kt) {
       // every fragment read of the previous step has returned before the request waves may refill its stage
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -723,6 +761,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
       st = st == 2 ? 0 : st + 1;
     }
     mma_half(af1, bf1);
+    }
 
     // ---- epilogue of tile k (the request waves are already filling the ring for tile k+1) ----
     // All 16 residual reads of a lane are requested before the first one is used: written as load-use-store per
@@ -909,7 +948,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, sizeof(T) == 2 ? 13 : 12, d.algo_flops, d.algo_bytes);
+  prof_begin_launch(s, prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_ws_kernel<T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -1424,8 +1463,7 @@ static int launch_v3(ConvDesc d, hipStream_t s) {
     RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T, UNI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_done = true;
   }
-  const int variant = sizeof(T) == 2 ? 13 : 12;
-  prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
+  prof_begin_launch(s, prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_v3_kernel<T, UNI>), dim3((unsigned)nblk), dim3(512), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -1438,8 +1476,7 @@ static int launch_one_g(ConvDesc d, hipStream_t s) {
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  const int variant = (sizeof(T) == 2 ? 4 : 0) + (BCH == 16 ? 0 : BCH == 32 ? 1 : BCH == 64 ? 2 : 3);
-  prof_begin_launch(s, variant, d.algo_flops, d.algo_bytes);
+  prof_begin_launch(s, prof_row_generic<T>(BCH), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_glds_kernel<T, BCH, BPIX, UNI>), dim3((unsigned)nblk), dim3(256), 0, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -1484,7 +1521,8 @@ bool conv_ws64_eligible(const ConvDesc& d, int dtype) {
 }
 
 int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s) {
-  return dtype == BF16 ? launch_dtype_g<unsigned short>(d, s) : dtype == F16 ? launch_dtype_g<f16_t>(d, s) : launch_dtype_g<float>(d, s);
+  return dtype == BF16 ? launch_dtype_g<unsigned short>(d, s) : dtype == F16 ? launch_dtype_g<f16_t>(d, s)
+         : dtype == BF16X3 ? launch_dtype_g<bx3_t>(d, s) : launch_dtype_g<float>(d, s);
 }
 
 }  // namespace rgbm

@@ -38,6 +38,9 @@ int launch_gather_points(int dtype, const void* feat, const int* choose, float* 
   else if (dtype == F16)
     hipLaunchKernelGGL(gather_points_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)feat, choose,
                        out, V, P, HW, C);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(gather_points_kernel<bx3_t>, dim3(g), dim3(256), 0, s, (const bx3_t*)feat, choose,
+                       out, V, P, HW, C);
   else
     hipLaunchKernelGGL(gather_points_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)feat, choose, out, V, P, HW, C);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -125,6 +128,9 @@ int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, co
                        choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
   else if (dtype == F16)
     hipLaunchKernelGGL(prob_softmax_depth_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)u11, wprob,
+                       choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(prob_softmax_depth_kernel<bx3_t>, dim3(g), dim3(256), 0, s, (const bx3_t*)u11, wprob,
                        choose, depths, prob, depth_out, v0, Vc, B, P, D, H, W, classmajor);
   else
     hipLaunchKernelGGL(prob_softmax_depth_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)u11, wprob, choose, depths,
@@ -234,6 +240,9 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
                        homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
   else if (dtype == F16)
     hipLaunchKernelGGL((fuse_points_kernel<f16_t, true>), dim3(g), dim3(256), 0, s, (const f16_t*)feat,
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL((fuse_points_kernel<bx3_t, false>), dim3(g), dim3(256), 0, s, (const bx3_t*)feat,
                        homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
   else
     hipLaunchKernelGGL((fuse_points_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)feat, homog, depths,

@@ -38,6 +38,24 @@ int upload_packed(const std::vector<float>& w, int dtype, void** dev) {
     for (size_t i = 0; i < w.size(); ++i) h[i] = dtype == BF16 ? host_f32_to_bf16(w[i]) : host_f32_to_f16(w[i]);
     RGBM_CHECK_HIP(hipMalloc(dev, h.size() * 2));
     RGBM_CHECK_HIP(hipMemcpy(*dev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  } else if (dtype == BF16X3) {
+    // split-pair chunks (common.h, bx3_t): every 4 consecutive values become {hi01, hi23, lo01, lo23}
+    RGBM_REQUIRE(w.size() % 4 == 0, "bf16x3 weights: element count must be a multiple of 4");
+    std::vector<unsigned> h(w.size());
+    for (size_t i = 0; i < w.size(); i += 4) {
+      unsigned short hi[4], lo[4];
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = host_f32_to_bf16(w[i + e]);
+        unsigned u = (unsigned)hi[e] << 16;
+        float hf;
+        memcpy(&hf, &u, 4);
+        lo[e] = host_f32_to_bf16(w[i + e] - hf);
+      }
+      h[i] = hi[0] | ((unsigned)hi[1] << 16); h[i + 1] = hi[2] | ((unsigned)hi[3] << 16);
+      h[i + 2] = lo[0] | ((unsigned)lo[1] << 16); h[i + 3] = lo[2] | ((unsigned)lo[3] << 16);
+    }
+    RGBM_CHECK_HIP(hipMalloc(dev, h.size() * 4));
+    RGBM_CHECK_HIP(hipMemcpy(*dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   } else {
     RGBM_CHECK_HIP(hipMalloc(dev, w.size() * 4));
     RGBM_CHECK_HIP(hipMemcpy(*dev, w.data(), w.size() * 4, hipMemcpyHostToDevice));
@@ -51,7 +69,7 @@ int ConvLayer::init(int dtype_, const ConvGeom& g_, const float* w, const float*
   dtype = dtype_;
   Cin_pad = Cin_pad_;
   Cout_pad = Cout_pad_;
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   const int BK = conv_bk(dtype);
   RGBM_REQUIRE(Cin_pad % E == 0 && Cin_pad >= g.Cin, "Cin_pad");
   RGBM_REQUIRE(Cout_pad % 4 == 0 && Cout_pad >= g.Cout, "Cout_pad");
@@ -200,7 +218,7 @@ int ConvLayer::run_then_1x1(const ConvLayer& next, const void* in, void* mid, in
   const ConvGeom& ng = next.g;
   const bool is1x1 = !ng.transposed && ng.KD == 1 && ng.KH == 1 && ng.KW == 1 && ng.sd == 1 && ng.sh == 1 && ng.sw == 1 &&
                      ng.pd == 0 && ng.ph == 0 && ng.pw == 0 && next.packs.size() == 1;
-  if (allow_fuse && is1x1 && !g.transposed && dtype != F32 && next.dtype == dtype && next.Cin_pad == Cout_pad) {
+  if (allow_fuse && is1x1 && !g.transposed && dtype_size(dtype) == 2 && next.dtype == dtype && next.Cin_pad == Cout_pad) {
     ConvDesc d;
     if (int rc = build_desc(d, in, mid, N, Di, Hi, Wi, ldmid, nullptr, RES_NONE, nullptr, 0, 0)) return rc;
     d.w2 = next.packs[0].w; d.bias2 = next.bias; d.out2 = out2; d.ldo2 = ldo2; d.cout2 = next.Cout_pad;

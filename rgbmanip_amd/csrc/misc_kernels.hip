@@ -40,6 +40,9 @@ int launch_nchw_to_nhwc_pad(int dtype, const float* in, void* out, int V, int C,
   else if (dtype == F16)
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, s, in,
                        (f16_t*)out, V, C, H, W, Cp);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<bx3_t>, dim3(grid_for(total)), dim3(256), 0, s, in,
+                       (bx3_t*)out, V, C, H, W, Cp);
   else
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, (float*)out, V, C, H, W, Cp);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -80,7 +83,7 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
 
 int launch_maxpool3x3s2(int dtype, const void* in, void* out, int V, int H, int W, int C, hipStream_t s) {
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   RGBM_REQUIRE(C % E == 0, "maxpool channels");
   const long long total = (long long)V * Ho * Wo * (C / E);
   if (dtype == BF16)
@@ -89,6 +92,9 @@ int launch_maxpool3x3s2(int dtype, const void* in, void* out, int V, int H, int 
   else if (dtype == F16)
     hipLaunchKernelGGL(maxpool3x3s2_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, s,
                        (const f16_t*)in, (f16_t*)out, V, H, W, C, Ho, Wo);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<bx3_t>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const bx3_t*)in, (bx3_t*)out, V, H, W, C, Ho, Wo);
   else
     hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out, V,
                        H, W, C, Ho, Wo);
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void resize2x_ac_kernel(const T* __restrict__ 
 
 int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int Hs, int Ws, int C, int Ho, int Wo, int ldo,
                               int ch_off, hipStream_t s) {
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   RGBM_REQUIRE(C % E == 0 && ldo % E == 0 && ch_off % E == 0, "resize channel alignment");
   const float sy = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
   const float sx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
@@ -251,6 +257,9 @@ int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int H
     else if (dtype == F16)
       hipLaunchKernelGGL(resize2x_ac_kernel<f16_t>, dim3(grid_for(blocks)), dim3(256), 0, s, (const f16_t*)in,
                          (f16_t*)out, V, Hs, Ws, C, ldo, ch_off, sy, sx);
+    else if (dtype == BF16X3)
+      hipLaunchKernelGGL(resize2x_ac_kernel<bx3_t>, dim3(grid_for(blocks)), dim3(256), 0, s, (const bx3_t*)in,
+                         (bx3_t*)out, V, Hs, Ws, C, ldo, ch_off, sy, sx);
     else
       hipLaunchKernelGGL(resize2x_ac_kernel<float>, dim3(grid_for(blocks)), dim3(256), 0, s, (const float*)in, (float*)out, V, Hs,
                          Ws, C, ldo, ch_off, sy, sx);
@@ -264,6 +273,9 @@ int launch_resize_bilinear_ac(int dtype, const void* in, void* out, int V, int H
   else if (dtype == F16)
     hipLaunchKernelGGL(resize_bilinear_ac_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, s,
                        (const f16_t*)in, (f16_t*)out, V, Hs, Ws, C, Ho, Wo, ldo, ch_off, sy, sx);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(resize_bilinear_ac_kernel<bx3_t>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const bx3_t*)in, (bx3_t*)out, V, Hs, Ws, C, Ho, Wo, ldo, ch_off, sy, sx);
   else
     hipLaunchKernelGGL(resize_bilinear_ac_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in,
                        (float*)out, V, Hs, Ws, C, Ho, Wo, ldo, ch_off, sy, sx);
@@ -285,7 +297,7 @@ __global__ void copy_channels_kernel(const T* __restrict__ in, T* __restrict__ o
 }
 
 int launch_copy_channels(int dtype, const void* in, void* out, long long npix, int C, int ldo, int ch_off, hipStream_t s) {
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   RGBM_REQUIRE(C % E == 0 && ldo % E == 0 && ch_off % E == 0, "copy channel alignment");
   const long long total = npix * (C / E);
   if (dtype == BF16)
@@ -294,6 +306,9 @@ int launch_copy_channels(int dtype, const void* in, void* out, long long npix, i
   else if (dtype == F16)
     hipLaunchKernelGGL(copy_channels_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, s,
                        (const f16_t*)in, (f16_t*)out, npix, C, ldo, ch_off);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(copy_channels_kernel<bx3_t>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const bx3_t*)in, (bx3_t*)out, npix, C, ldo, ch_off);
   else
     hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out,
                        npix, C, ldo, ch_off);
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(512) void adaptive_avgpool_kernel(const T* __restri
 
 int launch_adaptive_avgpool_multi(int dtype, const void* in, void* const* outs, const int* bins, int nb, int V, int H, int W, int C,
                                   hipStream_t s) {
-  const int E = dtype == F32 ? 4 : 8;
+  const int E = dtype_chunk(dtype);
   RGBM_REQUIRE(C % E == 0 && nb >= 1 && nb <= 4, "avgpool channel alignment / bin count");
   PoolBins pb;
   pb.n = nb;
@@ -376,6 +391,8 @@ int launch_adaptive_avgpool_multi(int dtype, const void* in, void* const* outs, 
     hipLaunchKernelGGL(adaptive_avgpool_kernel<unsigned short>, dim3((unsigned)blocks), dim3(512), 0, s, (const unsigned short*)in, pb, V, H, W, C);
   else if (dtype == F16)
     hipLaunchKernelGGL(adaptive_avgpool_kernel<f16_t>, dim3((unsigned)blocks), dim3(512), 0, s, (const f16_t*)in, pb, V, H, W, C);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<bx3_t>, dim3((unsigned)blocks), dim3(512), 0, s, (const bx3_t*)in, pb, V, H, W, C);
   else
     hipLaunchKernelGGL(adaptive_avgpool_kernel<float>, dim3((unsigned)blocks), dim3(512), 0, s, (const float*)in, pb, V, H, W, C);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -519,6 +536,9 @@ int launch_build_volume(int dtype, const void* feat, const float* homog, const f
   else if (dtype == F16)
     hipLaunchKernelGGL(build_volume_kernel<f16_t>, dim3(grid_for(total) * 4), dim3(256), 0, s,
                        (const f16_t*)feat, homog, depths, (f16_t*)vol, v0, Vc, V, B, D, H, W);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(build_volume_kernel<bx3_t>, dim3(grid_for(total) * 4), dim3(256), 0, s,
+                       (const bx3_t*)feat, homog, depths, (bx3_t*)vol, v0, Vc, V, B, D, H, W);
   else
     hipLaunchKernelGGL(build_volume_kernel<float>, dim3(grid_for(total) * 4), dim3(256), 0, s, (const float*)feat, homog,
                        depths, (float*)vol, v0, Vc, V, B, D, H, W);
@@ -538,6 +558,8 @@ int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_
     hipLaunchKernelGGL(to_f32_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, s, (const unsigned short*)in, out, n);
   else if (dtype == F16)
     hipLaunchKernelGGL(to_f32_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const f16_t*)in, out, n);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(to_f32_kernel<bx3_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bx3_t*)in, out, n);
   else
     hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)in, out, n);
   RGBM_CHECK_HIP(hipGetLastError());

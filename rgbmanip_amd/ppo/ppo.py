@@ -22,7 +22,7 @@ from collections import deque
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, dist_utils
 from ..spaces import Space, concat_spaces
 from .module import ActorCritic
 from .storage import RolloutStorage
@@ -87,9 +87,9 @@ class PPO:
         if learn_cfg["policy"]["actor_critic_class"] != "ActorCritic":
             raise NotImplementedError(learn_cfg["policy"]["actor_critic_class"])
         self.process_group = process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        # equal shards are a requirement of the update (one all-reduce per minibatch, every rank's minibatch mean weighs the same)
+        self.world = dist_utils.require_uniform(self.num_envs, "PPO: num_envs per rank", self.device, process_group)
+        self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
 
         self.vec_env = vec_env
         self.actor_critic = ActorCritic(self.observation_space.shape, self.state_space.shape, self.action_space.shape,
@@ -111,11 +111,12 @@ class PPO:
         self.log_dir = lc["log_dir"]
         self.print_log = lc["print_log"]
         self.writer = None
-        try:  # TensorBoard is optional (absent in the build image)
-            from torch.utils.tensorboard import SummaryWriter  # type: ignore
-            self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
-        except Exception:  # noqa: BLE001
-            self.writer = None
+        if self.rank == 0:      # one writer / one checkpoint file per job, not one per rank
+            try:  # TensorBoard is optional (absent in the build image)
+                from torch.utils.tensorboard import SummaryWriter  # type: ignore
+                self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
+            except Exception:  # noqa: BLE001
+                self.writer = None
         self.tot_timesteps = 0
         self.tot_time = 0.0
         self.is_testing = lc["testing"]
@@ -150,7 +151,12 @@ class PPO:
         self.actor_critic.train()
 
     def save(self, path):
-        torch.save({k: v.cpu() for k, v in self.actor_critic.state_dict().items()}, path)
+        """Rank 0 writes (every rank holds the same parameters); the file appears atomically."""
+        if self.rank != 0:
+            return
+        tmp = f"{path}.tmp{os.getpid()}"
+        torch.save({k: v.cpu() for k, v in self.actor_critic.state_dict().items()}, tmp)
+        os.replace(tmp, path)
 
     # ------------------------------------------------------------------ evaluation helpers (ppo.py:142-199)
     def play(self):
@@ -183,11 +189,17 @@ class PPO:
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
         ep_reward = torch.zeros(self.num_envs, device=self.device)
         ep_len = torch.zeros(self.num_envs, device=self.device)
+        # finished-episode records of one iteration stay on the device ([T, N], NaN = no episode ended there) and reach
+        # the host in ONE copy after the rollout: the reference's per-step `.cpu()` (ppo.py:262-271) would synchronise
+        # the stream 16 times per iteration
+        T_ = self.num_transitions_per_env
+        fin_rew = torch.empty(T_, self.num_envs, device=self.device) if self.print_log else None
+        fin_len = torch.empty(T_, self.num_envs, device=self.device) if self.print_log else None
         self.last_fps = 0.0
         for it in range(self.current_learning_iteration, num_learning_iterations):
             start = time.time()
             ep_infos = []
-            for _ in range(self.num_transitions_per_env):
+            for t_step in range(self.num_transitions_per_env):
                 actions, logp, values, mu, sigma = self.actor_critic.act(cur_obs, cur_states)
                 nxt_obs, rews, dones, infos = self.vec_env.step(actions)
                 nxt_obs = prepare_obs(nxt_obs)[0].to(self.device)
@@ -197,17 +209,20 @@ class PPO:
                 cur_obs, cur_states = nxt_obs, nxt_states
                 ep_infos.append(infos)
                 if self.print_log:
-                    ep_reward += rews.float()
+                    ep_reward += rews.float().view(-1)
                     ep_len += 1
-                    fin = dones > 0
-                    if bool(fin.any()):
-                        rewbuffer.extend(ep_reward[fin].cpu().tolist())
-                        lenbuffer.extend(ep_len[fin].cpu().tolist())
-                        ep_reward[fin] = 0
-                        ep_len[fin] = 0
+                    fin = dones.view(-1) > 0
+                    fin_rew[t_step] = torch.where(fin, ep_reward, torch.full_like(ep_reward, float("nan")))
+                    fin_len[t_step] = ep_len
+                    ep_reward = torch.where(fin, torch.zeros_like(ep_reward), ep_reward)
+                    ep_len = torch.where(fin, torch.zeros_like(ep_len), ep_len)
             _, _, last_values, _, _ = self.actor_critic.act(cur_obs, cur_states)     # extra stochastic act, as ppo.py:287
             torch.cuda.synchronize()
             collection_time = time.time() - start
+            if self.print_log:      # same order as the reference's per-step extends: by step, then by env
+                done_at = ~torch.isnan(fin_rew)
+                rewbuffer.extend(fin_rew[done_at].cpu().tolist())
+                lenbuffer.extend(fin_len[done_at].cpu().tolist())
             mean_trajectory_length, mean_reward = self.storage.get_statistics()
             start = time.time()
             self.storage.compute_returns(last_values[:self.num_envs], self.gamma, self.lam, process_group=self.process_group)
@@ -240,14 +255,42 @@ class PPO:
         if len(locs["rewbuffer"]) > 0:
             lines.insert(5, f"{'Mean reward:':>{pad}} {np.mean(locs['rewbuffer']):.2f}")
             lines.insert(6, f"{'Mean episode length:':>{pad}} {np.mean(locs['lenbuffer']):.2f}")
+        ep_scalars = self.episode_scalars(locs.get("ep_infos"))
+        for key, val in ep_scalars.items():
+            label = "Mean episode " + key[len("Episode/"):].replace("_train", " train") + ":"
+            lines.append(f"{label:>{pad}} {val:.4f}")
+        self.last_scalars = dict(ep_scalars)
+        self.last_scalars.update({"Loss/value_function": locs["mean_value_loss"], "Loss/surrogate": locs["mean_surrogate_loss"],
+                                  "Policy/mean_noise_std": self.actor_critic.log_std.exp().mean().item(), "Policy/lr": self.step_size,
+                                  "Train2/mean_reward/step": locs["mean_reward"],
+                                  "Train2/mean_episode_length/episode": locs["mean_trajectory_length"]})
+        if len(locs["rewbuffer"]) > 0:
+            self.last_scalars["Train/mean_reward"] = float(np.mean(locs["rewbuffer"]))
+            self.last_scalars["Train/mean_episode_length"] = float(np.mean(locs["lenbuffer"]))
         if self.writer is not None:
-            it = locs["it"]
-            self.writer.add_scalar("Loss/value_function", locs["mean_value_loss"], it)
-            self.writer.add_scalar("Loss/surrogate", locs["mean_surrogate_loss"], it)
-            self.writer.add_scalar("Policy/lr", self.step_size, it)
-            self.writer.add_scalar("Train2/mean_reward/step", locs["mean_reward"], it)
-        if not int(os.environ.get("RANK", "0")):
+            for key, val in self.last_scalars.items():
+                self.writer.add_scalar(key, val, locs["it"])
+        if self.rank == 0:
             print("\n".join(["#" * width] + lines), flush=True)
+
+    def episode_scalars(self, ep_infos):
+        """`Episode/<key>_train` = mean over the iteration's steps and envs of every entry of the env's info dict — the
+        reward terms of `ControlInterface.get_reward` (ppo.py:364-384).  All means are formed on the device and fetched in
+        one copy.  As in the reference, a key named "success_rate" is averaged over an EMPTY tensor (its loop sits in the
+        else branch, ppo.py:368-380): both of its scalars are NaN."""
+        if not ep_infos:
+            return {}
+        keys = list(ep_infos[0])
+        plain = [k for k in keys if k != "success_rate"]
+        out = {}
+        if plain:
+            means = torch.stack([torch.cat([torch.as_tensor(ei[k]).to(self.device).float().reshape(-1) for ei in ep_infos]).mean()
+                                 for k in plain]).cpu().tolist()
+            out.update({f"Episode/{k}_train": float(m) for k, m in zip(plain, means)})
+        if "success_rate" in keys:
+            out["Episode/worst_50.0%_success_rate_train"] = float("nan")
+            out["Episode/success_rate_train"] = float("nan")
+        return out
 
     # ------------------------------------------------------------------ the learn phase (ppo.py:449-534)
     def update(self, it):
@@ -280,11 +323,11 @@ class PPO:
                     _lib.ptr(sl["actions_log_prob"]), _lib.ptr(sl["advantages"]), _lib.ptr(sl["returns"]), _lib.ptr(sl["values"]),
                     _lib.ptr(sl["mu"]), _lib.ptr(sl["sigma"]), float(self.clip_param), float(self.value_loss_coef),
                     float(self.entropy_coef), _lib.ptr(self._partial), _lib.ptr(self._grads), stream), "rgbm_ppo_minibatch_fwd_bwd")
-                if self.world > 1:
-                    torch.distributed.all_reduce(self._grads, group=self.process_group)
+                # sum over ranks of (gradient of the local minibatch mean | loss / KL sums); the optimiser applies 1/world
+                inv_world = dist_utils.average_flat_gradient(self._grads, self.process_group)
                 _lib.check(lib.rgbm_ppo_clip_adam(
                     _lib.ptr(ac.flat), _lib.ptr(self._grads), _lib.ptr(self._exp_avg), _lib.ptr(self._exp_avg_sq),
-                    _lib.ptr(self._opt_state), C.byref(ac.layout), 1.0 / self.world, float(self.max_grad_norm),
+                    _lib.ptr(self._opt_state), C.byref(ac.layout), inv_world, float(self.max_grad_norm),
                     float(self.desired_kl or 0.0), self.lr_lower, self.lr_upper, adaptive, stream), "rgbm_ppo_clip_adam")
         s1 = self._read_opt_state()            # the only host sync of the learn phase
         n_up = max(s1["n_updates"] - s0["n_updates"], 1)

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import _lib
+from .. import _lib, dist_utils
 
 
 class RolloutStorage:
@@ -30,6 +30,7 @@ class RolloutStorage:
         self.num_envs = N
         self.step = 0
         self._sums = None
+        self._count = None           # (process group, global element count) of compute_returns
 
     _FIELDS = ("observations", "states", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma")
 
@@ -58,12 +59,12 @@ class RolloutStorage:
         _lib.check(lib.rgbm_gae(T, N, _lib.ptr(self.rewards), _lib.ptr(self.dones), _lib.ptr(self.values), _lib.ptr(lv),
                                 float(gamma), float(lam), _lib.ptr(self.returns), _lib.ptr(adv), _lib.ptr(self._sums),
                                 _lib.stream_ptr()), "rgbm_gae")
-        count = float(T * N)
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                         and torch.distributed.get_world_size() > 1):
-            import torch.distributed as dist
-            dist.all_reduce(self._sums[:2], group=process_group)
-            count *= dist.get_world_size(process_group)
+        # several ranks train one policy: the statistics are those of ALL ranks' advantages.  The element count is summed over
+        # ranks too (shards may differ by an env, dist_utils.shard_range); it cannot change, so it is exchanged once.
+        if self._count is None or self._count[0] is not process_group:
+            self._count = (process_group, dist_utils.global_count(T * N, self.rewards.device, process_group))
+        count = self._count[1]
+        dist_utils.all_reduce_adv_sums(self._sums, process_group)
         _lib.check(lib.rgbm_adv_normalise(T * N, _lib.ptr(adv), _lib.ptr(self._sums), count, _lib.stream_ptr()),
                    "rgbm_adv_normalise")
         self.advantages = adv

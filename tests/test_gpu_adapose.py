@@ -116,6 +116,45 @@ def test_fp32_matches_reference_golden(inputs, golden_dir):
         assert errs[k] < RTOL_FP32, (k, errs)
 
 
+def test_bf16x3_matches_reference_golden(inputs, golden_dir):
+    """The split-pair mode (RGBM_BF16X3: values as bf16 hi + lo, products hi*hi + lo*hi + hi*lo on the bf16 matrix pipe, fp32
+    accumulate) must meet north_star's fp32 gate — it is the mode that is benched as "passes 1e-4".  CPU emulation of the
+    arithmetic through the oracle (tools/split_emulation.py) predicts a worst output error of 2.2e-5."""
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    out = _run(_net("bf16x3"), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print("bf16x3 vs reference golden:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+        assert errs[k] < RTOL_FP32, (k, errs)
+
+
+def test_bf16x3_intermediates_vs_oracle(inputs, oracle_taps):
+    """Stage taps of the split-pair mode against the oracle: every stage inside the fp32 gate."""
+    _, taps = oracle_taps
+    net = _net("bf16x3")
+    B, V = 2, 4
+    _run(net, inputs, stop_after=1)
+
+    def nhwc(name, C, H):
+        return net.fetch(B, name, V * H * H * C).view(V, H, H, C)[:B].permute(0, 3, 1, 2).cpu().numpy()
+    errs = {"conv1": _rel(nhwc("conv1", 64, 112), taps["v1_conv1"].numpy()), "layer4": _rel(nhwc("layer4", 512, 28), taps["v1_layer4"].numpy()),
+            "cat": _rel(nhwc("cat", 1024, 28), taps["v1_psp"].numpy()), "u1": _rel(nhwc("u1", 256, 56), taps["v1_up_1"].numpy()),
+            "u2": _rel(nhwc("u2", 64, 112), taps["v1_up_2"].numpy()), "feat": _rel(nhwc("feat", 32, 224), taps["feat1"].numpy())}
+    _run(net, inputs, stop_after=2)
+
+    def ndhwc(name, C, D, H):
+        return net.fetch(B, name, V * D * H * H * C).view(V, D, H, H, C)[:B].permute(0, 4, 1, 2, 3).cpu().numpy()
+    errs["c0"] = _rel(ndhwc("c0", 8, 24, 224), taps["v1_c0"].numpy())
+    errs["c4"] = _rel(ndhwc("c4", 32, 6, 56), taps["v1_c4"].numpy())
+    errs["u9"] = _rel(ndhwc("u9", 16, 12, 112), taps["v1_u9"].numpy())
+    prob = net.fetch(B, "prob", V * 1024 * 24).view(V, 1024, 24)[:B].permute(0, 2, 1).cpu().numpy()
+    errs["prob"] = _rel(prob, taps["v1_prob"].numpy())
+    print("bf16x3 stage errors:", errs)
+    for k, e in errs.items():
+        assert e < RTOL_FP32, (k, errs)
+
+
 def test_fp32_batch_invariance_and_chunking():
     """B=3 with a chunked cost volume (4 views per chunk, ragged last chunk) equals per-pose results."""
     inp3 = synth.adapose_inputs(3, seed=5)
