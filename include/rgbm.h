@@ -256,7 +256,8 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
                      const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
                      int V, int B, int D, int H, int W, void* stream);
-/* the same kernel for either 16-bit storage type (dtype = RGBM_BF16 or RGBM_F16; feat / out in that type) */
+/* the same kernel for either 16-bit storage type (dtype = RGBM_BF16 or RGBM_F16; feat / out in that type); dtype = RGBM_BF16X3
+ * runs conv0_sweep_x3_kernel: feat is PLAIN fp32 [V][H][W][32], out is the split-pair tensor [V][D][H][W][8] */
 int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
                         const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
                         int V, int B, int D, int H, int W, void* stream);

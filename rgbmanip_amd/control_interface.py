@@ -305,7 +305,33 @@ class ControlInterface:
         return self.get_observation()
 
 
-class RLPoseController:
+class BaseController:
+    """`models/controller/base_controller.py:8-60`: holds env / estimator / manipulation / cfg / logger; `train_controller`
+    and `train_manipulation` forward to `.learn` of the respective model."""
+
+    def __init__(self, env, pose_estimator, manipulation, cfg: dict, logger=None):
+        self.env = env
+        self.pose_estimator = pose_estimator
+        self.manipulation = manipulation
+        self.controller = None
+        self.cfg = cfg
+        self.logger = logger
+
+    def run(self):
+        pass
+
+    def train_controller(self, steps, log_interval=1, save_interval=1):
+        if self.logger is not None:
+            self.logger.info("Training controller model...")
+        self.controller.learn(steps=steps, log_interval=log_interval, save_interval=save_interval)
+
+    def train_manipulation(self, steps, log_interval=1, save_interval=1):
+        if self.logger is not None:
+            self.logger.info("Training manipulation model...")
+        self.manipulation.learn(steps=steps, log_interval=log_interval, save_interval=save_interval)
+
+
+class RLPoseController(BaseController):
     """`RLPoseController` (`models/controller/rl_pose.py:464-516`): the control interface plus its PPO agent.
 
     `train_controller` runs PPO over `ControlInterface.step`; `run` rolls the trained policy out deterministically
@@ -314,7 +340,8 @@ class RLPoseController:
 
     def __init__(self, vec_env, pose_estimator, manipulation, cfg: dict, logger=None, process_group=None):
         from .ppo import PPO
-        self.env, self.estimator, self.manipulation, self.cfg, self.logger = vec_env, pose_estimator, manipulation, cfg, logger
+        super().__init__(vec_env, pose_estimator, manipulation, cfg, logger)
+        self.estimator = pose_estimator
         self.control_interface = ControlInterface(vec_env, pose_estimator, manipulation, cfg)
         self.controller = PPO(self.control_interface, cfg, process_group=process_group)
 

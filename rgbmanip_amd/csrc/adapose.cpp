@@ -132,10 +132,11 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
-      if (i == 0 && dtype_size(dtype) == 2) {
-        // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip)
+      if (i == 0 && dtype != F32) {
+        // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip / conv0_sweep_x3.hip)
         conv0_sweep_pack(w->data, scale.data(), packed);
-        if (upload_packed(packed, dtype, &sweep_w)) return -2;
+        if (dtype == BF16X3) { if (conv0_sweep_x3_upload(packed, &sweep_w)) return -2; }
+        else if (upload_packed(packed, dtype, &sweep_w)) return -2;
       }
     }
   }
@@ -213,6 +214,7 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   bf.homog = (float*)A.alloc((size_t)V * 12 * 4);
   bf.choose = (int*)A.alloc(VP * 4);
   bf.feat = A.alloc((size_t)V * S * S * 32 * es);
+  bf.featf = dtype == BF16X3 ? (float*)A.alloc((size_t)V * S * S * 32 * 4) : nullptr;
   bf.X0 = (float*)A.alloc(VP * 32 * 4);
   bf.X1 = (float*)A.alloc(VP * 64 * 4);
   bf.H128 = (float*)A.alloc(VP * 128 * 4);
@@ -352,6 +354,11 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
       d.wgt = sweep_w;
       return launch_conv0_sweep(d, dtype, s);
     }
+    if (layer == 10 && cost_impl == 3 && dtype == BF16X3 && sweep_w) {
+      d.wgt = sweep_w;
+      d.feat = bf.featf;
+      return launch_conv0_sweep_x3(d, s);
+    }
     return launch_conv3d_tile(layer, dtype, d, s);
   };
   for (int v0 = 0; cost_impl >= 1 && v0 < V; v0 += Vc0) {
@@ -428,10 +435,17 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
 
   if (int rc = pspnet(bf, V, s)) return rc;
   if (int rc = launch_homography(bf.Pviews, bf.homog, V, B, s)) return rc;
+  // bf16x3 nets: everything that GATHERS from the feature map (plane sweep, point heads) reads a plain fp32 copy of it
+  const void* featg = bf.feat;
+  int fdt = dtype;
+  if (dtype == BF16X3) {
+    if (int rc = launch_bx3_to_f32(bf.feat, bf.featf, (long long)V * S * S * 32, s)) return rc;
+    featg = bf.featf; fdt = F32;
+  }
   if (stop_after == 1) return 0;
 
   // ---- per-point NOCS branch (network_v5.py:432-444) ----
-  if (int rc = launch_gather_points(dtype, bf.feat, bf.choose, bf.X0, V, P, S * S, 32, s)) return rc;
+  if (int rc = launch_gather_points(fdt, featg, bf.choose, bf.X0, V, P, S * S, 32, s)) return rc;
   if (int rc = inst.run(bf.X0, bf.X1, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = nh[0].run(bf.X1, bf.H128, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = nh[1].run(bf.H128, bf.H64, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
@@ -444,7 +458,7 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   if (stop_after == 2) return 0;
 
   // ---- depth-guided fusion + pose regression (network_v5.py:457-508) ----
-  if (int rc = launch_fuse_points(dtype, bf.feat, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s)) return rc;
+  if (int rc = launch_fuse_points(fdt, featg, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s)) return rc;
   // bf16 nets: the four big per-point layers of the pose MLP run in fp16 storage (fp32 they took 1.8 ms per 512 views at
   // 78 TFLOP/s on the fp32 matrix path); PF96 is produced in fp32 by its two writers and converted once
   const int pdt = pose_dtype();

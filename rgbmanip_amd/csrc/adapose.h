@@ -40,7 +40,7 @@ struct AdaPose {
   int igemm_conv6 = 1;          // bf16 + cost_impl 3: conv6 through the implicit-GEMM path instead of the halo-tile kernel
   int fuse_final = 1;           // bf16: PSPNet `final` 1x1 fused into up_3's kernel (0 = two launches; `u3` is then materialised)
   int sparse_tail = 1;          // cost_impl 3: evaluate conv11 + prob only where prob is gathered (0 = dense conv11, for A/B and tests)
-  void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (bf16 nets only)
+  void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (16-bit nets; bf16x3 nets: hi + lo operand arrays of conv0_sweep_x3.hip)
   int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,
                                 // 3 = 2 with the depth-sweeping conv0 kernel (bf16; fp32 nets run 2)
   float* wprob = nullptr;
@@ -52,6 +52,7 @@ struct AdaPose {
 
   struct Buffers {
     float *Pviews, *homog; int* choose; void* feat;
+    float* featf;                      // bf16x3 nets: plain fp32 copy of feat (what the plane sweep and the point heads gather from)
     float *X0, *X1, *H128, *H64, *nocs4, *N32, *PF96, *prob, *depth, *Q128a, *Q128b, *G256a, *G256b;
     void* PF96h;                       // fp16 copy of PF96 (pose MLP input of 16-bit nets)
     float *glob, *vbias, *pf2, *h1, *h2, *r6, *R, *tv, *sv;

@@ -242,12 +242,13 @@ extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float*
                                    void* out_dev, int V, int B, int D, int H, int W, void* stream) {
   RGBM_REQUIRE(feat_dev && P_views_dev && depths_dev && homog_scratch && w_host && bn_scale_host && bn_shift_host && out_dev,
                "conv0_sweep arguments");
-  RGBM_REQUIRE(dtype == BF16 || dtype == F16, "conv0_sweep: 16-bit storage types only");
+  RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "conv0_sweep: 16-bit storage types or bf16x3 (fp32 features in, split-pair c0 out)");
   if (int rc = launch_homography(P_views_dev, homog_scratch, V, B, (hipStream_t)stream)) return rc;
   std::vector<float> packed;
   conv0_sweep_pack(w_host, bn_scale_host, packed);
   void* wdev = nullptr; float* bdev = nullptr;
-  if (upload_packed(packed, dtype, &wdev)) return -2;
+  if (dtype == BF16X3) { if (conv0_sweep_x3_upload(packed, &wdev)) return -2; }
+  else if (upload_packed(packed, dtype, &wdev)) return -2;
   std::vector<float> bpad(16, 0.f);
   for (int o = 0; o < 8; ++o) bpad[o] = bn_shift_host[o];
   if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;
@@ -257,7 +258,7 @@ extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float*
   d.N = V; d.Di = D; d.Hi = H; d.Wi = W; d.Do = D; d.Ho = H; d.Wo = W; d.Dq = D; d.Hq = H; d.Wq = W;
   d.Cout = 8; d.relu = 1; d.prof_variant = -1;
   d.feat = feat_dev; d.homog = homog_scratch; d.depths = depths_dev; d.v0 = 0; d.V = V; d.B = B;
-  int rc = launch_conv0_sweep(d, dtype, (hipStream_t)stream);
+  int rc = dtype == BF16X3 ? launch_conv0_sweep_x3(d, (hipStream_t)stream) : launch_conv0_sweep(d, dtype, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;

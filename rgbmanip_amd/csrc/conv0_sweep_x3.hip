@@ -1,0 +1,439 @@
+// conv0 of the cost-regularisation net + plane sweep for the BF16X3 (split pair) mode: the depth-sweeping producer / consumer
+// structure of conv0_sweep.hip (Conv3d 32->8 k3 p1 + BN + ReLU over "ref + warped", network_v5.py:260-291,378-430) with
+//   * fp32 arithmetic up to the MFMA operands: the feature map is read as plain fp32 (a copy the forward makes once), the
+//     bilinear blend runs in fp32, and only then each voxel is split into bf16 hi + lo (common.h, bx3_t) — so the volume
+//     the convolution sees carries 16 significand bits (a single-term 16-bit volume alone puts the depth output at 2.4e-4
+//     from the reference, tools/split_emulation.py);
+//   * three products per tap: W_lo*x_hi, W_hi*x_lo, W_hi*x_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulation;
+//   * one persistent workgroup per CU walking its tiles (the 121 KB plane ring and the 36 weight operands a consumer lane
+//     keeps in registers allow one resident workgroup anyway): weights are loaded once per launch, the plane ring runs on
+//     across tile boundaries.
+// LDS voxel = [hi: 32 channels, 64 B][lo: 64 B][32 B pad]: with the 160-byte stride the 16 consecutive voxels x 4 k-groups a
+// ds_read_b128 lane group touches fall on distinct banks (the 80-byte voxels of the 16-bit kernel are 2-way conflicted).
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "prof.h"
+
+#ifndef X3_DTAP
+#define X3_DTAP 4     // X3_DBG & 4: which in-plane tap's operand is dumped
+#endif
+#ifndef X3_DBG
+#define X3_DBG 0      // experiment builds only (tools/abl_build.sh): 1 = every blend waits for ALL gathers, 2 = two barriers per plane
+#endif
+
+namespace rgbm {
+
+namespace {
+
+constexpr int X3_TH = 12, X3_TW = 16;
+constexpr int X3_HH = X3_TH + 2, X3_HW = X3_TW + 2;
+constexpr int X3_NV = X3_HH * X3_HW;             // 252 voxels per input plane incl. halo
+constexpr int X3_VS = 160;
+constexpr int X3_SLOT = X3_NV * X3_VS;           // 40320
+constexpr int X3_NSLOT = 3;                      // plane p is written during step p, read during step p + 1, rewritten during step p + 3
+constexpr int X3_RING = X3_NSLOT * X3_SLOT;      // 120960
+constexpr int X3_WLDS = 9 * 64 * 16;             // lo operands of the kd=2 taps, lane-linear per tap (the consumers' register budget)
+constexpr int X3_LDS = X3_RING + X3_WLDS;
+constexpr int X3_NPW = 4, X3_NCW = 3;            // producer waves (one per SIMD), consumer waves (4 rows of 16 voxels each)
+constexpr int X3_THREADS = (X3_NPW + X3_NCW) * 64;
+constexpr int X3_NCH = 8;                        // 16-byte chunks (4 fp32 channels) per voxel of the feature map
+static_assert(X3_NV <= X3_NPW * 64, "one producer thread per voxel");
+
+struct Sweep3Desc {
+  const float* feat;        // [V][H][W][32] fp32
+  const uint4* wgt;         // [2][18][16 rows][4 k-groups] bf16x8: hi operands (A01[9], A2[9]) then the lo operands
+  const float* bias;        // [16] folded BN shift
+  const float* homog;       // [V][12]
+  const float* depths;      // [B][D]
+  bx3_t* out;               // [N][D][H][W][8]
+  int N, D, H, W, v0, V, B, nth, ntw, relu, n_tiles;
+};
+
+struct Corner3 {
+  unsigned off[4];          // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
+  float w[4];               // bilinear weights: 0 outside the image, NaN for a non-finite projection
+};
+
+typedef __attribute__((ext_vector_type(4))) float f4v;        // native vectors: usable as tied inline-asm operands
+typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+__device__ __forceinline__ u4v ld_u4v(const uint4* p) { const uint4 t = *p; return u4v{t.x, t.y, t.z, t.w}; }
+
+__device__ __forceinline__ f32x4 mma32(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// 4 channels of one voxel: ref + w0*a + w1*b + w2*c + w3*e as one fma chain (whole-vector arithmetic: the gathered registers
+// are tied inline-asm results, see hazard (4) in DESIGN.md about indexing them with an unrolled loop counter)
+__device__ __forceinline__ f4v blend4(const f4v& r, const f4v& a, const f4v& b, const f4v& c, const f4v& e, const float* w) {
+  f4v t = a * w[0] + r;
+  t = b * w[1] + t;
+  t = c * w[2] + t;
+  t = e * w[3] + t;
+  return t;
+}
+
+// 8 fp32 channels -> their bf16 hi parts (16 bytes) and lo parts (16 bytes)
+__device__ __forceinline__ void split8(const float* o, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = pack2_bf16(o[2 * q], o[2 * q + 1]);
+    l[q] = pack2_bf16(o[2 * q] - __uint_as_float(h[q] << 16), o[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+}  // namespace
+
+// one workgroup per CU (<= 256 VGPRs): 7 waves
+__global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Sweep3Desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = d.D, H = d.H, W = d.W;
+  const int n_my = (d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // XCD-aware tile order (the grid is a multiple of 8): every XCD walks a contiguous run of tiles, i.e. whole views, so the
+  // partner feature maps its CUs gather from stay in that XCD's L2
+  auto tile_of = [&](int k, int& n, int& h0, int& w0) {
+    const int v = (int)blockIdx.x + k * (int)gridDim.x;
+    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
+    int t = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+    const int tw = t % d.ntw; t /= d.ntw;
+    const int th = t % d.nth; t /= d.nth;
+    n = t; h0 = th * X3_TH; w0 = tw * X3_TW;
+  };
+
+  // lo operands of the kd=2 taps -> LDS (read by the consumers every plane): lane-linear rows [tap][lane]
+  for (int i = tid; i < 9 * 64; i += X3_THREADS) {
+    const int s9 = i >> 6, ln = i & 63;
+    reinterpret_cast<uint4*>(planes + X3_RING)[i] = d.wgt[((27 + s9) * 16 + (ln & 15)) * 4 + (ln >> 4)];
+  }
+  __syncthreads();
+
+  if (wave < X3_NPW) {
+    // ------------------------------------------------------------------ producers: one thread per voxel of the 14 x 18 plane
+    const int pv = tid;
+    const bool act = pv < X3_NV;
+    const int hh = pv / X3_HW, hw = pv - hh * X3_HW;
+    unsigned char* dst0 = planes + pv * X3_VS;
+    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+    f4v g[X3_NCH][4];                                    // [chunk][corner]: one whole voxel of corner data in flight
+#pragma unroll
+    for (int k = 0; k < X3_NCH; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[k][q] = f4v{0.f, 0.f, 0.f, 0.f};
+    // Gathers are issued from inline asm and counted by hand (see conv0_sweep.hip): chunk k of plane z + 1 is requested right
+    // after chunk k of plane z has been blended out of the same registers; each blend waits for exactly its 4 oldest loads
+    // (28 stay in flight).  The asm results must not be touched before X3_WAIT(k), which names them as in/out.
+#define X3_GATHER(K, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
+#define X3_GATHER4(K, C) do { X3_GATHER(K, 0, (C).off[0]); X3_GATHER(K, 1, (C).off[1]); X3_GATHER(K, 2, (C).off[2]); X3_GATHER(K, 3, (C).off[3]); } while (0)
+#if X3_DBG & 1
+#define X3_WAITB(K) X3_WAIT(K, 0)
+#else
+#define X3_WAITB(K) X3_WAIT(K, 28)
+#endif
+#define X3_WAIT(K, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+    int pg = 0;                                          // planes produced so far (ring slot = pg % 3)
+    for (int k = 0; k < n_my; ++k) {
+      int n, h0, w0;
+      tile_of(k, n, h0, w0);
+      const int vv = d.v0 + n;
+      const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+      const bool inb = act && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      const int partner = (vv + d.B) % d.V, bb = vv % d.B;
+      const float* __restrict__ hm = d.homog + (long long)vv * 12;
+      const unsigned char* __restrict__ srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
+      // the previous tile's trailing re-request must have landed before its registers are requested again
+      X3_WAIT(0, 0); X3_WAIT(1, 0); X3_WAIT(2, 0); X3_WAIT(3, 0); X3_WAIT(4, 0); X3_WAIT(5, 0); X3_WAIT(6, 0); X3_WAIT(7, 0);
+      f4v ref[X3_NCH];
+#pragma unroll
+      for (int c = 0; c < X3_NCH; ++c) ref[c] = f4v{0.f, 0.f, 0.f, 0.f};     // outside the image: conv zero padding
+      if (inb) {
+        const f4v* pr = reinterpret_cast<const f4v*>(d.feat + (((long long)vv * H + gh) * W + gw) * 32);
+#pragma unroll
+        for (int c = 0; c < X3_NCH; ++c) ref[c] = pr[c];
+      }
+      // projection of this pixel (network_v5.py:378-430 folded as in conv0_sweep.hip): p = rot*(x,y,1)*depth + t
+      const float x = (float)gw, y = (float)gh;
+      const float rx = hm[0] * x + hm[1] * y + hm[2];
+      const float ry = hm[3] * x + hm[4] * y + hm[5];
+      const float rz = hm[6] * x + hm[7] * y + hm[8];
+      const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
+      const int dbits = __float_as_int(lane < D ? d.depths[(long long)bb * D + lane] : 1.f);      // lane z holds depth z
+      auto corners = [&](int z, Corner3& c) {
+        const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
+        const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
+        const float ix = (px / pz) * sx - 0.5f, iy = (py / pz) * sy - 0.5f;       // true divisions: the fp32 path's accuracy
+        const bool fin = isfinite(ix) && isfinite(iy);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
+        const float tx = ix - fx, ty = iy - fy;
+        const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+        const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+        const float ux = 1.f - tx, uy = 1.f - ty;
+        c.w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
+        c.w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
+        c.w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
+        c.w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
+        if (inb && !fin) c.w[0] = __builtin_nanf("");          // the voxel becomes NaN like the reference's
+        const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+        c.off[0] = (r0 + (unsigned)xc0) * 128u;
+        c.off[1] = (r0 + (unsigned)xc1) * 128u;
+        c.off[2] = (r1 + (unsigned)xc0) * 128u;
+        c.off[3] = (r1 + (unsigned)xc1) * 128u;
+      };
+      Corner3 cur, nxt;
+      if (act) {
+        corners(0, cur);
+        X3_GATHER4(0, cur); X3_GATHER4(1, cur); X3_GATHER4(2, cur); X3_GATHER4(3, cur);
+        X3_GATHER4(4, cur); X3_GATHER4(5, cur); X3_GATHER4(6, cur); X3_GATHER4(7, cur);
+      }
+      for (int z = 0; z <= D; ++z) {
+        if (act && z < D) {
+          corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
+          unsigned char* dst = dst0 + (pg % X3_NSLOT) * X3_SLOT;
+          float o[8];
+          uint4 hi, lo;
+          // blend of chunk K (4 channels): ref + w0*a + w1*b + w2*c + w3*e as one fma chain; two chunks make an 8-channel hi / lo pair
+#define X3_BLEND(K, OB)                                                                                         \
+          X3_WAITB(K);                                                                                           \
+          { const f4v t = blend4(ref[K], g[K][0], g[K][1], g[K][2], g[K][3], cur.w);                              \
+            o[OB] = t.x; o[OB + 1] = t.y; o[OB + 2] = t.z; o[OB + 3] = t.w; }                                    \
+          X3_GATHER4(K, nxt);
+          X3_BLEND(0, 0) X3_BLEND(1, 4)
+          split8(o, hi, lo);
+          *reinterpret_cast<uint4*>(dst) = hi; *reinterpret_cast<uint4*>(dst + 64) = lo;
+          X3_BLEND(2, 0) X3_BLEND(3, 4)
+          split8(o, hi, lo);
+          *reinterpret_cast<uint4*>(dst + 16) = hi; *reinterpret_cast<uint4*>(dst + 80) = lo;
+          X3_BLEND(4, 0) X3_BLEND(5, 4)
+          split8(o, hi, lo);
+          *reinterpret_cast<uint4*>(dst + 32) = hi; *reinterpret_cast<uint4*>(dst + 96) = lo;
+          X3_BLEND(6, 0) X3_BLEND(7, 4)
+          split8(o, hi, lo);
+          *reinterpret_cast<uint4*>(dst + 48) = hi; *reinterpret_cast<uint4*>(dst + 112) = lo;
+#undef X3_BLEND
+          cur = nxt;
+        }
+        if (z < D) ++pg;
+        // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
+#if X3_DBG & 2
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
+      }
+    }
+#undef X3_GATHER
+#undef X3_GATHER4
+#undef X3_WAIT
+  } else {
+    // ------------------------------------------------------------------ consumers: 4 rows x 16 voxels per wave
+    const int cw = wave - X3_NPW;
+    const int lr = lane & 15, lg = lane >> 4;
+    // weights of all 9 in-plane taps, hi and lo: rows 0-7 of A01 = W(kd=0), rows 8-15 = W(kd=1); rows 8-15 of A2 = W(kd=2)
+    // (the paired-tap scheme of conv0_sweep.hip).  108 registers, loaded once per launch; the fourth set (lo operands of the
+    // kd=2 taps) sits in LDS, one lane-linear 1 KB row per tap — with it in registers too the kernel spilled at the 256 cap
+    // (7 waves on 4 SIMDs: two waves share a SIMD's 512 registers), and a spill reload in a consumer waits on vmcnt, i.e. on
+    // its output stores.
+    u4v A01h[9], A01l[9], A2h[9];
+    // Operand registers of the plane loop and the hazard they are laid out for.  The first version of this loop was plain
+    // C++ (ds_read into `uint4` temporaries, MFMA builtins): about one (workgroup, consumer wave, plane) in a thousand came
+    // out wrong, differently from run to run — with one barrier per plane or two, with counted or drained gathers, while a
+    // dump of what the consumers READ from the ring was always right.  64 wait states of s_nop between a step's MFMAs and
+    // the next step's ds_reads made every run exact; 32 did not.  hipcc had (legally, by its hazard tables: `s_nop 2`)
+    // given the ds_reads destination registers that MFMAs issued just before still had to read — operand registers, and
+    // accumulator inputs it rotates (vDst != SrcC): on this part an LDS return can land in a register before an MFMA issued
+    // ~10 instructions earlier has read it.  (The same signature — one consumer wave, one input plane — is hazard (3) of
+    // the 16-bit sweep in DESIGN.md, where a third ring slot only moved the timing.)  So here nothing is left to the
+    // register allocator: accumulators are updated in place by inline-asm MFMAs and never serve as load destinations,
+    // and the operands rotate through three fixed register sets — a set is reloaded only after a whole further step of 12
+    // MFMAs has been issued behind its last reader.
+    u4v B[3][4];                       // [set][frag0 hi, frag0 lo, frag1 hi, frag1 lo]
+    u4v AL[3];                         // lo weight operand of the kd=2 taps (from LDS), one per tap in flight
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      AL[i] = u4v{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) B[i][q] = u4v{0u, 0u, 0u, 0u};
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
+    const unsigned wa = lds_base + X3_RING + lane * 16;      // this lane's lo-weight operand of tap 0
+#define X3_BOFF(TP, F) ((((F) + (TP) / 3) * X3_HW + (TP) % 3) * X3_VS)
+#define X3_LDB(SET, TP, F0)                                                                                          \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8" \
+                 : "+v"(B[SET][0]), "+v"(B[SET][1]), "+v"(B[SET][2]), "+v"(B[SET][3])                                 \
+                 : "v"(sa), "n"(X3_BOFF(TP, F0)), "n"(X3_BOFF(TP, F0) + 64), "n"(X3_BOFF(TP, F0 + 1)), "n"(X3_BOFF(TP, F0 + 1) + 64) : "memory");
+#define X3_LDW(SET, TP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(AL[SET]) : "v"(wa), "n"((TP) * 1024) : "memory");
+#define X3_MFMA(ACC, A, BB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(BB))
+#define X3_MMA12(I)                                                                                                  \
+    X3_MFMA(Xn[2 * ((I) % 2)], A01l[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], AL[((I) / 2) % 3], B[(I) % 3][0]);           \
+    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01l[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], AL[((I) / 2) % 3], B[(I) % 3][2]);   \
+    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][1]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][1]);                \
+    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][3]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][3]);        \
+    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][0]);                \
+    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][2]);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      A01h[s] = ld_u4v(d.wgt + (s * 16 + lr) * 4 + lg);
+      A2h[s] = ld_u4v(d.wgt + ((9 + s) * 16 + lr) * 4 + lg);
+      A01l[s] = ld_u4v(d.wgt + ((18 + s) * 16 + lr) * 4 + lg);
+    }
+    const int ch = (lg & 1) * 4;       // after the lane-half swap: fragment (lg < 2 ? first : second of the pair), voxel lr, channels ch..ch+3
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = d.bias[ch + r];
+    const int boff = ((cw * 4) * X3_HW + lr) * X3_VS + lg * 16;     // fragment 0, tap (0,0), hi part
+    int pg0 = 0;                                                     // ring index of this tile's plane 0
+    for (int k = 0; k < n_my; ++k) {
+      int n, h0, w0;
+      tile_of(k, n, h0, w0);
+      const int ow = w0 + lr;
+      int oh[2];
+      bool ook[2];
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        oh[pr] = h0 + cw * 4 + pr * 2 + (lg >> 1);
+        ook[pr] = oh[pr] < H && ow < W;
+      }
+      f32x4 Xp[4], Xn[4], Lp[2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) Xp[f] = Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      Lp[0] = Lp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto emit = [&](int o) {         // out plane o from Xp (= X[o]) and Lp (= rows 0-7 of X[o-1]); leaves Lp = rows 0-7 of X[o]
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          f32x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[2 * pr][r]), __float_as_uint(Xp[2 * pr + 1][r]), false, false);
+            lo[r] = __uint_as_float(sw[0]);
+            hi[r] = __uint_as_float(sw[1]);
+          }
+          if (o >= 0 && ook[pr] && !(X3_DBG & 4)) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = (hi[r] + Lp[pr][r]) + bias[r];
+              if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
+            }
+            store4(d.out + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
+          }
+          Lp[pr] = lo;
+        }
+      };
+      for (int z = 0; z <= D; ++z) {
+        if (z >= 1) {
+          const int p = z - 1;
+          const unsigned sa = lds_base + (unsigned)(((pg0 + p) % X3_NSLOT) * X3_SLOT + boff);      // LDS address of (fragment 0, tap (0,0), hi)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+          // 18 steps per plane: step i = in-plane tap i/2, fragments 2*(i%2), 2*(i%2)+1: 4 operand reads (5 with the tap's lo
+          // weights) and 12 MFMAs (W_lo*x_hi, W_hi*x_lo, W_hi*x_hi for the two depth-tap pairs; 4 independent accumulators
+          // between two MFMAs on the same one).  The reads of step i + 2 are issued behind the MFMAs of step i into the
+          // register set that step i - 1 multiplied from (see X3_LDB above for why the distance matters).  Counted waits: at
+          // step i the reads of steps i and i + 1 are outstanding, LDS operations complete in order, so step i's have landed
+          // once at most n(i + 1) remain: 4 behind an even step, 5 behind an odd one (the tap's lo weights ride with it).
+          X3_LDW(0, 0) X3_LDB(0, 0, 0) X3_LDB(1, 0, 2)
+#define X3_STEP(I, NEXT, WAITN)                                                                                      \
+          asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" ::: "memory");                                                \
+          X3_MMA12(I)                                                                                                \
+          NEXT
+          X3_STEP(0, X3_LDW(1, 1) X3_LDB(2, 1, 0), 4)   X3_STEP(1, X3_LDB(0, 1, 2), 5)
+          X3_STEP(2, X3_LDW(2, 2) X3_LDB(1, 2, 0), 4)   X3_STEP(3, X3_LDB(2, 2, 2), 5)
+          X3_STEP(4, X3_LDW(0, 3) X3_LDB(0, 3, 0), 4)   X3_STEP(5, X3_LDB(1, 3, 2), 5)
+          X3_STEP(6, X3_LDW(1, 4) X3_LDB(2, 4, 0), 4)   X3_STEP(7, X3_LDB(0, 4, 2), 5)
+          X3_STEP(8, X3_LDW(2, 5) X3_LDB(1, 5, 0), 4)   X3_STEP(9, X3_LDB(2, 5, 2), 5)
+          X3_STEP(10, X3_LDW(0, 6) X3_LDB(0, 6, 0), 4)  X3_STEP(11, X3_LDB(1, 6, 2), 5)
+          X3_STEP(12, X3_LDW(1, 7) X3_LDB(2, 7, 0), 4)  X3_STEP(13, X3_LDB(0, 7, 2), 5)
+          X3_STEP(14, X3_LDW(2, 8) X3_LDB(1, 8, 0), 4)  X3_STEP(15, X3_LDB(2, 8, 2), 5)
+          X3_STEP(16, , 4)                              X3_STEP(17, , 0)
+#undef X3_STEP
+          // the accumulators were written by inline-asm MFMAs, which the compiler's hazard recogniser does not see: the last
+          // of them must have retired before VALU code (emit, the Xp <- Xn copies) reads its result (8-pass MFMA: 11+ wait states)
+          asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+          emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
+#pragma unroll
+          for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
+          // ... and the copies must be done before the next plane's MFMAs overwrite Xn (VALU reads its operands at issue)
+        }
+        // LDS reads pinned to their side of the barrier in both directions (see conv0_sweep.hip)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
+      pg0 += D;
+    }
+  }
+}
+
+// fp32 fragment-order weights of conv0_sweep_pack ([18][16 rows][4 k-groups][8]) -> device array of bf16x8 operands:
+// the 18 x 16 x 4 hi operands followed by the lo operands
+int conv0_sweep_x3_upload(const std::vector<float>& packed, void** dev) {
+  RGBM_REQUIRE(packed.size() == (size_t)18 * 16 * 4 * 8, "conv0 sweep weights: unexpected size");
+  const size_t nop = packed.size() / 8;
+  std::vector<unsigned short> h(2 * packed.size());
+  auto bf = [](float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  for (size_t i = 0; i < packed.size(); ++i) {
+    const unsigned short hi = bf(packed[i]);
+    const unsigned uh = (unsigned)hi << 16;
+    float hf;
+    memcpy(&hf, &uh, 4);
+    h[i] = hi;
+    h[nop * 8 + i] = bf(packed[i] - hf);
+  }
+  RGBM_CHECK_HIP(hipMalloc(dev, h.size() * 2));
+  RGBM_CHECK_HIP(hipMemcpy(*dev, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// t.feat: the fp32 feature map; t.wgt: conv0_sweep_x3_upload's array; t.out: bx3 [N][D][H][W][8]
+int launch_conv0_sweep_x3(const Conv3dTileDesc& t, hipStream_t s) {
+  Sweep3Desc d;
+  d.feat = reinterpret_cast<const float*>(t.feat);
+  d.wgt = reinterpret_cast<const uint4*>(t.wgt);
+  d.bias = t.bias; d.homog = t.homog; d.depths = t.depths;
+  d.out = reinterpret_cast<bx3_t*>(t.out);
+  d.N = t.N; d.D = t.Di; d.H = t.Hi; d.W = t.Wi; d.v0 = t.v0; d.V = t.V; d.B = t.B; d.relu = t.relu;
+  d.nth = (d.H + X3_TH - 1) / X3_TH; d.ntw = (d.W + X3_TW - 1) / X3_TW;
+  RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep (bf16x3) arguments");
+  RGBM_REQUIRE((long long)d.H * d.W * 128ll < (1ll << 32), "conv0 sweep (bf16x3): feature map too large for 32-bit offsets");
+  const long long ntiles = (long long)d.N * d.nth * d.ntw;
+  RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31), "conv0 sweep grid out of range");
+  d.n_tiles = (int)ntiles;
+  static int n_cu = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+    attr_done = true;
+  }
+  if (n_cu == 0) {
+    int dev = 0;
+    RGBM_CHECK_HIP(hipGetDevice(&dev));
+    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;                       // one resident workgroup per CU; a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+  }
+  // the tile order assumes a grid that is a multiple of 8 (XCD = block % 8); small launches round up and idle blocks exit
+  int grid = ntiles < n_cu ? (int)((ntiles + 7) / 8 * 8) : n_cu;
+  prof_begin_launch(s, t.prof_variant, t.algo_flops, t.algo_bytes);
+  hipLaunchKernelGGL(conv0_sweep_x3_kernel, dim3((unsigned)grid), dim3(X3_THREADS), X3_LDS, s, d);
+  prof_end_launch(s);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rgbm

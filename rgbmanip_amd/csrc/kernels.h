@@ -58,6 +58,11 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
 void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& packed);
 int launch_conv0_sweep(const Conv3dTileDesc& d, int dtype, hipStream_t s);      // dtype BF16 or F16
 
+// conv0_sweep_x3.hip — the same for the BF16X3 mode: fp32 feature map in, split-pair c0 out, three MFMAs per product
+int conv0_sweep_x3_upload(const std::vector<float>& packed, void** dev);      // packed: conv0_sweep_pack's fp32 fragment order
+int launch_conv0_sweep_x3(const Conv3dTileDesc& d, hipStream_t s);           // d.feat: fp32 [V][H][W][32]; d.wgt: the uploaded array
+int launch_bx3_to_f32(const void* in, float* out, long long n, hipStream_t s);   // misc_kernels.hip: split-pair tensor -> plain fp32 (n % 4 == 0)
+
 // prob_sparse.hip — conv11 + skip + prob conv + softmax + depth on the neighbourhoods of the chosen pixels (bf16)
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,

@@ -566,6 +566,22 @@ int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_
   return 0;
 }
 
+// ---------------------------------------------------------------- split-pair (BF16X3) -> plain fp32, one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void bx3_to_f32_kernel(const uint4* __restrict__ in, float4* __restrict__ out, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float v[4];
+    bx3_join4(in[i], v);
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int launch_bx3_to_f32(const void* in, float* out, long long n, hipStream_t s) {
+  RGBM_REQUIRE(n % 4 == 0, "bx3_to_f32: element count must be a multiple of 4");
+  hipLaunchKernelGGL(bx3_to_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (const uint4*)in, (float4*)out, n / 4);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- fp32 -> fp16 copy (input of the fp16 pose MLP), 8 elements per thread
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ in, f16_t* __restrict__ out, long long n8) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {

@@ -460,6 +460,57 @@ def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
     assert torch.equal(torch.isnan(y2), nan_ref)
 
 
+@pytest.mark.parametrize("shape", [(5, 20, 37), (1, 16, 16), (24, 33, 16), (3, 48, 50), (6, 100, 120)])
+def test_conv0_sweep_bf16x3_matches_volume_then_conv(shape):
+    """The split-pair sweep (conv0_sweep_x3.hip: fp32 features, fp32 blend, bf16 hi + lo operands, 3 MFMAs per product,
+    persistent workgroups) against build_volume in fp32 followed by a CPU fp32 conv3d + folded BN + ReLU: the fp32 gate.
+    Ragged tiles, D = 1, more tiles than one round of workgroups (the last shape), NaN isolation."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, host_f32, empty_out
+    lib = _lib.load()
+    D, H, W = shape
+    B, V = 2, 4
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) / np.sqrt(32 * 27)
+    scale = torch.rand(8, generator=g) + 0.5
+    shift = torch.randn(8, generator=g) * 0.1
+    wf = w * scale.view(-1, 1, 1, 1, 1)
+    wa, wp = host_f32(w)
+    sa, sp = host_f32(scale)
+    ha, hp = host_f32(shift)
+
+    def run(singular_pose):
+        feat, P, dep = _sweep_case(B, D, H, W, seed=11, singular_pose=singular_pose)
+        feat = feat + 0.01 * torch.randn(feat.shape, generator=torch.Generator().manual_seed(5))      # not bf16-representable
+        fd = to_channels_last(feat, _lib.F32)
+        Pd, dd = P.cuda(), dep.cuda()
+        hom = torch.empty(V * 12, dtype=torch.float32, device="cuda")
+        vol = torch.empty(V, D, H, W, 32, dtype=torch.float32, device="cuda")
+        _lib.check(lib.rgbm_build_volume(_lib.F32, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), _lib.ptr(vol),
+                                         V, B, D, H, W, _lib.stream_ptr()), "rgbm_build_volume")
+        out = empty_out((V, D, H, W, 8), _lib.BF16X3)
+        _lib.check(lib.rgbm_conv0_sweep_dt(_lib.BF16X3, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out),
+                                           V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_dt")
+        torch.cuda.synchronize()
+        x = vol.cpu().permute(0, 4, 1, 2, 3)
+        ref = F.relu(F.conv3d(x, wf, None, 1, 1) + shift.view(1, -1, 1, 1, 1))
+        return from_channels_last(out), ref
+
+    y, ref = run(None)
+    assert torch.isfinite(y).all()
+    err = rel_err(y, ref)
+    print(f"bf16x3 sweep {shape}: rel err {err:.2e}")
+    assert err < 5e-5, shape            # operands at 2^-17, dropped lo*lo at 2^-18, output rounded to 2^-17
+    # bit-stable from run to run: the first version of the consumer loop was not (about one (workgroup, consumer wave, plane)
+    # in a thousand: LDS returns landing in registers that queued MFMAs still had to read — see conv0_sweep_x3.hip)
+    for _ in range(3):
+        y_again, _ = run(None)
+        assert torch.equal(y_again, y), shape
+    y2, ref2 = run(1)                   # pose 1 = views 1 and 3 gets a singular view-2 projection
+    assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
+    assert torch.equal(torch.isnan(y2), torch.isnan(ref2))
+    assert torch.isnan(y2[1]).any() and torch.isnan(y2[3]).any()
+
+
 def test_conv0_sweep_fp16_blend_saturates():
     """fp16 instantiation: reference + warped features of +-40000 each overflow fp16 in the blend.  The kernel runs its producers
     with MODE.FP16_OVFL set, so the blended voxel must land on +-65504 like the saturating stores of build_volume — not on inf

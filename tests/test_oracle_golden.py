@@ -232,3 +232,32 @@ def test_align_oracle_matches_reference_golden(golden_dir):
         s, R, t, _ = ar.similarity_ransac(nocs, pts, ar.hash_sampler(3, case))
         np.testing.assert_allclose(s, g[f"c{case}_s"], rtol=1e-3)
         np.testing.assert_allclose(R, g[f"c{case}_R"], atol=5e-3)
+
+
+def test_resize_restatement_pinned_by_torch_interpolate():
+    """`prepare_model_input`'s two cv2.resize calls (interface_v5.py:99-118; OpenCV is not installable here) are restated in
+    oracle/postproc_ref.py from OpenCV's documented arithmetic.  Second, independent pin: torch's implementation of the
+    same arithmetic — `F.interpolate(mode="bilinear", align_corners=False, antialias=False)` is INTER_LINEAR's half-pixel
+    centres with edge clamp, `mode="nearest"` is INTER_NEAREST's floor(dst * scale) — on every crop-window size `get_bbox`
+    can produce (multiples of 40 up to 440: 5.6x up-scaling to 1.96x down-scaling) and a non-square crop.  Tolerance 1e-4 on
+    values in [0, 1): torch forms the source coordinate in fp32, OpenCV (and the restatement) in fp64 rounded to fp32 at the
+    end — the interpolation weights differ by a few ulps of a coordinate of up to 440 (~3e-5), never the taps, the edge clamp or the pixel-centre convention."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import postproc_ref
+    g = np.random.default_rng(11)
+    shapes = [(w, w) for w in range(40, 441, 40)] + [(120, 200), (440, 80)]
+    for h, w in shapes:
+        img = g.random((h, w, 3)).astype(np.float32)
+        got = postproc_ref.resize_linear(img, 224)
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(224, 224), mode="bilinear", align_corners=False,
+                            antialias=False)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4, err_msg=f"INTER_LINEAR {h}x{w}")
+        mask = (g.random((h, w)) > 0.6).astype(np.float32)
+        gotm = postproc_ref.resize_nearest(mask, 224)
+        refm = F.interpolate(torch.from_numpy(mask)[None, None], size=(224, 224), mode="nearest")[0, 0].numpy()
+        assert np.array_equal(gotm, refm), f"INTER_NEAREST {h}x{w}"
+        # the host path of the product uses the same arithmetic (rgbmanip_amd/estimator.py) — pinned through the oracle
+        from rgbmanip_amd import estimator
+        np.testing.assert_allclose(estimator._resize_linear(img, 224), ref, rtol=0, atol=1e-4)
+        assert np.array_equal(estimator._resize_nearest(mask, 224), refm)
