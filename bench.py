@@ -50,6 +50,107 @@ def make_inputs(B, device, unique=16):
     return out, dev
 
 
+def tree_hash():
+    """sha256 (first 16 hex digits) over the library sources: PMC measurements are only valid for the tree
+    they were taken on (tools/pmc_traffic.py stamps the same value into profiles/hbm_traffic.json)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def accuracy_vs_golden(net, device):
+    """Worst relative error (max |a - b| / max |b|) of the 10 network outputs and of the world box against the reference's
+    own outputs on the committed golden inputs (tests/golden/adapose_b2.npz: B = 2, produced by importing the reference
+    module, tools/make_goldens.py).  The reference box is the device post-processing applied to the golden network outputs,
+    so the figure isolates the network's arithmetic.  north_star's gate is 1e-4."""
+    from rgbmanip_amd import synth
+    from rgbmanip_amd.adapose import postprocess
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adapose_b2.npz"))
+    inp = synth.adapose_inputs(2, seed=0)
+    out = net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"])
+    torch.cuda.synchronize()
+    keys = ["view1_nocs", "view2_nocs", "view1_depth", "view2_depth", "view1_r", "view2_r", "view1_t", "view2_t", "view1_s", "view2_s"]
+    errs = {k: float(np.abs(out[k].cpu().double().numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1e-12)) for k in keys}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    bb, _, _ = postprocess(out["view1_nocs"], out["view1_depth"], out["view1_r"], t(inp["choose1"]).int(), t(inp["K1"]), t(inp["E1"]))
+    rb, _, _ = postprocess(t(g["view1_nocs"]).float(), t(g["view1_depth"]).float(), t(g["view1_r"]).float(), t(inp["choose1"]).int(),
+                           t(inp["K1"]), t(inp["E1"]))
+    bbox_err = float((bb - rb).abs().max() / rb.abs().max())
+    return {"worst_output_rel_err": float(f"{max(errs.values()):.3e}"), "world_bbox_rel_err": float(f"{bbox_err:.3e}"),
+            "per_output": {k: float(f"{v:.2e}") for k, v in errs.items()}, "meets_1e-4": bool(max(errs.values()) < 1e-4)}
+
+
+def cpu_baseline_ppo(n_envs=4):
+    """PPO leg on the host cores: the oracle's controller step — numpy camera + render of the same synthetic
+    env, prepare_model_input, PyTorch-CPU network, numpy post-processing, policy act — timed on a bounded sample of envs, and
+    the oracle's learn phase (GAE + 32 optimiser steps) on a full 16 x 512 rollout; env-steps/s is extrapolated to 512 envs."""
+    from oracle import adapose_ref, postproc_ref, ppo_ref, synth_env_ref as sr
+    from rgbmanip_amd import synth
+    from rgbmanip_amd import synthetic_env as se
+    from rgbmanip_amd.config import RL_CONTROLLER_CFG
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    tsd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+    psd = {k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()}
+    robots, boxes = (np.stack(a) for a in zip(*[se.sample_scene(i, 0) for i in range(n_envs)]))
+    rng = np.random.default_rng(0)
+    f = se.CAM_F
+
+    def frame(shift):
+        cam = np.zeros((n_envs, 7))
+        cam[:, :3] = [0.0, 0.05 * shift, 0.7]
+        cam[:, 3:] = [1.0, 0.0, 0.0, 0.0]
+        K, E, rays = sr.camera_ref(cam, robots, boxes, f, f, 320.0, 240.0)
+        color, mask = sr.render_ref(rays, boxes, f, f, 320.0, 240.0, 480, 640, env0=0)
+        return K, E, color, mask
+
+    def env_step():
+        K, E1, c1, m1 = frame(0)
+        _, E2, c2, m2 = frame(1)
+        ins = []
+        for i in range(n_envs):
+            a = postproc_ref.prepare_model_input(c1[i], m1[i], K[i], 224, rng=rng)
+            b = postproc_ref.prepare_model_input(c2[i], m2[i], K[i], 224, rng=rng)
+            if a[0] is None or b[0] is None:
+                continue
+            P1, P2 = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+            P1[:3] = a[3] @ E1[i][:3]
+            P2[:3] = b[3] @ E2[i][:3]
+            ins.append((a, b, P1, P2, E1[i]))
+        if ins:
+            st = lambda xs, dt: torch.from_numpy(np.stack(xs)).to(dt)  # noqa: E731
+            dep = (torch.arange(24, dtype=torch.float32) * 0.1 + 0.1)[None].repeat(len(ins), 1)
+            o = adapose_ref.adapose_forward(tsd, st([i[0][0] for i in ins], torch.float32), st([i[0][1] for i in ins], torch.int64),
+                                            st([i[1][0] for i in ins], torch.float32), st([i[1][1] for i in ins], torch.int64),
+                                            st([i[2] for i in ins], torch.float32), st([i[3] for i in ins], torch.float32), dep)
+            for q, it in enumerate(ins):
+                postproc_ref.bbox_world(o["view1_nocs"][q].numpy(), o["view1_depth"][q].numpy(), o["view1_r"][q].numpy(), it[0][1], it[0][3], it[4])
+        ppo_ref.act(psd, torch.zeros(n_envs, 60), torch.zeros(n_envs, 12))
+        return len(ins)
+    t0 = time.perf_counter()
+    used = env_step()
+    per_env_step = (time.perf_counter() - t0) / max(used, 1)
+    T, N = 16, 512
+    roll = {k: torch.from_numpy(v) for k, v in synth.ppo_rollout(T, N, seed=0).items()}
+    t0 = time.perf_counter()
+    ret, adv = ppo_ref.compute_returns(roll["rewards"], roll["dones"], roll["values"], roll["last_values"], 0.98, 0.98)
+    lc = RL_CONTROLLER_CFG["learn"]
+    ppo_ref.ppo_update(psd, roll, ret, adv, lc, lc["learning_rate"])
+    learn_s = time.perf_counter() - t0
+    value = T * N / (T * N * per_env_step + learn_s)
+    return {"value": round(value, 3), "unit": "env-steps/s", "cores": cores, "kind": "port", "learn_s": round(learn_s, 3),
+            "cpu_s_per_env_step": round(per_env_step, 3),
+            "sample": f"controller step of the oracle (numpy synthetic camera, prepare_model_input, PyTorch-CPU network, numpy post-processing, "
+                      f"policy act) timed on {used} envs x 1 step, oracle learn phase (GAE + 32 optimiser steps) on a full 16 x 512 rollout; "
+                      f"extrapolated to 16 transitions x 512 envs, {cores} threads"}
+
+
 def cpu_baseline(n_chunks=6, chunk=2):
     """Oracle (kind "port") on the host cores: network forward + numpy post-processing, bounded sample."""
     from oracle import adapose_ref, postproc_ref
@@ -92,6 +193,9 @@ def main():
     ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32", "bf16x3"], help="storage type of the mixed-object leg (configs[4] names fp16)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
+    ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
+    ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the golden-vector accuracy leg (profiling runs: keeps the trace to the timed steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +254,33 @@ def main():
         elapsed = float(tt.item())
     n_valid = int(valid.sum().item())
     finite = bool(torch.isfinite(bbox).all().item())
+
+    # ---- accuracy of the benched mode and throughput + accuracy of the modes that meet north_star's 1e-4 gate (not part of `value`) ----
+    acc_res, modes_res = None, None
+    if rank == 0 and not args.no_accuracy:
+        acc_res = accuracy_vs_golden(net, device)
+    if rank == 0 and not args.no_modes:
+        modes_res = {}
+        for md in ("bf16x3", "fp32"):
+            if md == args.dtype:
+                continue
+            mnet2 = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=md, device=local_rank, max_chunk_views=args.chunk or None)
+            macc = accuracy_vs_golden(mnet2, device)
+
+            def mstep2():
+                o = mnet2(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
+                return postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"])
+            mstep2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.mode_steps):
+                mstep2()
+            torch.cuda.synchronize()
+            mdt = (time.perf_counter() - t1) / args.mode_steps
+            modes_res[md] = {"poses_per_sec": round(B / mdt, 1), "ms_per_step": round(mdt * 1e3, 2), "batch": B, "steps": args.mode_steps,
+                             "accuracy": macc}
+            del mnet2
+            torch.cuda.empty_cache()
 
     # ---- SURVEY 8f-1 leg (not part of `value`): device-side prepare_model_input on 480x640 frames, vs the host numpy path ----
     prep_res = None
@@ -264,14 +395,22 @@ def main():
         peak = PEAK_TFLOPS[dom["dtype"]]
         # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure is read
         # from the committed rocprofv3 --pmc measurement of this same command (tools/pmc_traffic.py -> profiles/)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, hbm_step = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and B == 256 and args.dtype == "bf16":
-            key = dom["kernel"].split(" (")[0].rstrip(">")       # kernel name incl. template arguments as rocprofv3 prints it
-            for kname, nbytes in json.load(open(tpath)).items():
-                if key in kname:
-                    traffic, traffic_src = float(nbytes), "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
-                    break
+        if os.path.exists(tpath) and B == 256:
+            tj = json.load(open(tpath))
+            meta = tj.get("_meta", {})
+            # a PMC measurement describes the tree it was taken on: a stale file is refused, not silently reused
+            if meta.get("tree") == tree_hash() and meta.get("dtype") == args.dtype:
+                key = dom["kernel"].split(" (")[0].rstrip(">")       # kernel name incl. template arguments as rocprofv3 prints it
+                for kname, nbytes in tj["bytes_per_launch"].items():
+                    if key in kname:
+                        traffic = float(nbytes)
+                        traffic_src = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this tree, 2*FETCH+WRITE)"
+                        break
+                hbm_step = meta.get("hbm_bytes_per_step")
+            else:
+                traffic_src = f"profiles/hbm_traffic.json is for tree {meta.get('tree')} / {meta.get('dtype')}, this is {tree_hash()} / {args.dtype}: not used"
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom["avg_launch_ms"], 4), "launches_per_step": dom["launches_per_step"],
@@ -283,11 +422,23 @@ def main():
             "config": {"workload": f"adapose_cabinet forward + post-processing, batch={B} poses ({2 * B} views of 224x224) per GPU, "
                                    "synthetic RGB, random-init weights of the reference architecture",
                        "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}"},
+            "tree": tree_hash(),
             "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
             "whole_net_frac_of_mfma_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
             "valid_poses_last_step": n_valid, "outputs_finite": finite,
             "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
+        # whole-net HBM rate: measured bytes per step (PMC, every kernel of one forward) against the algorithmic minimum of
+        # SURVEY 8(d) (0.54 GB per pose at 2 bytes per element: every conv reads its input once and writes its output once)
+        algo_gb_pose = 0.54 * (2.0 if args.dtype in ("fp32", "bf16x3") else 1.0)
+        res["whole_net_hbm"] = {"algorithmic_GBps": round(algo_gb_pose * value / world, 1), "algorithmic_GB_per_pose": algo_gb_pose,
+                                "measured_GBps": round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1) if hbm_step else None,
+                                "measured_GB_per_step": round(hbm_step / 1e9, 2) if hbm_step else None, "peak_GBps": 8000.0}
+        res["accuracy"] = acc_res
+        if modes_res is not None:
+            res["modes"] = modes_res
+        res["timed_region_note"] = ("rgbm_prof_start brackets every conv launch with two HIP events inside the timed region: the headline includes "
+                                    "that overhead; inputs are 16 unique poses tiled to the batch (no dedupe exists in the library)")
         if ppo_res is not None:
             res["ppo"] = ppo_res
         if prep_res is not None:
@@ -297,6 +448,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+            if ppo_res is not None:
+                res["ppo"]["cpu_baseline"] = cpu_baseline_ppo()
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

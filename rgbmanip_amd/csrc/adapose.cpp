@@ -348,8 +348,10 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
     d.prof_variant = dtype == BF16X3 ? (layer == 10 ? 28 : 27) : layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
-    d.algo_bytes = ((double)Vc * Di * Hi * Wi * t3d[li].Cin + (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) *
-                   (double)dtype_size(dtype);
+    // layer 10 (conv0 with the plane sweep fused in) reads the two feature maps of a pair, not the 32 x D x H x W volume it
+    // never materialises: algorithmic bytes = features in + c0 out
+    d.algo_bytes = ((layer == 10 ? (double)Vc * Hi * Wi * t3d[li].Cin : (double)Vc * Di * Hi * Wi * t3d[li].Cin) +
+                    (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) * (double)dtype_size(dtype);
     if (layer == 10 && cost_impl == 3 && b16 && sweep_w && !(dtype == F16 && (g_debug_flags & 4096))) {
       d.wgt = sweep_w;
       return launch_conv0_sweep(d, dtype, s);

@@ -13,6 +13,7 @@
 // offset, A operand (16 output channels x 32 k, BN folded, pre-swizzled per lane on the host) from L1/L2,
 // MFMA 16x16x32 bf16 (or 16x16x4 f32) accumulating in registers.  Transposed convs run their 8 sub-pixel
 // classes off one halo.  All loads of the staging phase are issued in batches so that many are in flight.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -251,12 +252,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
     for (int a = 0; a < FM; ++a)
 #pragma unroll
       for (int f = 0; f < NF; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(d.dbg & 2))
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      // halo byte offset of this step's tap for this lane; compile-time when one tap spans the whole step
-      int so;
-      bool pad = false;
+    // halo byte offset of step s's tap for this lane (compile-time when one tap spans the whole step); pad: the tap does not exist
+    auto step_off = [&](int s, int& so, bool& pad) {
+      pad = false;
       if constexpr (TPS == 1) {
         const int tap = s / SPT;
         so = (((tap / (KH * KW)) * HH + (tap / KW) % KH) * HW + tap % KW) * VS + (s % SPT) * 64;
@@ -265,6 +263,51 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
         pad = tap >= NT;
         so = (((tap / (KH * KW)) * HH + (tap / KW) % KH) * HW + tap % KW) * VS + (lg % GPT) * 16;
       }
+    };
+    if constexpr (std::is_same<T, bx3_t>::value) {
+      // split pairs: two consecutive steps (2 x 4 k values per lane, hi and lo) make the operands of the full-rate 16x16x32
+      // instruction; an odd last step runs on the K=16 form
+      if (!(d.dbg & 2))
+#pragma unroll
+      for (int s = 0; s < NS; s += 2) {
+        const bool two = s + 1 < NS;
+        int so0, so1 = 0;
+        bool pad0, pad1 = false;
+        step_off(s, so0, pad0);
+        if (two) step_off(s + 1, so1, pad1);
+        uint4 ah[FM], al[FM], a0[FM];
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+          a0[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
+          if (two) bx3_pair(a0[a], *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s + 1) * COUTP + a * 16) * 64), ah[a], al[a]);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool mp0 = (TPS > 1) && ((s + 1) * TPS > NT), mp1 = (TPS > 1) && ((s + 2) * TPS > NT);
+          const uint4 b0 = *reinterpret_cast<const uint4*>(halo + ((mp0 && pad0) ? ZERO_OFF : base[f] + so0));
+          if (two) {
+            const uint4 b1 = *reinterpret_cast<const uint4*>(halo + ((mp1 && pad1) ? ZERO_OFF : base[f] + so1));
+            uint4 bh, bl;
+            bx3_pair(b0, b1, bh, bl);
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
+              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bl), acc[a][f], 0, 0, 0);
+              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int a = 0; a < FM; ++a) Mma3<T>::run(a0[a], b0, acc[a][f]);
+          }
+        }
+      }
+    } else {
+    if (!(d.dbg & 2))
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int so;
+      bool pad;
+      step_off(s, so, pad);
       uint4 af[FM];
 #pragma unroll
       for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
@@ -277,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
 #pragma unroll
         for (int a = 0; a < FM; ++a) Mma3<T>::run(af[a], b, acc[a][f]);
       }
+    }
     }
     // ---- epilogue: bias (folded BN), ReLU, post-activation skip add, 4-channel vector store ----
     // All skip reads of the pass are requested before its first store, and the bias sits in registers (bv, loaded once per

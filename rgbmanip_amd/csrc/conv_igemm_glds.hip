@@ -77,6 +77,30 @@ template <typename T> constexpr int prof_row_generic(int bch) {
 }
 template <typename T> constexpr int prof_row_ws() { return std::is_same<T, bx3_t>::value ? 29 : sizeof(T) == 2 ? 13 : 12; }
 
+// bx3 K tile (32 channels = the two half-tile chunks of a lane): hi / lo operands of the full-rate 16x16x32 instruction,
+// three products per accumulator, small terms first, all (a, b) pairs of a term before the next term
+template <int FM, int FN>
+__device__ __forceinline__ void mma_bx3_tile(const uint4 (&a0)[FM], const uint4 (&a1)[FM], const uint4 (&b0)[FN], const uint4 (&b1)[FN],
+                                             f32x4 (&acc)[FM][FN]) {
+  uint4 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a) bx3_pair(a0[a], a1[a], ah[a], al[a]);
+#pragma unroll
+  for (int b = 0; b < FN; ++b) bx3_pair(b0[b], b1[b], bh[b], bl[b]);
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al[a], bh[b], acc[a][b]);
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
+}
+
 template <int N> struct IC { static constexpr int value = N; };
 
 __device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
@@ -226,6 +250,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
     if (kt + 1 < d.KT) issue(kt + 1, cur ^ 1);
     const uint4* W = lds + cur * STAGE;
     const uint4* X = W + BCH * 8;
+    if constexpr (std::is_same<T, bx3_t>::value) {
+      uint4 af[2][FM], bf[2][FN];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int cidx = s * 4 + lg;
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+          const int row = wch + a * 16 + lr;
+          af[s][a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+        }
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+          const int row = wpix + b * 16 + lr;
+          bf[s][b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+        }
+      }
+      mma_bx3_tile<FM, FN>(af[0], af[1], bf[0], bf[1], acc);
+    } else {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int cidx = s * 4 + lg;
@@ -244,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+    }
     }
     cur ^= 1;
   }
@@ -423,6 +466,25 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
   auto compute = [&](int st) {
     const uint4* W = lds3 + st * STAGE;
     const uint4* X = W + BCH * 8;
+    if constexpr (std::is_same<T, bx3_t>::value) {
+      uint4 af[2][FM], bf[2][FN];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int cidx = s * 4 + lg;
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+          const int row = wch + a * 16 + lr;
+          af[s][a] = W[row * 8 + (cidx ^ ((row >> 1) & 7))];
+        }
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+          const int row = wpix + b * 16 + lr;
+          bf[s][b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+        }
+      }
+      mma_bx3_tile<FM, FN>(af[0], af[1], bf[0], bf[1], acc);
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int cidx = s * 4 + lg;
@@ -726,23 +788,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
         RGBM_BARRIER();
         load_half(st, 0, af0, bf0);
         load_half(st, 1, af1, bf1);
-        uint4 ah[FM], al[FM], bh[FN], bl[FN];
-#pragma unroll
-        for (int a = 0; a < FM; ++a) bx3_pair(af0[a], af1[a], ah[a], al[a]);
-#pragma unroll
-        for (int b = 0; b < FN; ++b) bx3_pair(bf0[b], bf1[b], bh[b], bl[b]);
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al[a], bh[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bl[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
+        mma_bx3_tile<FM, FN>(af0, af1, bf0, bf1, acc);
         st = st == 2 ? 0 : st + 1;
       }
     } else {

@@ -460,26 +460,27 @@ def test_bf16_batch256_one_chunk_identical_to_128_view_chunks():
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
-def test_mixed_object_batch_equals_per_head_runs():
-    """BASELINE configs[4] (mixed cabinet / drawer / mug / pot batch): four weight sets (independent seeds), a
-    shuffled batch routed by head — every pose's outputs are bit-identical to running its head's estimator on that head's
-    samples alone, and the rank shards reassemble the batch."""
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_mixed_object_batch_equals_per_head_runs(dtype):
+    """BASELINE configs[4] (mixed cabinet / drawer / mug / pot batch, fp16 as the config names it; bf16 too): four weight sets
+    (independent seeds), a shuffled batch routed by head — every pose's outputs are bit-identical to running its
+    head's estimator on that head's samples alone, and the rank shards reassemble the batch."""
     from rgbmanip_amd.mixed import MixedObjectNet, shard_by_head
     sds = {h: synth.adapose_state_dict(seed=10 + h, prefix="module.") for h in range(4)}
     inp = synth.adapose_inputs(8, seed=21)
     heads = np.array([2, 0, 3, 1, 0, 2, 1, 3])
-    mixed = MixedObjectNet(sds, dtype="bf16")
+    mixed = MixedObjectNet(sds, dtype=dtype)
     keys = ("img1", "choose1", "img2", "choose2", "P1", "P2", "depths")
     got = {k: v.cpu().numpy() for k, v in mixed(heads, *[inp[k] for k in keys]).items()}
     for h in range(4):
         sel = np.nonzero(heads == h)[0]
-        alone = _run(_net_sd(sds[h], "bf16"), {k: inp[k][sel] for k in inp})
+        alone = _run(_net_sd(sds[h], dtype), {k: inp[k][sel] for k in inp})
         for k in OUT_KEYS:
             np.testing.assert_array_equal(got[k][sel], alone[k], err_msg=f"head {h} {k}")
     # two "ranks": each runs its shard, together they cover the batch with identical numbers
     for r in range(2):
         idx = shard_by_head(heads, r, 2)
-        part = MixedObjectNet(sds, dtype="bf16")(heads[idx], *[inp[k][idx] for k in keys])
+        part = MixedObjectNet(sds, dtype=dtype)(heads[idx], *[inp[k][idx] for k in keys])
         for k in OUT_KEYS:
             np.testing.assert_array_equal(part[k].cpu().numpy(), got[k][idx], err_msg=f"rank {r} {k}")
 

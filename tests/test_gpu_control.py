@@ -303,3 +303,150 @@ def test_fp16_estimator_in_the_control_loop():
         boxes[dt] = np.stack(out)
     scale = np.abs(boxes["fp32"]).max()
     assert np.abs(boxes["fp16"] - boxes["fp32"]).max() / scale < 2e-2
+
+
+class _SubsetEnvView:
+    """A strided subset of a full-size SyntheticMultiVecEnv as numpy arrays (what the reference's host code would see for
+    those envs).  The full env has to move ALL its cameras to stay identical to the device run's env, so every
+    `cam_move_to` replays the full-size pose the device run issued at that call, with the subset's rows replaced by the
+    poses the oracle computed for them."""
+
+    def __init__(self, env, sub, recorded_poses):
+        self.env, self.sub, self.rec, self.calls = env, torch.as_tensor(sub, device="cuda"), recorded_poses, 0
+        self.num_envs = len(sub)
+
+    def cam_move_to(self, pose, **kw):
+        full = self.rec[self.calls].clone()
+        self.calls += 1
+        p = torch.as_tensor(np.asarray(pose), dtype=torch.float64, device="cuda")
+        if full.dim() == 2 and p.dim() == 2:
+            full[self.sub] = p
+        else:
+            assert p.dim() == 1 and torch.allclose(full.reshape(-1)[:7], p, rtol=0, atol=1e-12)      # a broadcast pose (reset_robot)
+        ok, period = self.env.cam_move_to(full, **kw)
+        return [ok[self.sub].cpu().numpy(), period[self.sub].cpu().numpy()]
+
+    def get_image(self):
+        return {"camera0": {k: v[self.sub].cpu().numpy() for k, v in self.env.get_image()["camera0"].items()}}
+
+    def camera_pose(self, robot_frame=False):
+        return self.env.camera_pose(robot_frame)[self.sub].cpu().numpy()
+
+    def robot_pose(self):
+        return self.env.robot_pose()[self.sub].cpu().numpy()
+
+    def get_observation(self, gt=False):
+        return {k: v[self.sub].cpu().numpy() for k, v in self.env.get_observation(gt).items()}
+
+
+def test_control_step_and_ppo_iteration_at_512_envs(monkeypatch):
+    """BASELINE configs[2] at its own size: `ControlInterface.step` over 512 synthetic envs with the HIP estimator in the loop
+    (bf16x3: the mode inside the 1e-4 gate), checked on a strided subset of envs against the oracle — `ControlInterfaceRef`
+    for observations / dones / the 17 reward terms, and the CPU estimator pipeline (oracle prepare_model_input with the same
+    subset hash -> oracle network -> oracle post-processing) for the boxes — and then one full `PPO.run` iteration
+    (16 transitions x 512 envs, 32 optimiser steps) with the bf16 estimator the config names."""
+    from oracle import adapose_ref, control_ref as cr, postproc_ref
+    from oracle.control_ref import ControlInterfaceRef
+    from test_gpu_ppo import CFG
+    from rgbmanip_amd import synthetic_env as se
+    from rgbmanip_amd.config import ADAPOSE_CFGS
+    from rgbmanip_amd.control_interface import ControlInterface, REWARD_KEYS
+    from rgbmanip_amd.estimator import AdaPoseEstimator_v5, DEFAULT_BBOX
+    from rgbmanip_amd.ppo import PPO
+    N, steps, sub, seed = 512, 2, [0, 73, 255, 511], 1
+    ecfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device", hip_prepare_seed=seed)
+    sd = synth.adapose_state_dict(seed=0, prefix="module.")
+    est = AdaPoseEstimator_v5(None, ecfg, None, state_dict=sd, dtype="bf16x3")
+    boxes, poses = [], []
+
+    class Rec:
+        cfg = est.cfg
+
+        def estimate_device_indexed(self, *a):
+            b = est.estimate_device_indexed(*a)
+            boxes.append(b.cpu().numpy())
+            return b
+    ccfg = synth.control_cfg("cabinet", 0.0)
+    env = se.SyntheticMultiVecEnv(N, "cuda", seed=3)
+    move = env.cam_move_to
+
+    def rec_move(pose, **kw):
+        poses.append(torch.as_tensor(pose).to(device="cuda", dtype=torch.float64).clone())
+        return move(pose, **kw)
+    env.cam_move_to = rec_move
+    ci = ControlInterface(env, Rec(), se.SyntheticManipulation(env), ccfg)
+    acts = [synth.control_actions(N, s, 9) * 0.3 for s in range(steps)]
+    dev = [ci.step(torch.from_numpy(a).cuda()) for a in acts]
+    assert len(boxes) == steps and boxes[0].shape == (N, 8, 3)
+    assert float((ci.mask_queue.view(ci.max_steps, N, -1).sum(-1) > 0).float().mean()) > 0.3      # handles are seen
+
+    tsd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+    own = []
+
+    class OracleEstimator:
+        """CPU pipeline on the subset's frames; hands the DEVICE boxes on (so the reward terms see identical numbers) and
+        keeps its own for the comparison below."""
+        cfg = {"task_name": "cabinet"}
+
+        def __init__(self):
+            self.i = 0
+
+        def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+            out = np.repeat(DEFAULT_BBOX[None], len(sub), axis=0)
+            rows, ins = [], []
+            for j, e in enumerate(sub):
+                a = postproc_ref.prepare_model_input(rgb1[j], m1[j], K[j], 224, rng=("hash", seed, e))
+                b = postproc_ref.prepare_model_input(rgb2[j], m2[j], K[j], 224, rng=("hash", seed + 1, e))
+                if a[0] is None or b[0] is None:
+                    continue
+                P1, P2 = np.eye(4), np.eye(4)
+                P1[:3] = a[3] @ E1[j][:3]
+                P2[:3] = b[3] @ E2[j][:3]
+                rows.append(j)
+                ins.append((a, b, P1.astype(np.float32), P2.astype(np.float32)))
+            if rows:
+                t = lambda xs, dt: torch.from_numpy(np.stack(xs)).to(dt)  # noqa: E731
+                dep = (torch.arange(24, dtype=torch.float32) * 0.1 + 0.1)[None].repeat(len(rows), 1)
+                o = adapose_ref.adapose_forward(tsd, t([i[0][0] for i in ins], torch.float32), t([i[0][1] for i in ins], torch.int64),
+                                                t([i[1][0] for i in ins], torch.float32), t([i[1][1] for i in ins], torch.int64),
+                                                t([i[2] for i in ins], torch.float32), t([i[3] for i in ins], torch.float32), dep)
+                for q, j in enumerate(rows):
+                    out[j] = postproc_ref.bbox_world(o["view1_nocs"][q].numpy(), o["view1_depth"][q].numpy(), o["view1_r"][q].numpy(),
+                                                     ins[q][0][1], ins[q][0][3], E1[j])
+            own.append(out)
+            self.i += 1
+            return boxes[self.i - 1][sub]
+
+    env2 = se.SyntheticMultiVecEnv(N, "cuda", seed=3)
+    raw_lookat = cr.lookat_quat
+    monkeypatch.setattr(cr, "lookat_quat", lambda d: cr.canonical_quat(raw_lookat(d)))
+    # the reference's quat_to_axis scrambles its batch (transform.py:234: row i holds elements 3i..3i+2 of [A.., B.., C..] over
+    # ALL envs), so REW:ori_rew of an env depends on the other envs' cameras: the subset oracle gets the rows the FULL batch gives
+    raw_q2a = cr.quat_to_axis0
+    monkeypatch.setattr(cr, "quat_to_axis0", lambda q: raw_q2a(env2.camera_pose(robot_frame=True).cpu().numpy()[:, 3:])[sub])
+    ref = ControlInterfaceRef(_SubsetEnvView(env2, sub, poses), OracleEstimator(), None, ccfg)
+    for s, a in enumerate(acts):
+        obs, rew, done, info = ref.step(a[sub])
+        dobs, drew, ddone, dinfo = dev[s]
+        np.testing.assert_array_equal(dobs[sub].cpu().numpy(), obs)
+        np.testing.assert_array_equal(ddone[sub].cpu().numpy(), done)
+        for k in REWARD_KEYS:
+            np.testing.assert_allclose(dinfo[k][sub].cpu().numpy(), np.asarray(info[k], dtype=np.float64), rtol=0, atol=1e-9, err_msg=k)
+        # the estimator in the loop against the CPU pipeline on the same frames (fp32 oracle vs bf16x3 device)
+        got, exp = boxes[s][sub], own[s]
+        real = np.abs(exp - DEFAULT_BBOX).max(axis=(1, 2)) > 1e-9
+        assert np.array_equal(real, np.abs(got - DEFAULT_BBOX).max(axis=(1, 2)) > 1e-9)          # same samples fell back to the +10 cube
+        assert real.any()
+        err = np.abs(got[real] - exp[real]).max() / np.abs(exp[real]).max()
+        print(f"step {s}: device boxes vs CPU oracle pipeline on envs {sub}: rel err {err:.2e}")
+        assert err < 1e-3, (s, err)
+
+    # one learning iteration of the trainer at the config's size (bf16 estimator, as configs[2] names it)
+    est16 = AdaPoseEstimator_v5(None, ecfg, None, state_dict=sd, dtype="bf16")
+    env3 = se.SyntheticMultiVecEnv(N, "cuda", seed=1)
+    ppo = PPO(ControlInterface(env3, est16, se.SyntheticManipulation(env3), ccfg), CFG)
+    before = ppo.actor_critic.flat.clone()
+    ppo.run(1, log_interval=1, save_interval=10 ** 9)
+    assert torch.isfinite(ppo.actor_critic.flat).all() and not torch.equal(before, ppo.actor_critic.flat)
+    assert ppo.storage.observations.shape == (16, N, 60) and ppo.last_fps > 0
+    assert env3.episode.min() >= 3                                   # 16 transitions = 4 episodes of 4 steps, on every env

@@ -1,0 +1,86 @@
+"""-m gpu: the trainer's real multi-rank path — `RolloutStorage.compute_returns` and `PPO.update` of two
+ranks that each own half of the environments must leave every rank with the parameters a single process gets from all
+of them.  The box has one GPU: both ranks use cuda:0 and exchange through gloo (RCCL refuses two ranks on one device);
+the kernels and the host logic are exactly those of an 8-GPU run, only the transport differs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+T, N_TOTAL = 16, 64
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _train_once(lo, hi):
+    """One compute_returns + update on envs [lo, hi) of the recorded rollout (the fill of test_gpu_ppo.py / make_goldens.py)."""
+    from test_gpu_ppo import CFG, FakeEnv
+    from rgbmanip_amd import synth
+    from rgbmanip_amd.ppo import PPO
+    ppo = PPO(FakeEnv(hi - lo), CFG)
+    ppo.actor_critic.load_state_dict({k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()})
+    roll = synth.ppo_rollout(T, N_TOTAL, seed=0)
+    tr = {k: torch.from_numpy(v).cuda() for k, v in roll.items()}
+    ac = ppo.actor_critic
+    for t in range(T):
+        obs, act = tr["observations"][t][lo:hi].contiguous(), tr["actions"][t][lo:hi].contiguous()
+        lp, _, _, mm, ss, _ = ac.evaluate(obs, None, act)
+        mm = mm + 0.02 * torch.sin(torch.arange(12.0)).cuda()[None]
+        ppo.storage.add_transitions(obs, tr["states"][t][lo:hi], act, tr["rewards"][t].view(-1)[lo:hi], tr["dones"][t].view(-1)[lo:hi],
+                                    tr["values"][t][lo:hi], lp - 0.01, mm, ss - 0.005)
+    ppo.storage.compute_returns(tr["last_values"][lo:hi], 0.98, 0.98)
+    mvl, msl = ppo.update(0)
+    torch.cuda.synchronize()
+    return dict(flat=ac.flat.cpu().numpy(), adv=ppo.storage.advantages.cpu().numpy(), mvl=mvl, msl=msl, lr=ppo.step_size,
+                world=ppo.world)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = N_TOTAL // world
+    res = _train_once(rank * per, (rank + 1) * per)
+    res["rank"] = rank
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_single_process_update():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = _train_once(0, N_TOTAL)                                   # this process: no process group, all 64 envs
+    assert one["world"] == 1 and all(r["world"] == 2 for r in res)
+    # advantages: each rank's slice of the globally normalised vector (storage.py:63-64 over all T*N values)
+    adv = np.concatenate([r["adv"] for r in res], axis=1)
+    np.testing.assert_allclose(adv, one["adv"], rtol=1e-5, atol=1e-6)
+    # every rank ends with the same parameters, equal to the single-process ones; losses and the adaptive LR agree
+    np.testing.assert_array_equal(res[0]["flat"], res[1]["flat"])
+    scale = np.abs(one["flat"]).max()
+    assert np.abs(res[0]["flat"] - one["flat"]).max() / scale < 1e-5
+    for r in res:
+        assert abs(r["mvl"] - one["mvl"]) < 1e-5 * abs(one["mvl"]) and abs(r["msl"] - one["msl"]) < 1e-5 + 1e-4 * abs(one["msl"])
+        assert r["lr"] == one["lr"]
