@@ -41,6 +41,10 @@ int fail(const char* what, const char* file, int line);
     }                                                                                    \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for `fn` on the current device: raised whenever a launch needs more than was set
+// for that (device, kernel) so far (a once-per-process flag would leave a second device, or a later wider launch, without it)
+int ensure_dynamic_lds(const void* fn, int bytes);
+
 static inline size_t dtype_size(int dt) { return (dt == F32 || dt == BF16X3) ? 4 : 2; }
 static inline int dtype_chunk(int dt) { return 16 / (int)dtype_size(dt); }      // elements per 16-byte chunk
 static inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }

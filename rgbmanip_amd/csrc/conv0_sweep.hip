@@ -414,12 +414,8 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep arguments");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short>), SW_LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t>), SW_LDS)) return rc;
   prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
   if (dtype == BF16) hipLaunchKernelGGL(conv0_sweep_kernel<unsigned short>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   else hipLaunchKernelGGL(conv0_sweep_kernel<f16_t>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);

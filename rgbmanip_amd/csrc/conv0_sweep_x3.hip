@@ -243,18 +243,23 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     // (7 waves on 4 SIMDs: two waves share a SIMD's 512 registers), and a spill reload in a consumer waits on vmcnt, i.e. on
     // its output stores.
     u4v A01h[9], A01l[9], A2h[9];
-    // Operand registers of the plane loop and the hazard they are laid out for.  The first version of this loop was plain
-    // C++ (ds_read into `uint4` temporaries, MFMA builtins): about one (workgroup, consumer wave, plane) in a thousand came
-    // out wrong, differently from run to run — with one barrier per plane or two, with counted or drained gathers, while a
-    // dump of what the consumers READ from the ring was always right.  64 wait states of s_nop between a step's MFMAs and
-    // the next step's ds_reads made every run exact; 32 did not.  hipcc had (legally, by its hazard tables: `s_nop 2`)
-    // given the ds_reads destination registers that MFMAs issued just before still had to read — operand registers, and
-    // accumulator inputs it rotates (vDst != SrcC): on this part an LDS return can land in a register before an MFMA issued
-    // ~10 instructions earlier has read it.  (The same signature — one consumer wave, one input plane — is hazard (3) of
-    // the 16-bit sweep in DESIGN.md, where a third ring slot only moved the timing.)  So here nothing is left to the
-    // register allocator: accumulators are updated in place by inline-asm MFMAs and never serve as load destinations,
-    // and the operands rotate through three fixed register sets — a set is reloaded only after a whole further step of 12
-    // MFMAs has been issued behind its last reader.
+    // Operand registers of the plane loop.  The first version of this loop was plain C++ (ds_read into `uint4` temporaries,
+    // MFMA builtins, hipcc's own waits): about one (workgroup, consumer wave, input plane) in a thousand came out wrong,
+    // differently from run to run, always as ONE consumer wave's rows of three consecutive output planes — the signature of
+    // hazard (3) of the 16-bit sweep in DESIGN.md, where a third ring slot only moved the timing.  Established on the device:
+    // it is not the ring protocol (two barriers per plane: same rate), not the counted gathers (vmcnt(0) before every blend:
+    // same rate), not the ring's contents (a build that dumps what the consumers READ from the ring — first, centre and
+    // last tap — never showed a wrong value); 64 wait states of s_nop between a step's MFMAs and the next step's ds_reads
+    // made every run exact, 32 did not.  hipcc's schedule issues the next operands' ds_reads into registers that MFMAs issued
+    // a few instructions earlier still name as sources or accumulator inputs (it rotates accumulators, vDst != SrcC, and
+    // pads such reuses with `s_nop 2`).  A stand-alone reproduction of exactly those register reuses
+    // (tools/micro/mfma_lds_war.hip: B-operand reload, accumulator-input reload, dependent chains, with and without a
+    // VALU / ds_write stress wave on the same SIMD) shows NO corruption, so the mechanism is not isolated; what is established
+    // is the cure: nothing is left to the register allocator or the scheduler here.  Accumulators are updated in place by
+    // inline-asm MFMAs and never serve as load destinations, operands rotate through three fixed register sets (a set is
+    // reloaded only after a whole further step of 12 MFMAs has been issued behind its last reader), LDS reads and their counted
+    // waits are placed by hand.  Bit-stable over repeated runs at every size tried
+    // (test_conv0_sweep_bf16x3_matches_volume_then_conv, tools/debug_sweep_x3.py).
     u4v B[3][4];                       // [set][frag0 hi, frag0 lo, frag1 hi, frag1 lo]
     u4v AL[3];                         // lo weight operand of the kd=2 taps (from LDS), one per tap in flight
 #pragma unroll
@@ -357,7 +362,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
 #undef X3_STEP
           // the accumulators were written by inline-asm MFMAs, which the compiler's hazard recogniser does not see: the last
           // of them must have retired before VALU code (emit, the Xp <- Xn copies) reads its result (8-pass MFMA: 11+ wait states)
-          asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+          // — and every later read is made to depend on this statement (operands tied): without that the compiler may place
+          // emit's first VALU reads in front of the wait states, the asm having no visible connection to the accumulators
+          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Xn[3]) :: "memory");
           emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
           for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
@@ -415,11 +422,7 @@ int launch_conv0_sweep_x3(const Conv3dTileDesc& t, hipStream_t s) {
   RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31), "conv0 sweep grid out of range");
   d.n_tiles = (int)ntiles;
   static int n_cu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_sweep_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_x3_kernel), X3_LDS)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));

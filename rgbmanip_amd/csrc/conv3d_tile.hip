@@ -429,11 +429,7 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
   const long long nblk = (long long)d.N * d.ntd * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv3d grid out of range");
   auto kern = conv3d_tile_kernel<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WARP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)LDS)) return rc;
   d.dbg = g_debug_flags;
   prof_begin_launch(s, d.prof_variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, s, d);

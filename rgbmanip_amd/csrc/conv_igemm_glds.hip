@@ -981,11 +981,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   static int n_cu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T>), (int)LDS)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));
@@ -1467,12 +1463,8 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   static int n_cu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false, T>), 160 * 1024)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true, T>), 160 * 1024)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));
@@ -1504,11 +1496,7 @@ static int launch_v3(ConvDesc d, hipStream_t s) {
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long nblk = (long long)d.n_pix_tiles * d.n_ch_tiles;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T, UNI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_v3_kernel<T, UNI>), (int)LDS)) return rc;
   prof_begin_launch(s, prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_v3_kernel<T, UNI>), dim3((unsigned)nblk), dim3(512), LDS, s, d);
   prof_end_launch(s);

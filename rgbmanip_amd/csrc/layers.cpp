@@ -2,6 +2,8 @@
 
 #include <string.h>
 
+#include <map>
+#include <utility>
 #include <vector>
 
 namespace rgbm {
@@ -16,6 +18,18 @@ static inline unsigned short host_f32_to_bf16(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+int ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::map<std::pair<int, const void*>, int> set_for;      // (device, kernel) -> bytes granted; launches come from one thread per device
+  int dev = 0;
+  RGBM_CHECK_HIP(hipGetDevice(&dev));
+  int& have = set_for[std::make_pair(dev, fn)];
+  if (bytes > have) {
+    RGBM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+  }
+  return 0;
 }
 
 int upload_f32(const float* host, size_t n, float** dev) {

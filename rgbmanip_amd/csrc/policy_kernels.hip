@@ -313,11 +313,7 @@ int launch_ppo_minibatch(const float* params, const PolicyLayout& L, int n, cons
   for (int l = 0; l < 4; ++l) { asum += L.dims[l] + 1; if (l > 0 && L.dims[l] > wmax) wmax = L.dims[l]; }
   const size_t lds = (size_t)(PK_ROWS * (asum + 2 * (wmax + 1)) + PK_ROWS * 20) * sizeof(float);
   RGBM_REQUIRE(lds <= 160 * 1024, "policy too wide for the LDS-resident backward pass");
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_loss_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ppo_loss_grad_kernel), (int)lds)) return rc;
   hipLaunchKernelGGL(ppo_loss_grad_kernel, dim3(nblk), dim3(256), lds, s, params, L, n, obs, actions, old_logp, adv, returns,
                      old_values, old_mu, old_sigma, clip, vcoef, ecoef, partial, pstride);
   RGBM_CHECK_HIP(hipGetLastError());

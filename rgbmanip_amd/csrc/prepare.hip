@@ -240,16 +240,14 @@ int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const dou
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
                           unsigned char* small_scratch, hipStream_t s) {
   RGBM_REQUIRE(rgb && mask && K && img && choose && Kcrop && window && valid && small_scratch, "prepare_inputs arguments");
-  RGBM_REQUIRE(N > 0 && H >= 40 && W >= 40 && S > 0 && P > 0 && S * S <= 65536, "prepare_inputs sizes");
+  // the crop window is a square of up to 440 pixels shifted back into the frame (lib/utils.py:10-38 does it for 480 x 640): a
+  // smaller frame could not hold it and the shifted window would start at a negative row / column
+  RGBM_REQUIRE(N > 0 && H >= 440 && W >= 440 && S > 0 && P > 0 && S * S <= 65536, "prepare_inputs sizes (frames must be at least 440 x 440)");
   hipLaunchKernelGGL(mask_window_kernel, dim3(N), dim3(PRE_THREADS), 0, s, mask, K, frame_map, H, W, S, window, Kcrop, valid);
   const long long tot = (long long)N * S * S;
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rgb, mask, frame_map, window, N, H, W, S, img, small_scratch);
   const size_t lds = (size_t)S * S * sizeof(unsigned short);
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(choose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(choose_kernel), 150 * 1024)) return rc;
   hipLaunchKernelGGL(choose_kernel, dim3(N), dim3(PRE_THREADS), lds, s, small_scratch, window, S, P, seed, choose, pts2d, valid);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

@@ -122,6 +122,11 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
 
     # ------------------------------------------------------------------ interface_v5.py:58-170
     def prepare_model_input(self, rgb, mask, intrinsic, resize_size):
+        rgb = np.asarray(rgb)
+        if rgb.dtype == np.uint8:           # transforms.ToTensor scales uint8 images to [0, 1] (interface_v5.py:52-54,149); floats pass as they are
+            rgb = rgb.astype(np.float32) / np.float32(255.0)
+        elif rgb.dtype.kind != "f":
+            raise TypeError(f"prepare_model_input: rgb must be a float image in [0, 1] or uint8, got {rgb.dtype}")
         ys, xs = np.nonzero(mask)
         if len(ys) == 0:
             return None, None, None, None

@@ -500,8 +500,8 @@ def test_conv0_sweep_bf16x3_matches_volume_then_conv(shape):
     err = rel_err(y, ref)
     print(f"bf16x3 sweep {shape}: rel err {err:.2e}")
     assert err < 5e-5, shape            # operands at 2^-17, dropped lo*lo at 2^-18, output rounded to 2^-17
-    # bit-stable from run to run: the first version of the consumer loop was not (about one (workgroup, consumer wave, plane)
-    # in a thousand: LDS returns landing in registers that queued MFMAs still had to read — see conv0_sweep_x3.hip)
+    # bit-stable from run to run: the first, compiler-scheduled version of the consumer loop was not (about one (workgroup,
+    # consumer wave, input plane) in a thousand differed — see the note on the operand registers in conv0_sweep_x3.hip)
     for _ in range(3):
         y_again, _ = run(None)
         assert torch.equal(y_again, y), shape

@@ -147,3 +147,23 @@ def test_mixed_object_batches_shard_by_head():
     assert sorted(np.concatenate(parts).tolist()) == list(range(10))
     assert all((np.diff(heads[p]) >= 0).all() for p in parts) and heads[parts[0]].max() <= heads[parts[1]].min() <= heads[parts[2]].min()
     assert all(len(np.unique(heads[p])) <= 3 for p in parts)
+
+
+def test_prepare_model_input_uint8_follows_totensor():
+    """uint8 frames are scaled by 1/255 like torchvision's ToTensor (interface_v5.py:52-54,149) and then normalised in
+    float; other integer types are rejected (they used to divide by a mean / std cast to 0)."""
+    g = np.random.default_rng(2)
+    rgb8 = g.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    mask = np.zeros((480, 640), dtype=bool)
+    mask[180:320, 240:400] = True
+    K = np.array([[439.3, 0, 320.0], [0, 439.3, 240.0], [0, 0, 1.0]])
+    est = estimator.AdaPoseEstimator_v5.__new__(estimator.AdaPoseEstimator_v5)
+    est.cfg = config.ADAPOSE_CFGS["adapose_cabinet"]
+    est.rng = np.random.default_rng(7)
+    v8, c8, _, _ = est.prepare_model_input(rgb8, mask, K, 224)
+    est.rng = np.random.default_rng(7)
+    vf, cf, _, _ = est.prepare_model_input(rgb8.astype(np.float32) / np.float32(255.0), mask, K, 224)
+    assert np.array_equal(c8, cf) and torch.isfinite(v8).all()
+    np.testing.assert_allclose(v8.numpy(), vf.numpy(), rtol=0, atol=1e-6)
+    with pytest.raises(TypeError):
+        est.prepare_model_input(rgb8.astype(np.int32), mask, K, 224)
