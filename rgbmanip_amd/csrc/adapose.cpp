@@ -132,6 +132,13 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
+      if (i == 9 && dtype == BF16X3) {
+        // conv11 for the sparse tail (prob_sparse.hip): its step structure is the 16-bit kernels' (two taps x 16 channels per
+        // MFMA), so the weights are packed in that geometry and split into hi / lo operand arrays
+        std::vector<float> p16;
+        conv3d_tile_pack(w->data, scale.data(), cin[i], cout[i], coutp, true, BF16, p16);
+        if (conv0_sweep_x3_upload(p16, &w11_x3)) return -2;
+      }
       if (i == 0 && dtype != F32) {
         // the same conv0 weights in the depth-sweeping kernel's paired-tap fragment order (conv0_sweep.hip / conv0_sweep_x3.hip)
         conv0_sweep_pack(w->data, scale.data(), packed);
@@ -197,6 +204,8 @@ void AdaPose::destroy() {
   for (auto& t : t3d) { if (t.w) (void)hipFree(t.w); if (t.bias) (void)hipFree(t.bias); t.w = nullptr; t.bias = nullptr; }
   if (sweep_w) (void)hipFree(sweep_w);
   sweep_w = nullptr;
+  if (w11_x3) (void)hipFree(w11_x3);
+  w11_x3 = nullptr;
   if (wprob) (void)hipFree(wprob);
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
@@ -376,7 +385,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0)) return rc;
     if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0)) return rc;
-    if (cost_impl == 3 && b16 && igemm_conv6) {
+    if (cost_impl == 3 && (b16 || dtype == BF16X3) && igemm_conv6) {
       // conv6 (64 -> 64, K = 27 x 64): a plain GEMM shape, 2.7x faster on the role-specialised implicit-GEMM kernel
       if (int rc = c3d[6].run(bf.c[5], bf.c[6], Vc, D / 8, S / 8, S / 8, 64, nullptr, RES_NONE, nullptr, 0, s)) return rc;
     } else {
@@ -384,10 +393,10 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     }
     if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
     if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
-    if (cost_impl == 3 && b16 && sparse_tail) {
+    if (cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail) {
       // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
-      if (int rc = launch_prob_sparse(bf.u9, bf.c[0], t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc,
-                                      B, P, D, S, S, dtype, s)) return rc;
+      if (int rc = launch_prob_sparse(bf.u9, bf.c[0], dtype == BF16X3 ? w11_x3 : t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob,
+                                      bf.depth, v0, Vc, B, P, D, S, S, dtype, s)) return rc;
       continue;
     }
     if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;

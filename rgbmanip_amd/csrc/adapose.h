@@ -43,6 +43,7 @@ struct AdaPose {
   void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (16-bit nets; bf16x3 nets: hi + lo operand arrays of conv0_sweep_x3.hip)
   int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,
                                 // 3 = 2 with the depth-sweeping conv0 kernel (bf16; fp32 nets run 2)
+  void* w11_x3 = nullptr;       // bf16x3 nets: conv11 weights for prob_sparse (16-bit step geometry, hi operands then lo operands)
   float* wprob = nullptr;
   ConvLayer inst, nh[3], npm[2], pm1[2], pm2[2];
   float* pm2_0_wfull = nullptr;

@@ -38,7 +38,10 @@ namespace {
 constexpr int SW_TH = 12, SW_TW = 16;
 constexpr int SW_HH = SW_TH + 2, SW_HW = SW_TW + 2;
 constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
-constexpr int SW_VS = 80;                        // LDS bytes per voxel: 64 data + 16 pad (conflict-free b128 rows)
+#ifndef SW_VS_BYTES
+#define SW_VS_BYTES 80
+#endif
+constexpr int SW_VS = SW_VS_BYTES;               // LDS bytes per voxel: 64 data + 16 pad (conflict-free b128 rows)
 constexpr int SW_SLOT = SW_NV * SW_VS;           // 20160
 constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
 constexpr int SW_NCW = SW_TH / 4;                // 3 consumer waves, 4 fragments (rows) each

@@ -381,10 +381,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
   }
 }
 
-// fp32 fragment-order weights of conv0_sweep_pack ([18][16 rows][4 k-groups][8]) -> device array of bf16x8 operands:
-// the 18 x 16 x 4 hi operands followed by the lo operands
+// fp32 weights in a 16-bit kernel's fragment order ([operands][8 values]: conv0_sweep_pack's [18][16 rows][4 k-groups][8], or
+// conv3d_tile_pack in the BF16 geometry) -> device array of bf16x8 operands: all hi operands, followed by all lo operands
 int conv0_sweep_x3_upload(const std::vector<float>& packed, void** dev) {
-  RGBM_REQUIRE(packed.size() == (size_t)18 * 16 * 4 * 8, "conv0 sweep weights: unexpected size");
+  RGBM_REQUIRE(!packed.empty() && packed.size() % 8 == 0, "split operand upload: element count must be a multiple of 8");
   const size_t nop = packed.size() / 8;
   std::vector<unsigned short> h(2 * packed.size());
   auto bf = [](float f) {

@@ -12,6 +12,7 @@
 // the 16-byte half voxel its MFMA lane needs.  A class has 12, 24 or 48 neighbourhood voxels = 1..3 fragments.  The
 // 3 x 3 x D neighbourhood of u11 is kept in LDS in fp32 (never rounded to bf16, never written to HBM), then 24 lanes run
 // the 27-tap prob conv, and the wave reduces softmax and depth.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -22,9 +23,9 @@ namespace {
 constexpr int PS_DMAX = 24;
 
 struct ProbSparseDesc {
-  const unsigned short* u9;     // [Vc][D/2][H/2][W/2][16] bf16
-  const unsigned short* c0;     // [Vc][D][H][W][8] bf16
-  const unsigned short* w11;    // conv3d_tile_pack(conv11): [14 steps][16][4][8] bf16
+  const void* u9;               // [Vc][D/2][H/2][W/2][16] in the storage type
+  const void* c0;               // [Vc][D][H][W][8]
+  const void* w11;              // conv3d_tile_pack(conv11) in the 16-bit step geometry: [14 steps][16][4][8] (bf16x3: hi operands, then lo)
   const float* bias11;          // [16] folded BN shift
   const float* wprob;           // [27][8]
   const int* choose;            // [V][P]
@@ -43,6 +44,7 @@ template <> __device__ __forceinline__ f32x4 mma16<unsigned short>(const uint4& 
 template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+constexpr int PS_W11_OPS = 14 * 16 * 4;      // 16-byte weight operands of conv11 (bf16x3: the lo operands follow the hi ones)
 
 }  // namespace
 
@@ -66,9 +68,10 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
     *reinterpret_cast<f32x4*>(Uw + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  constexpr bool X3 = std::is_same<T, bx3_t>::value;      // split pairs: 8 channels = two 16-byte chunks {hi, lo}, three products
   const uint4* wq = reinterpret_cast<const uint4*>(d.w11);
-  const unsigned short* u9v = d.u9 + (long long)vl * Dq * Hq * Wq * 16;
-  const unsigned short* c0v = d.c0 + (long long)vl * D * H * W * 8;
+  const T* u9v = reinterpret_cast<const T*>(d.u9) + (long long)vl * Dq * Hq * Wq * 16;
+  const T* c0v = reinterpret_cast<const T*>(d.c0) + (long long)vl * D * H * W * 8;
 
   auto run_class = [&](auto pc) {
     constexpr int PASS = decltype(pc)::value;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
       const bool valid = active && slot < nvox && oz < D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
       const int qd = oz >> 1, qh = yy >> 1, qw = xx >> 1;              // input (u9) voxel of tap (0,0,0)
       // every gather of the fragment is requested before the first MFMA (masked lanes read voxel 0 and are zeroed)
-      uint4 bv[NS];
+      uint4 bv[NS], bv2[X3 ? NS : 1];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         // MFMA step s: lane groups 0,1 carry tap 2s, groups 2,3 tap 2s+1; each group one 16-byte half of the 16 channels
@@ -107,14 +110,30 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
         const int off = inb ? (((iz * Hq + iy) * Wq + ix) * 16 + (lg & 1) * 8) : 0;       // per-view offsets fit 32 bits (launcher checks)
         const uint4 t = *reinterpret_cast<const uint4*>(u9v + off);
         bv[s] = inb ? t : make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (X3) {                                             // channels +4..+7 of the lane's 8: the second chunk
+          const uint4 t2 = *reinterpret_cast<const uint4*>(u9v + off + 4);
+          bv2[s] = inb ? t2 : make_uint4(0u, 0u, 0u, 0u);
+        }
       }
       const bool wr = valid && lg < 2;
       const int ch = (lg & 1) * 4;
       float cv[4];
-      load4(reinterpret_cast<const T*>(c0v) + (wr ? (((oz * H + yy) * W + xx) * 8 + ch) : 0), cv);
+      load4(c0v + (wr ? (((oz * H + yy) * W + xx) * 8 + ch) : 0), cv);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (X3) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc = mma16<T>(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
+        for (int s = 0; s < NS; ++s) {
+          uint4 bh, bl;
+          bx3_pair(bv[s], bv2[s], bh, bl);
+          const uint4 wh = wq[((S0 + s) * 16 + lr) * 4 + lg], wl = wq[PS_W11_OPS + ((S0 + s) * 16 + lr) * 4 + lg];
+          acc = mma16<unsigned short>(wl, bh, acc);
+          acc = mma16<unsigned short>(wh, bl, acc);
+          acc = mma16<unsigned short>(wh, bh, acc);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc = mma16<T>(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
+      }
       if (wr) {
         f32x4 r;
 #pragma unroll
@@ -178,19 +197,18 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
                        int D, int H, int W, int dtype, hipStream_t s) {
-  RGBM_REQUIRE(dtype == BF16 || dtype == F16, "prob_sparse: 16-bit storage types only");
+  RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "prob_sparse: 16-bit storage types or bf16x3");
   RGBM_REQUIRE(u9 && c0 && w11_packed && bias11 && wprob && choose && depths && prob && depth_out, "prob_sparse arguments");
   RGBM_REQUIRE(D <= PS_DMAX && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0, "prob_sparse supports even D <= 24 and even H, W");
   RGBM_REQUIRE((long long)D * H * W * 8 < (1ll << 31), "prob_sparse view too large for 32-bit offsets");
   ProbSparseDesc d;
-  d.u9 = reinterpret_cast<const unsigned short*>(u9);
-  d.c0 = reinterpret_cast<const unsigned short*>(c0);
-  d.w11 = reinterpret_cast<const unsigned short*>(w11_packed);
+  d.u9 = u9; d.c0 = c0; d.w11 = w11_packed;
   d.bias11 = bias11; d.wprob = wprob; d.choose = choose; d.depths = depths; d.prob = prob; d.depth_out = depth_out;
   d.v0 = v0; d.Vc = Vc; d.B = B; d.P = P; d.D = D; d.H = H; d.W = W;
   const long long npts = (long long)Vc * P;
   RGBM_REQUIRE(npts > 0 && (npts + 3) / 4 < (1ll << 31), "prob_sparse grid out of range");
   if (dtype == BF16) hipLaunchKernelGGL(prob_sparse_kernel<unsigned short>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
+  else if (dtype == BF16X3) hipLaunchKernelGGL(prob_sparse_kernel<bx3_t>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(prob_sparse_kernel<f16_t>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

@@ -252,6 +252,24 @@ def test_bf16_sparse_tail_vs_dense_tail(inputs, oracle_taps):
     assert e_sparse < 3e-2 and e_sparse < e_dense + 5e-3
 
 
+def test_bf16x3_sparse_tail_vs_dense_tail(inputs, oracle_taps):
+    """The split-pair instantiation of prob_sparse.hip (u9 / c0 as bf16 hi + lo chunks, three MFMAs per product, u11 kept in
+    fp32) against the dense conv11 + gathering prob kernel on the same tensors, and both against the oracle: all inside the
+    fp32 gate."""
+    _, taps = oracle_taps
+    got = {}
+    for st in (0, 1):
+        net = _net("bf16x3", sparse_tail=st)
+        _run(net, inputs, stop_after=2)
+        got[st] = net.fetch(2, "prob", 4 * 1024 * 24).view(4, 1024, 24).cpu().numpy()
+    assert np.isfinite(got[1]).all()
+    np.testing.assert_allclose(got[1].sum(-1), 1.0, rtol=0, atol=1e-5)
+    ref = np.transpose(taps["v1_prob"].numpy(), (0, 2, 1))           # [2,1024,24]
+    e_dense, e_sparse = _rel(got[0][:2], ref), _rel(got[1][:2], ref)
+    print("bf16x3 prob error vs oracle: dense tail", e_dense, "sparse tail", e_sparse, "sparse vs dense", _rel(got[1], got[0]))
+    assert e_sparse < RTOL_FP32 and e_dense < RTOL_FP32 and _rel(got[1], got[0]) < 5e-5
+
+
 def test_nan_projection_stays_per_sample(inputs):
     """A degenerate pair (singular projection) must poison only its own pose."""
     inp = {k: v.copy() for k, v in inputs.items()}
