@@ -396,7 +396,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure is read
         # from the committed rocprofv3 --pmc measurement of this same command (tools/pmc_traffic.py -> profiles/)
         traffic, traffic_src, hbm_step = None, None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.dtype == "bf16" else f"hbm_traffic_{args.dtype}.json")
         if os.path.exists(tpath) and B == 256:
             tj = json.load(open(tpath))
             meta = tj.get("_meta", {})
@@ -410,7 +410,7 @@ def main():
                         break
                 hbm_step = meta.get("hbm_bytes_per_step")
             else:
-                traffic_src = f"profiles/hbm_traffic.json is for tree {meta.get('tree')} / {meta.get('dtype')}, this is {tree_hash()} / {args.dtype}: not used"
+                traffic_src = f"{os.path.basename(tpath)} is for tree {meta.get('tree')} / {meta.get('dtype')}, this is {tree_hash()} / {args.dtype}: not used"
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom["avg_launch_ms"], 4), "launches_per_step": dom["launches_per_step"],

@@ -177,7 +177,11 @@ def test_bf16_close_to_golden(inputs, golden_dir, cost_impl):
     print(f"bf16 (cost_impl={cost_impl}) vs reference golden:", errs)
     for k in OUT_KEYS:
         assert np.isfinite(out[k]).all(), k
-    assert errs["view1_depth"] < 3e-2 and errs["view1_nocs"] < 1e-1 and errs["view1_r"] < 1.5e-1, errs
+    # gates at 2x the measured errors (nocs 1.34e-2, depth 4.9e-3, R 2.97e-3, t 1.72e-3, s 5.7e-4): a regression of the
+    # bf16 path by a factor of two fails here
+    gate = {"nocs": 2.7e-2, "depth": 1.0e-2, "r": 6.0e-3, "t": 3.5e-3, "s": 1.2e-3}
+    for k in OUT_KEYS:
+        assert errs[k] < gate[k.split("_")[1]], (k, errs)
 
 
 @pytest.mark.parametrize("cost_impl", [3, 0])
@@ -190,7 +194,10 @@ def test_fp16_close_to_golden(inputs, golden_dir, cost_impl):
     print(f"fp16 (cost_impl={cost_impl}) vs reference golden:", errs)
     for k in OUT_KEYS:
         assert np.isfinite(out[k]).all(), k
-    assert errs["view1_depth"] < 5e-3 and errs["view1_nocs"] < 2e-2 and errs["view1_r"] < 2e-2, errs
+    # gates at 2x the measured errors (nocs 1.2e-3, depth 8.3e-4, R 5.8e-5, t 1.5e-4, s 3.5e-5)
+    gate = {"nocs": 2.4e-3, "depth": 1.7e-3, "r": 1.2e-4, "t": 3.0e-4, "s": 7.0e-5}
+    for k in OUT_KEYS:
+        assert errs[k] < gate[k.split("_")[1]], (k, errs)
 
 
 def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
