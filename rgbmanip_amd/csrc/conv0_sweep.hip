@@ -38,6 +38,18 @@ namespace {
 constexpr int SW_TH = 12, SW_TW = 16;
 constexpr int SW_HH = SW_TH + 2, SW_HW = SW_TW + 2;
 constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
+#ifndef SW_HAND
+#define SW_HAND 0     // consumer plane loop: 0 = the compiler-scheduled C++ loop (default: 18.1 ms per batch-256 step in bf16), 1 = hand-
+                      // scheduled like conv0_sweep_x3.hip (in-place asm MFMAs, operand reads rotating through four pinned register sets,
+                      // counted lgkmcnt: 20.0 ms).  Round-2 A/B on the f16 build, 5 runs at batch 256 (tools/f16_sweep_check.py): both
+                      // schedules are bit-stable with the three-slot plane ring and neither is with two slots (compiler schedule: ~100 of
+                      // 512 views differ, always one consumer wave's rows of output planes 2-4; hand schedule: every view differs) — with
+                      // one workgroup per CU forced and with all waves retiring together as well, while the ring + barrier protocol in
+                      // isolation (tools/micro/ring_barrier.hip: two slots, 5.4e9 checked reads per variant) never fails.
+#endif
+#ifndef SW_NSLOT_N
+#define SW_NSLOT_N 3
+#endif
 #ifndef SW_VS_BYTES
 #define SW_VS_BYTES 80
 #endif
@@ -54,8 +66,14 @@ constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
 // slower (explicit saturation code in the pack) was stable, and so is the third slot, which gives every plane one more
 // barrier interval before its slot is reused (tools/f16_sweep_check.py 256).  60 KB per workgroup; occupancy is set by
 // the VGPRs, not by LDS.
-constexpr int SW_NSLOT = 3;
-constexpr int SW_LDS = SW_NSLOT * SW_SLOT;
+constexpr int SW_NSLOT = SW_NSLOT_N;
+#ifndef SW_LDS_PAD
+#define SW_LDS_PAD 0       // experiment builds: extra dynamic LDS per workgroup (forces one workgroup per CU)
+#endif
+#ifndef SW_EXIT_BARRIER
+#define SW_EXIT_BARRIER 0  // experiment builds: one more barrier after the last plane, so that all waves of a workgroup retire together
+#endif
+constexpr int SW_LDS = SW_NSLOT * SW_SLOT + SW_LDS_PAD;
 static_assert(SW_TH % 4 == 0, "a consumer wave owns 4 rows");
 
 struct SweepDesc {
@@ -77,7 +95,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;     // native vector: usable as a tied inline-asm operand
 
 template <typename T> struct Sw16;                                   // the two 16-bit storage types of this kernel
+typedef __attribute__((ext_vector_type(4))) unsigned sw_u4v;       // native vector: usable as a tied inline-asm operand
+#define SW_MFMA_BF16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define SW_MFMA_F16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 template <> struct Sw16<unsigned short> {                            // bf16: a dword's halves are the high halves of two floats
+  __device__ static __forceinline__ void mma_inplace(f32x4& c, const sw_u4v& a, const sw_u4v& b) { SW_MFMA_BF16(c, a, b); }
   __device__ static __forceinline__ f32x2 unpack(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
   __device__ static __forceinline__ unsigned pack(f32x2 v) { return pack2_bf16(v.x, v.y); }
   __device__ static __forceinline__ f32x4 mma(const uint4& a, const uint4& b, const f32x4& c) {
@@ -86,6 +108,7 @@ template <> struct Sw16<unsigned short> {                            // bf16: a 
 };
 template <> struct Sw16<f16_t> {
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  __device__ static __forceinline__ void mma_inplace(f32x4& c, const sw_u4v& a, const sw_u4v& b) { SW_MFMA_F16(c, a, b); }
   __device__ static __forceinline__ f32x2 unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(h2, u), f32x2); }
   __device__ static __forceinline__ unsigned pack(f32x2 v) {
     const h2 h = {(f16_t)sat_f16(v.x), (f16_t)sat_f16(v.y)};
@@ -292,6 +315,9 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
     }
+#if SW_EXIT_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
 #undef SW_GATHER
 #undef SW_GATHER4
 #undef SW_WAIT12
@@ -299,6 +325,39 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
     // ------------------------------------------------------------------ consumers
     const int cw = wave - SW_NPW;
     const int lr = lane & 15, lg = lane >> 4;
+#if SW_HAND
+    sw_u4v A01[9], A2[9];
+    {
+      const uint4* wq = reinterpret_cast<const uint4*>(d.wgt);
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const uint4 t0 = wq[(s * 16 + lr) * 4 + lg], t1 = wq[((9 + s) * 16 + lr) * 4 + lg];
+        A01[s] = sw_u4v{t0.x, t0.y, t0.z, t0.w};
+        A2[s] = sw_u4v{t1.x, t1.y, t1.z, t1.w};
+      }
+    }
+    // Operand registers of the plane loop: four fixed sets of two fragments, reloaded by hand (see conv0_sweep_x3.hip for the
+    // run-to-run corruption a compiler-scheduled loop of this shape showed there; this kernel's own hazard (3) in DESIGN.md
+    // has the same signature).  A set is reloaded only after two further half-tap steps (8 MFMAs) have been issued behind its
+    // last reader; accumulators are updated in place and never serve as load destinations.  (Three sets of four fragments,
+    // as in the split-pair kernel, do not fit the 168-register budget of three waves per SIMD.)
+    sw_u4v Bq[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bq[i][0] = Bq[i][1] = sw_u4v{0u, 0u, 0u, 0u};
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
+#define SW_BOFF(TP, F) ((((F) + (TP) / 3) * SW_HW + (TP) % 3) * SW_VS)
+    // step I = in-plane tap I / 2, fragments 2 * (I % 2) and 2 * (I % 2) + 1, register set I % 4
+#define SW_LDB(I)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "+v"(Bq[(I) % 4][0]), "+v"(Bq[(I) % 4][1])    \
+                 : "v"(sa), "n"(SW_BOFF((I) / 2, 2 * ((I) % 2))), "n"(SW_BOFF((I) / 2, 2 * ((I) % 2) + 1)) : "memory");
+#define SW_MMA4(I)                                                                                                   \
+    Sw16<T>::mma_inplace(Xn[2 * ((I) % 2)], A01[(I) / 2], Bq[(I) % 4][0]); Sw16<T>::mma_inplace(Xp[2 * ((I) % 2)], A2[(I) / 2], Bq[(I) % 4][0]);          \
+    Sw16<T>::mma_inplace(Xn[2 * ((I) % 2) + 1], A01[(I) / 2], Bq[(I) % 4][1]); Sw16<T>::mma_inplace(Xp[2 * ((I) % 2) + 1], A2[(I) / 2], Bq[(I) % 4][1]);
+#define SW_STEP(I, NEXT, WAITN)                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" ::: "memory");                                                      \
+    SW_MMA4(I)                                                                                                       \
+    NEXT
+#else
     uint4 A01[9], A2[9];
     {
       const uint4* wq = reinterpret_cast<const uint4*>(d.wgt);
@@ -308,6 +367,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
         A2[s] = wq[((9 + s) * 16 + lr) * 4 + lg];
       }
     }
+#endif
     // after the lane-half swap a lane holds: fragment (lg < 2 ? first : second of the pair), voxel lr, channels (lg&1)*4..+3
     const int ch = (lg & 1) * 4;
     float bias[4];
@@ -358,6 +418,21 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
         f32x4 Xn[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if SW_HAND
+        // 18 half-tap steps of 2 fragment reads + 4 MFMAs; the reads of step i + 2 are issued behind the MFMAs of step i into the
+        // set step i - 2 multiplied from; at step i the reads of steps i and i + 1 are outstanding and LDS operations complete
+        // in order, so step i's have landed once at most 2 remain
+        (void)slot;
+        const unsigned sa = lds_base + (unsigned)((p % SW_NSLOT) * SW_SLOT + boff);
+        SW_LDB(0) SW_LDB(1)
+        SW_STEP(0, SW_LDB(2), 2) SW_STEP(1, SW_LDB(3), 2) SW_STEP(2, SW_LDB(4), 2) SW_STEP(3, SW_LDB(5), 2) SW_STEP(4, SW_LDB(6), 2)
+        SW_STEP(5, SW_LDB(7), 2) SW_STEP(6, SW_LDB(8), 2) SW_STEP(7, SW_LDB(9), 2) SW_STEP(8, SW_LDB(10), 2) SW_STEP(9, SW_LDB(11), 2)
+        SW_STEP(10, SW_LDB(12), 2) SW_STEP(11, SW_LDB(13), 2) SW_STEP(12, SW_LDB(14), 2) SW_STEP(13, SW_LDB(15), 2) SW_STEP(14, SW_LDB(16), 2)
+        SW_STEP(15, SW_LDB(17), 2) SW_STEP(16, , 2) SW_STEP(17, , 0)
+        // asm MFMAs are opaque to the compiler's hazard recogniser: wait states before any VALU read of their results, tied to
+        // the accumulators so that no such read can be scheduled in front of them
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Xn[3]) :: "memory");
+#else
 #pragma unroll
         for (int tp = 0; tp < ((SW_ABL & 2) ? 0 : 9); ++tp) {
 #pragma unroll
@@ -367,6 +442,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
             Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
           }
         }
+#endif
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
         for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
@@ -382,6 +458,9 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       asm volatile("" ::: "memory");
     }
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
+#if SW_EXIT_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
   }
 }
 
