@@ -638,6 +638,9 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
 
   if (wave >= 8) {
     // ------------------------------------------------------------------ request waves
+#ifdef WS_PRIO
+    if (WS_PRIO == 3) __builtin_amdgcn_s_setprio(2);
+#endif
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
     const int pw = wave - 8;
@@ -722,6 +725,12 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   }
 
   // -------------------------------------------------------------------- multiply waves
+#ifdef WS_PRIO
+  // experiment builds: 1 = the second-dispatched half of the multiply waves at static priority 1, 2 = all multiply waves above
+  // the request waves, 3 = request waves above the multiply waves (set in their branch)
+  if (WS_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+#endif
   const int wch = (wave >> 2) * 64;
   const int wpix = (wave & 3) * 64;
   const int lr = lane & 15, lg = lane >> 4;
