@@ -138,6 +138,11 @@ def cpu_baseline_ppo(n_envs=4):
     per_env_step = (time.perf_counter() - t0) / max(used, 1)
     T, N = 16, 512
     roll = {k: torch.from_numpy(v) for k, v in synth.ppo_rollout(T, N, seed=0).items()}
+    with torch.no_grad():      # the rollout's recorded policy outputs (untimed: the env-step leg above already counts policy act)
+        lp, _, _, mu, sig = ppo_ref.evaluate(psd, roll["observations"].reshape(T * N, -1), roll["actions"].reshape(T * N, -1))
+    roll["actions_log_prob"] = lp.reshape(T, N, 1) - 0.01
+    roll["mu"] = mu.reshape(T, N, -1)
+    roll["sigma"] = sig.reshape(T, N, -1) - 0.005
     t0 = time.perf_counter()
     ret, adv = ppo_ref.compute_returns(roll["rewards"], roll["dones"], roll["values"], roll["last_values"], 0.98, 0.98)
     lc = RL_CONTROLLER_CFG["learn"]

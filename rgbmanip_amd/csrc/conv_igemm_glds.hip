@@ -1007,6 +1007,304 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves of 128 channels x 64 pixels (layers whose output channels are a multiple of 256: layer3, layer4,
+// up_1 — 96 % of the implicit GEMM's flops).  Why: the role-specialised kernel above pays one 12-wave barrier, one LDS fill of
+// 48 KB and 16 fragment reads per wave for every 32 MFMAs per wave; its counters show the multiply waves 38 % of their cycles
+// in s_waitcnt / s_barrier and 37 % stalled at issue, with the matrix pipe 45 % busy.  Here a K tile carries 64 MFMAs per wave
+// for 24 fragment reads and one 8-wave barrier, and the operand bytes that cross L2 -> LDS per flop drop by a third
+// ((256+256)/(256*256) against (128+256)/(128*256)).  128 accumulator registers per lane leave no room for a separate request
+// role at three waves per SIMD, so every wave issues its own eighth of the tile's LDS-DMA (8 pieces per K tile, wave-uniform tap
+// walk) right behind the barrier; two 64 KB stages; the K-tile sequence runs on across tile boundaries (persistent workgroups),
+// so the first K tile of the next tile lands under the epilogue of the current one.
+// vmcnt: loads and stores of a wave retire out of order with respect to each other on gfx9, so a counted wait cannot be used once
+// epilogue stores are in flight; every wait here is vmcnt(0) — at the one point per K tile where nothing but the tile that is
+// about to be multiplied is outstanding.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc d) {
+  constexpr int BCH = 256, BPIX = 256;
+  constexpr int E = 8, BK = 64;
+  constexpr int FM = 8, FN = 4;
+  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (64 KB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
+  static_assert(sizeof(T) == 2, "16-bit storage types only");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+  const int KT = d.KT;
+  const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = n_my * KT;
+  auto tile_of = [&](int k, int& pix_tile, int& ch_tile) {
+    const int v = (int)blockIdx.x + k * (int)gridDim.x;
+    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
+    const int lid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+    pix_tile = lid / d.n_ch_tiles;
+    ch_tile = lid - pix_tile * d.n_ch_tiles;
+  };
+  float* lbias = reinterpret_cast<float*>(lds3 + 2 * STAGE);
+  const bool bias_lds = d.bias != nullptr && d.bias_stride == 0 && d.Cout <= 2048;
+  if (bias_lds)
+    for (int i = tid; i < d.Cout; i += 512) lbias[i] = d.bias[i];
+  __syncthreads();
+
+  // ---- request side: this wave's pieces of a K tile.  Piece p = rows 8p .. 8p+7 (1 KB); wave w owns pieces w, w+8, w+16, w+24 of
+  // the X tile and of the W tile.  Lane (r8, j) fills slot (row, j) with source chunk j ^ swizzle(row).
+  const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+  const int j = lane & 7, r8 = lane >> 3;
+  const char* rowp[4];
+  unsigned rmask[4];
+  const char* wrow[4];
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // wave-uniform tap walker
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3));
+  auto enter_tile = [&](int k) {
+    int pix_tile, ch_tile;
+    tile_of(k, pix_tile, ch_tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * i) * 8 + r8;
+      const long long m = (long long)pix_tile * BPIX + row;
+      int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
+      if (m < d.M) {
+        unsigned n, qd, qh, qw;
+        decode_row(d, (unsigned)m, n, qd, qh, qw);
+        xn = (int)n * d.Di;
+        xd0 = (int)qd * d.sd - d.pd;
+        xh0 = (int)qh * d.sh - d.ph;
+        xw0 = (int)qw * d.sw - d.pw;
+      }
+      unsigned mk = 0;
+      for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+      for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+      for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
+      rmask[i] = mk;
+      const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
+      rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((row >> 1) & 7)) * E) * 2ll;
+      wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
+    }
+    tkd = tkh = tkw = tc = 0;
+  };
+  int ikt = 0, itile = 0;
+  auto issue = [&](int stage) {
+    if (ikt == 0) enter_tile(itile);
+    const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
+    const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+    const long long soff = ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * 2ll;
+    const bool cok = tkd < d.KD && tc + (j ^ 0) * 0 < d.Cin;      // K tiles never straddle Cin here (Cin % 64 == 0 or 1x1 padded)
+    const long long wk = (long long)ikt * BK * 2ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = cok && (rmask[i] & sel) == sel;
+      glds16(ok ? rowp[i] + soff : zero, sbase + (BCH * 8 + (wave + 8 * i) * 64) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(wrow[i] + wk, sbase + ((wave + 8 * i) * 64) * 16);
+    tc += BK;
+    if (d.lcin >= 0 && tc >= d.Cin) {
+      tc = 0;
+      if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+    }
+    if (++ikt == KT) { ikt = 0; ++itile; }
+  };
+
+  // ---- multiply side ----
+  const int wch = (wave >> 2) * 128;
+  const int wpix = (wave & 3) * 64;
+  const int lr = lane & 15, lg = lane >> 4;
+  f32x4 acc[FM][FN];
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
+  auto tile_interior = [&](int pix_tile, int ch_tile) {
+    return (d.bias == nullptr || bias_lds) && (long long)(pix_tile + 1) * BPIX <= d.M && (ch_tile + 1) * BCH <= d.Cout && d.act != ACT_TANH;
+  };
+  auto seed_acc = [&](int k) {
+    int pt, ct;
+    tile_of(k, pt, ct);
+    if (tile_interior(pt, ct) && d.bias) {
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        // fragment a of 64-channel group a >> 2: the lane's channels are group*64 + lg*16 + (a&3)*4 ..
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + ct * BCH + wch + (a >> 2) * 64 + lg * 16 + (a & 3) * 4);
+#pragma unroll
+        for (int b = 0; b < FN; ++b) acc[a][b] = b4;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto compute = [&](int stage) {
+    const uint4* W = lds3 + stage * STAGE;
+    const uint4* X = W + BCH * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int cidx = s2 * 4 + lg;
+      uint4 af[FM], bf[FN];
+#pragma unroll
+      for (int b = 0; b < FN; ++b) {
+        const int row = wpix + b * 16 + lr;
+        bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        const int row = wch + (a >> 2) * 64 + (lr >> 2) * 16 + (a & 3) * 4 + (lr & 3);     // the ws kernel's row permutation per 64-channel group
+        af[a] = W[row * 8 + (cidx ^ swz_w(row))];
+      }
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
+    }
+  };
+  auto epilogue = [&](int k) {
+    int pix_tile, ch_tile;
+    tile_of(k, pix_tile, ch_tile);
+    const bool interior = tile_interior(pix_tile, ch_tile);
+    long long obase[FN];
+    int nn[FN];
+    bool pok[FN];
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
+      pok[b] = m < d.M;
+      unsigned n, qd, qh, qw;
+      decode_row(d, pok[b] ? (unsigned)m : 0u, n, qd, qh, qw);
+      nn[b] = (int)n;
+      obase[b] = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo;
+    }
+    const float slope = d.slope;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {                  // the wave's two 64-channel groups: 16 consecutive channels per lane each
+      const int chL = ch_tile * BCH + wch + grp * 64 + lg * 16;
+      if (interior) {
+        auto fast = [&](auto actc, auto resc) {
+          constexpr int ACT = decltype(actc)::value, RES = decltype(resc)::value;
+          uint4 rr[2][FN];
+          if (RES != RES_NONE) {
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) rr[q][b] = *reinterpret_cast<const uint4*>(res + obase[b] + chL + q * 8);
+          }
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float v[8], rv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = acc[grp * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3];
+              if (RES != RES_NONE) unpack_chunk(rr[q][b], rv, T());
+              if (RES == RES_PRE_ACT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                v[e] = ACT == ACT_RELU ? (v[e] < 0.f ? 0.f : v[e]) : ACT == ACT_PRELU ? (v[e] < 0.f ? v[e] * slope : v[e]) : v[e];
+              if (RES == RES_POST_ACT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+              }
+              *reinterpret_cast<uint4*>(out + obase[b] + chL + q * 8) = pack_chunk(v, T());
+            }
+        };
+        auto by_res = [&](auto actc) {
+          if (d.res_mode == RES_NONE) fast(actc, IC<RES_NONE>{});
+          else if (d.res_mode == RES_PRE_ACT) fast(actc, IC<RES_PRE_ACT>{});
+          else fast(actc, IC<RES_POST_ACT>{});
+        };
+        if (d.act == ACT_RELU) by_res(IC<ACT_RELU>{});
+        else if (d.act == ACT_PRELU) by_res(IC<ACT_PRELU>{});
+        else by_res(IC<ACT_NONE>{});
+        continue;
+      }
+      // ragged tiles (last pixel tile), per-sample bias, tanh: per-chunk checks
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = chL + q * 8;
+          if (!pok[b] || c >= d.Cout) continue;
+          const bool whole = c + 8 <= d.Cout;
+          float v[8], rv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = acc[grp * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3]; rv[e] = 0.f; }
+          if (d.bias) {
+            const float* bp = d.bias + (long long)nn[b] * d.bias_stride + c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < 4 || whole) v[e] += bp[e];
+          }
+          if (d.res_mode != RES_NONE) {
+            if (whole) unpack_chunk(*reinterpret_cast<const uint4*>(res + obase[b] + c), rv, T());
+            else load4(res + obase[b] + c, rv);
+          }
+          if (d.res_mode == RES_PRE_ACT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
+          if (d.res_mode == RES_POST_ACT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (whole) *reinterpret_cast<uint4*>(out + obase[b] + c) = pack_chunk(v, T());
+          else store4(out + obase[b] + c, v);
+        }
+    }
+  };
+
+  if (total > 0) issue(0);
+  int k = 0, kt = 0;
+  if (n_my > 0) seed_acc(0);
+  for (int g = 0; g < total; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step g (and any epilogue stores) have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its fragment reads of step g-1 have returned
+    RGBM_BARRIER();              // step g is complete in LDS; every wave is done with the other stage
+    if (g + 1 < total) issue((g + 1) & 1);
+    compute(g & 1);
+    if (++kt == KT) {
+      epilogue(k);
+      kt = 0;
+      if (++k < n_my) seed_acc(k);
+    }
+  }
+}
+
+template <typename T>
+static int launch_w256(ConvDesc d, hipStream_t s) {
+  constexpr int BCH = 256, BPIX = 256;
+  constexpr size_t LDS = 2 * (BCH + BPIX) * 8 * sizeof(uint4) + 2048 * sizeof(float);      // two 64 KB stages + per-channel bias table
+  d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
+  d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
+  const long long ntiles = (long long)d.n_pix_tiles * d.n_ch_tiles;
+  RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31) && d.M < (1ll << 31), "conv grid out of range");
+  d.n_tiles = (int)ntiles;
+  make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
+  make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
+  make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_w256_kernel<T>), (int)LDS)) return rc;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    RGBM_CHECK_HIP(hipGetDevice(&dev));
+    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
+  prof_begin_launch(s, 30, d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL((conv_igemm_w256_kernel<T>), dim3((unsigned)grid), dim3(512), LDS, s, d);
+  prof_end_launch(s);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 256 pixel x 64 channel tile, bf16, three roles (layers with 33..64 output channels and no residual: up_2, up_3).
 // These layers have short K (9..36 K tiles) and 6.6 GB of activations per launch: with the 2-stage kernel the epilogue
 // (8-byte stores from the MFMA C layout) and the pipeline refill of every tile left them at 0.43 PFLOP/s / 1.5 TB/s.
@@ -1543,6 +1841,11 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
     // role-specialised (uniform taps, 16-byte aligned output / residual rows)
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
+    if constexpr (sizeof(T) == 2) {
+      // 256 x 256 tiles for the layers whose channel count allows them (debug flag 8192 selects the 128 x 256 kernel for A/B)
+      if (uni && (al & 15ull) == 0ull && d.Cout % 256 == 0 && d.Cin % 64 == 0 && d.KT >= 2 && (g_debug_flags & 8192) && !(g_debug_flags & 64))
+        return launch_w256<T>(d, s);
+    }
     if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) return launch_ws<T>(d, s);
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
