@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
     ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
     ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
+    ap.add_argument("--debug-flags", type=int, default=0, help="kernel A/B switches (rgbm_debug_flags); a non-zero value is echoed in config")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the golden-vector accuracy leg (profiling runs: keeps the trace to the timed steps)")
     args = ap.parse_args()
 
@@ -227,6 +228,8 @@ def main():
     from rgbmanip_amd import _lib, synth
     from rgbmanip_amd.adapose import AdaPoseNet, postprocess
     lib = _lib.load()
+    if args.debug_flags:
+        lib.rgbm_debug_flags(args.debug_flags)
     net = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank,
                      max_chunk_views=args.chunk or None, cost_impl=None if args.cost_impl < 0 else args.cost_impl)
     B = args.batch
@@ -426,7 +429,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"adapose_cabinet forward + post-processing, batch={B} poses ({2 * B} views of 224x224) per GPU, "
                                    "synthetic RGB, random-init weights of the reference architecture",
-                       "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}"},
+                       "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
+                       **({"debug_flags": args.debug_flags} if args.debug_flags else {})},
             "tree": tree_hash(),
             "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
             "whole_net_frac_of_mfma_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),

@@ -8,6 +8,12 @@
 #include "common.h"
 #include "prof.h"
 
+#ifndef W256_DIST
+#define W256_DIST 422     // LDS-DMA pieces per phase of the 256 x 256 kernel (4 digits, phases 1-4)
+#endif
+#ifndef W256_ABL
+#define W256_ABL 0    // experiment builds of the 256 x 256 kernel: 1 = no MFMA, 2 = no LDS-DMA, 4 = no fragment reads, 8 = no setprio
+#endif
 #ifndef IG_ABL
 #define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too,
                       // 8 = no DMA; ws kernel: 16 = no epilogue, 32 = generic epilogue only, 64 = no output stores, 128 = no residual reads
@@ -595,9 +601,12 @@ __device__ __forceinline__ void decode_row(const ConvDesc& d, unsigned m, unsign
   q = fdiv(t, d.fd_m[2], d.fd_s[2]); qd = t - q * (unsigned)d.Dq; n = q;
 }
 
-template <typename T>
+// WIDE: the tile is 256 channels x 128 pixels instead of 128 x 256 (same LDS, same MFMA count, same 12 pieces per request wave):
+// for Cout % 256 == 0 it halves the gathered-pixel bytes that cross L2 -> LDS at the price of twice the weight bytes, and the
+// weight slice of a K tile is the same 32 KB for every workgroup of the chip while the pixel rows are a stream from HBM
+template <typename T, bool WIDE>
 __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
-  constexpr int BCH = 128, BPIX = 256;
+  constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
   constexpr int E = 16 / sizeof(T);
   constexpr int BK = 8 * E;
   constexpr int XR = BPIX / 32;              // 8 gathered rows per request thread
@@ -731,8 +740,8 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   if (WS_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if (WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #endif
-  const int wch = (wave >> 2) * 64;
-  const int wpix = (wave & 3) * 64;
+  const int wch = WIDE ? (wave >> 1) * 64 : (wave >> 2) * 64;
+  const int wpix = WIDE ? (wave & 1) * 64 : (wave & 3) * 64;
   const int lr = lane & 15, lg = lane >> 4;
   // Fragment reads run half a K tile ahead of the MFMAs that consume them (two register sets): after the barrier of
   // step g the first-half fragments are requested, the second half of the previous step is multiplied out of registers
@@ -977,9 +986,9 @@ static void make_fastdiv(int dvs, unsigned& m, int& sh) {
   m = (unsigned)(((1ull << sh) + (unsigned long long)dvs - 1ull) / (unsigned long long)dvs);
 }
 
-template <typename T>
+template <typename T, bool WIDE>
 static int launch_ws(ConvDesc d, hipStream_t s) {
-  constexpr int BCH = 128, BPIX = 256;
+  constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
   constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4) + 2048 * sizeof(float);      // K-tile ring + per-channel bias table
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
@@ -990,7 +999,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   static int n_cu = 0;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T>), (int)LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE>), (int)LDS)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));
@@ -999,39 +1008,48 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_ws_kernel<T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
+  prof_begin_launch(s, WIDE && sizeof(T) == 2 ? 31 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE>), dim3((unsigned)grid), dim3(768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves of 128 channels x 64 pixels (layers whose output channels are a multiple of 256: layer3, layer4,
-// up_1 — 96 % of the implicit GEMM's flops).  Why: the role-specialised kernel above pays one 12-wave barrier, one LDS fill of
-// 48 KB and 16 fragment reads per wave for every 32 MFMAs per wave; its counters show the multiply waves 38 % of their cycles
-// in s_waitcnt / s_barrier and 37 % stalled at issue, with the matrix pipe 45 % busy.  Here a K tile carries 64 MFMAs per wave
-// for 24 fragment reads and one 8-wave barrier, and the operand bytes that cross L2 -> LDS per flop drop by a third
-// ((256+256)/(256*256) against (128+256)/(128*256)).  128 accumulator registers per lane leave no room for a separate request
-// role at three waves per SIMD, so every wave issues its own eighth of the tile's LDS-DMA (8 pieces per K tile, wave-uniform tap
-// walk) right behind the barrier; two 64 KB stages; the K-tile sequence runs on across tile boundaries (persistent workgroups),
-// so the first K tile of the next tile lands under the epilogue of the current one.
-// vmcnt: loads and stores of a wave retire out of order with respect to each other on gfx9, so a counted wait cannot be used once
-// epilogue stores are in flight; every wait here is vmcnt(0) — at the one point per K tile where nothing but the tile that is
-// about to be multiplied is outstanding.
+// 256 x 256 tile, 8 waves of 128 channels x 64 pixels, two wave groups in ping-pong (layers whose output channels are a multiple
+// of 256: layer3, layer4, up_1 — 96 % of the implicit GEMM's flops).
+// Why: the role-specialised kernel above spends one 12-wave barrier, one 48 KB LDS fill and 16 fragment reads per wave for every
+// 32 MFMAs per wave; its counters show the multiply waves 38 % of their cycles in s_waitcnt / s_barrier and the matrix pipe 45 %
+// busy.  Here a K tile (64 channels of one tap) carries 64 MFMAs per wave for 24 fragment reads, the bytes that cross L2 -> LDS
+// per flop drop by a third, and the schedule is the two-group alternation the CDNA4 guide measures fastest for this tile:
+//   * a K tile is four phases, one accumulator quadrant (4 x 2 fragments x K=64 = 16 MFMAs) each, in the order Q00 Q01 Q11 Q10 so
+//     that every phase needs at most one new operand half (phase 1: W half 0 + X half 0, 2: X half 1, 3: W half 1, 4: none);
+//   * a phase is [fragment reads + one half-tile of LDS-DMA] s_barrier [16 MFMAs] s_barrier; waves 4-7 run one barrier behind
+//     waves 0-3, so on every SIMD (it hosts one wave of each group) one wave multiplies while the other reads and requests;
+//   * the operand stream is one half-tile (16 KB = 2 pieces per wave) per phase, in the order W0 X0 X1 W1 per K tile, and a
+//     half-tile slot is refilled three phases after the phase that read it: W0/X0 of K tile g+2 during phases 3/4 of g, X1/W1 of
+//     g+1 during phases 1/2 of g — two 64 KB stages, every request 5-6 phases ahead of its first use;
+//   * one counted wait per K tile: in phase 4, before the phase's first barrier, vmcnt(4) leaves only W0/X0 of g+2 in flight, so
+//     all of K tile g+1 has landed; its first read is in the next phase, behind a barrier every wave passed after its own wait
+//     (both groups: the later group's wait precedes the barrier that releases the earlier group into that phase).
+// vmcnt also counts the epilogue's stores, which retire out of order with respect to loads, so the K tile that follows an
+// epilogue (and the last two of the stream) waits with vmcnt(0) instead; once per tile.
+// Every wave issues its own eighth of each half-tile with the wave-uniform tap walk of the kernel above; the K-tile stream runs
+// on across tile boundaries (persistent workgroups, XCD-aware tile order).
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc d) {
   constexpr int BCH = 256, BPIX = 256;
   constexpr int E = 8, BK = 64;
-  constexpr int FM = 8, FN = 4;
-  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (64 KB)
+  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (64 KB): W half 0 | W half 1 | X half 0 | X half 1, 128 rows each
   extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
   static_assert(sizeof(T) == 2, "16-bit storage types only");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+  const int grp = wave >> 2;                 // channel half of the tile, and the ping-pong group
+  const int wc = wave & 3;                   // pixel quarter
   const int KT = d.KT;
   const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = n_my * KT;
@@ -1047,73 +1065,111 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc 
   if (bias_lds)
     for (int i = tid; i < d.Cout; i += 512) lbias[i] = d.bias[i];
   __syncthreads();
+  if (total == 0) return;
 
-  // ---- request side: this wave's pieces of a K tile.  Piece p = rows 8p .. 8p+7 (1 KB); wave w owns pieces w, w+8, w+16, w+24 of
-  // the X tile and of the W tile.  Lane (r8, j) fills slot (row, j) with source chunk j ^ swizzle(row).
+  // ---- request side.  Half-tile h of an operand = LDS rows h*128 .. h*128+127 of its region; this wave fills rows q = i*64 + 8*wave
+  // + r8 (i = 0, 1) of each half.  W row (h, q) holds tile channel (q>>6)*128 + h*64 + (q&63); X row (h, q) holds tile pixel
+  // (q>>5)*64 + h*32 + (q&31) — each wave's fragments of one half are 64 (W) / 32 (X) consecutive LDS rows.  Lane (r8, j) of a
+  // piece fills slot (row, j) with source chunk j ^ swizzle(LDS row).
   const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
   const int j = lane & 7, r8 = lane >> 3;
-  const char* rowp[4];
-  unsigned rmask[4];
-  const char* wrow[4];
+  const char* rowp[2][2];
+  unsigned rmask[2][2];
+  const char* wrow[2][2];
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
-  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // wave-uniform tap walker
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3));
+  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // wave-uniform tap walker of the request stream
+  int ikt = 0, itile = 0, ist = 0;           // K tile within the tile, tile, stream step of the next request
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3)) + (unsigned)wave * 1024u;
   auto enter_tile = [&](int k) {
     int pix_tile, ch_tile;
     tile_of(k, pix_tile, ch_tile);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave + 8 * i) * 8 + r8;
-      const long long m = (long long)pix_tile * BPIX + row;
-      int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
-      if (m < d.M) {
-        unsigned n, qd, qh, qw;
-        decode_row(d, (unsigned)m, n, qd, qh, qw);
-        xn = (int)n * d.Di;
-        xd0 = (int)qd * d.sd - d.pd;
-        xh0 = (int)qh * d.sh - d.ph;
-        xw0 = (int)qw * d.sw - d.pw;
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = i * 64 + 8 * wave + r8;
+        const int lrow = h * 128 + q;
+        const long long m = (long long)pix_tile * BPIX + ((q >> 5) * 64 + h * 32 + (q & 31));
+        int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
+        if (m < d.M) {
+          unsigned n, qd, qh, qw;
+          decode_row(d, (unsigned)m, n, qd, qh, qw);
+          xn = (int)n * d.Di;
+          xd0 = (int)qd * d.sd - d.pd;
+          xh0 = (int)qh * d.sh - d.ph;
+          xw0 = (int)qw * d.sw - d.pw;
+        }
+        unsigned mk = 0;
+        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
+        rmask[h][i] = mk;
+        const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
+        rowp[h][i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((lrow >> 1) & 7)) * E) * 2ll;
+        const int ch = (q >> 6) * 128 + h * 64 + (q & 63);
+        wrow[h][i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + ch) * d.Kpad + (j ^ swz_w(lrow)) * E);
       }
-      unsigned mk = 0;
-      for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
-      for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
-      for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
-      rmask[i] = mk;
-      const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
-      rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((row >> 1) & 7)) * E) * 2ll;
-      wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
-    }
     tkd = tkh = tkw = tc = 0;
   };
-  int ikt = 0, itile = 0;
-  auto issue = [&](int stage) {
-    if (ikt == 0) enter_tile(itile);
-    const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
-    const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
-    const long long soff = ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * 2ll;
-    const bool cok = tkd < d.KD && tc + (j ^ 0) * 0 < d.Cin;      // K tiles never straddle Cin here (Cin % 64 == 0 or 1x1 padded)
-    const long long wk = (long long)ikt * BK * 2ll;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = cok && (rmask[i] & sel) == sel;
-      glds16(ok ? rowp[i] + soff : zero, sbase + (BCH * 8 + (wave + 8 * i) * 64) * 16);
+  // one 1 KB piece of the stream: which = 0 W half 0 (its first piece enters a new tile when due), 1 X half 0, 2 X half 1, 3 W half 1
+  // (after its second piece the walker advances to the next K tile); i = 0, 1 the wave's two pieces of the half-tile
+  auto issue_piece = [&](auto whichc, auto ic) {
+    constexpr int which = decltype(whichc)::value, i = decltype(ic)::value;
+    if (ist >= total) return;
+    if ((W256_ABL & 2) && ist >= 2) {
+      if (which == 3 && i == 1) { if (++ikt == KT) { ikt = 0; ++itile; } ++ist; }
+      return;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(wrow[i] + wk, sbase + ((wave + 8 * i) * 64) * 16);
-    tc += BK;
-    if (d.lcin >= 0 && tc >= d.Cin) {
-      tc = 0;
-      if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+    if (which == 0 && i == 0 && ikt == 0) enter_tile(itile);
+    const unsigned sbase = lds0 + (unsigned)(ist & 1) * (STAGE * 16);
+    if (W256_ABL & 128) {
+      glds16(zero, sbase + ((which == 0 || which == 3 ? 0 : 256) + (which == 0 || which == 1 ? 0 : 128) + i * 64) * 128);
+    } else if (W256_ABL & 256) {
+      if (lane == 0) glds16(zero, sbase + ((which == 0 || which == 3 ? 0 : 256) + (which == 0 || which == 1 ? 0 : 128) + i * 64) * 128);
+    } else if (which == 0 || which == 3) {
+      constexpr int h = which == 0 ? 0 : 1;
+      const long long wk = (long long)ikt * BK * 2ll;
+      glds16((W256_ABL & 512) ? zero : wrow[h][i] + wk, sbase + (h * 128 + i * 64) * 128);
+    } else if (W256_ABL & 1024) {
+      constexpr int h = which - 1;
+      glds16(zero, sbase + (256 + h * 128 + i * 64) * 128);
+    } else {
+      constexpr int h = which - 1;
+      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
+      const long long soff = ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * 2ll;
+      const bool ok = (rmask[h][i] & sel) == sel;
+      glds16(ok ? rowp[h][i] + soff : zero, sbase + (256 + h * 128 + i * 64) * 128);
     }
-    if (++ikt == KT) { ikt = 0; ++itile; }
+    if (which == 3 && i == 1) {
+      tc += BK;
+      if (tc >= d.Cin) {
+        tc = 0;
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      }
+      if (++ikt == KT) { ikt = 0; ++itile; }
+      ++ist;
+    }
   };
+  // pieces q0 .. q1-1 of the per-K-tile sequence X1a X1b W1a W1b (of K tile g+1) W0a W0b X0a X0b (of K tile g+2)
+  auto issue_seq = [&](auto q0c, auto q1c) {
+    constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+    if (q0 <= 0 && 0 < q1) issue_piece(IC<2>{}, IC<0>{});
+    if (q0 <= 1 && 1 < q1) issue_piece(IC<2>{}, IC<1>{});
+    if (q0 <= 2 && 2 < q1) issue_piece(IC<3>{}, IC<0>{});
+    if (q0 <= 3 && 3 < q1) issue_piece(IC<3>{}, IC<1>{});
+    if (q0 <= 4 && 4 < q1) issue_piece(IC<0>{}, IC<0>{});
+    if (q0 <= 5 && 5 < q1) issue_piece(IC<0>{}, IC<1>{});
+    if (q0 <= 6 && 6 < q1) issue_piece(IC<1>{}, IC<0>{});
+    if (q0 <= 7 && 7 < q1) issue_piece(IC<1>{}, IC<1>{});
+  };
+  auto issue_half = [&](auto whichc) { issue_piece(whichc, IC<0>{}); issue_piece(whichc, IC<1>{}); };
 
   // ---- multiply side ----
-  const int wch = (wave >> 2) * 128;
-  const int wpix = (wave & 3) * 64;
+  const int wch = grp * 128;
+  const int wpix = wc * 64;
   const int lr = lane & 15, lg = lane >> 4;
-  f32x4 acc[FM][FN];
+  f32x4 acc[8][4];
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
   auto tile_interior = [&](int pix_tile, int ch_tile) {
@@ -1124,51 +1180,82 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc 
     tile_of(k, pt, ct);
     if (tile_interior(pt, ct) && d.bias) {
 #pragma unroll
-      for (int a = 0; a < FM; ++a) {
-        // fragment a of 64-channel group a >> 2: the lane's channels are group*64 + lg*16 + (a&3)*4 ..
+      for (int a = 0; a < 8; ++a) {
+        // fragment a = (half a >> 2, a & 3): the lane's channels are wch + (a>>2)*64 + lg*16 + (a&3)*4 .. +3
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + ct * BCH + wch + (a >> 2) * 64 + lg * 16 + (a & 3) * 4);
 #pragma unroll
-        for (int b = 0; b < FN; ++b) acc[a][b] = b4;
+        for (int b = 0; b < 4; ++b) acc[a][b] = b4;
       }
     } else {
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+      for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto compute = [&](int stage) {
-    const uint4* W = lds3 + stage * STAGE;
-    const uint4* X = W + BCH * 8;
+  // fragment slots of this lane inside a stage (uint4 units), without the k-step chunk: row * 8, and the row's swizzle
+  int wslot[4], wsw[4], xslot[2], xsw[2];
+#pragma unroll
+  for (int a2 = 0; a2 < 4; ++a2) {
+    const int row = grp * 64 + (lr >> 2) * 16 + a2 * 4 + (lr & 3);        // + half * 128; the ws kernel's row permutation per 64 channels
+    wslot[a2] = row * 8;
+    wsw[a2] = swz_w(row);
+  }
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    const int row = wc * 32 + b2 * 16 + lr;                               // + half * 128
+    xslot[b2] = (256 + row) * 8;
+    xsw[b2] = (row >> 1) & 7;
+  }
+  uint4 af[2][4] = {}, b0f[2][2] = {}, b1f[2][2] = {};      // [k-step][fragment]
+  auto read_w = [&](const uint4* S, int h) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int a2 = 0; a2 < 4; ++a2) {
+        if (W256_ABL & 4) asm volatile("" : "+v"(af[s2][a2].x), "+v"(af[s2][a2].y), "+v"(af[s2][a2].z), "+v"(af[s2][a2].w));
+        else af[s2][a2] = S[h * 1024 + wslot[a2] + ((s2 * 4 + lg) ^ wsw[a2])];
+      }
+  };
+  auto read_x = [&](const uint4* S, int h, uint4 (&bf)[2][2]) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        if (W256_ABL & 4) asm volatile("" : "+v"(bf[s2][b2].x), "+v"(bf[s2][b2].y), "+v"(bf[s2][b2].z), "+v"(bf[s2][b2].w));
+        else bf[s2][b2] = S[h * 1024 + xslot[b2] + ((s2 * 4 + lg) ^ xsw[b2])];
+      }
+  };
+  auto quadrant = [&](int mh, int nh, const uint4 (&bf)[2][2], auto mid) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(W256_ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const int cidx = s2 * 4 + lg;
-      uint4 af[FM], bf[FN];
 #pragma unroll
-      for (int b = 0; b < FN; ++b) {
-        const int row = wpix + b * 16 + lr;
-        bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
+      for (int a2 = 0; a2 < 4; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          if (W256_ABL & 1) asm volatile("" : "+v"(acc[mh * 4 + a2][nh * 2 + b2]) : "v"(af[s2][a2].x), "v"(af[s2][a2].w), "v"(bf[s2][b2].x), "v"(bf[s2][b2].w));
+          else MmaG<T>::run(af[s2][a2], bf[s2][b2], acc[mh * 4 + a2][nh * 2 + b2]);
+        }
+      if (s2 == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int a = 0; a < FM; ++a) {
-        const int row = wch + (a >> 2) * 64 + (lr >> 2) * 16 + (a & 3) * 4 + (lr & 3);     // the ws kernel's row permutation per 64-channel group
-        af[a] = W[row * 8 + (cidx ^ swz_w(row))];
-      }
-#pragma unroll
-      for (int a = 0; a < FM; ++a)
-#pragma unroll
-        for (int b = 0; b < FN; ++b) MmaG<T>::run(af[a], bf[b], acc[a][b]);
     }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto epilogue = [&](int k) {
     int pix_tile, ch_tile;
     tile_of(k, pix_tile, ch_tile);
     const bool interior = tile_interior(pix_tile, ch_tile);
-    long long obase[FN];
-    int nn[FN];
-    bool pok[FN];
+    long long obase[4];
+    int nn[4];
+    bool pok[4];
 #pragma unroll
-    for (int b = 0; b < FN; ++b) {
+    for (int b = 0; b < 4; ++b) {
       const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
       pok[b] = m < d.M;
       unsigned n, qd, qh, qw;
@@ -1178,25 +1265,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc 
     }
     const float slope = d.slope;
 #pragma unroll
-    for (int grp = 0; grp < 2; ++grp) {                  // the wave's two 64-channel groups: 16 consecutive channels per lane each
-      const int chL = ch_tile * BCH + wch + grp * 64 + lg * 16;
+    for (int half = 0; half < 2; ++half) {               // the wave's two 64-channel halves: 16 consecutive channels per lane each
+      const int chL = ch_tile * BCH + wch + half * 64 + lg * 16;
       if (interior) {
         auto fast = [&](auto actc, auto resc) {
           constexpr int ACT = decltype(actc)::value, RES = decltype(resc)::value;
-          uint4 rr[2][FN];
+          uint4 rr[2][4];
           if (RES != RES_NONE) {
 #pragma unroll
-            for (int b = 0; b < FN; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
               for (int q = 0; q < 2; ++q) rr[q][b] = *reinterpret_cast<const uint4*>(res + obase[b] + chL + q * 8);
           }
 #pragma unroll
-          for (int b = 0; b < FN; ++b)
+          for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               float v[8], rv[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = acc[grp * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3];
+              for (int e = 0; e < 8; ++e) v[e] = acc[half * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3];
               if (RES != RES_NONE) unpack_chunk(rr[q][b], rv, T());
               if (RES == RES_PRE_ACT) {
 #pragma unroll
@@ -1224,24 +1311,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc 
       }
       // ragged tiles (last pixel tile), per-sample bias, tanh: per-chunk checks
 #pragma unroll
-      for (int b = 0; b < FN; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int c = chL + q * 8;
           if (!pok[b] || c >= d.Cout) continue;
-          const bool whole = c + 8 <= d.Cout;
           float v[8], rv[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] = acc[grp * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3]; rv[e] = 0.f; }
+          for (int e = 0; e < 8; ++e) { v[e] = acc[half * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3]; rv[e] = 0.f; }
           if (d.bias) {
             const float* bp = d.bias + (long long)nn[b] * d.bias_stride + c;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < 4 || whole) v[e] += bp[e];
+            for (int e = 0; e < 8; ++e) v[e] += bp[e];
           }
-          if (d.res_mode != RES_NONE) {
-            if (whole) unpack_chunk(*reinterpret_cast<const uint4*>(res + obase[b] + c), rv, T());
-            else load4(res + obase[b] + c, rv);
-          }
+          if (d.res_mode != RES_NONE) unpack_chunk(*reinterpret_cast<const uint4*>(res + obase[b] + c), rv, T());
           if (d.res_mode == RES_PRE_ACT) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
@@ -1252,27 +1335,63 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
           }
-          if (whole) *reinterpret_cast<uint4*>(out + obase[b] + c) = pack_chunk(v, T());
-          else store4(out + obase[b] + c, v);
+          *reinterpret_cast<uint4*>(out + obase[b] + c) = pack_chunk(v, T());
         }
     }
   };
 
-  if (total > 0) issue(0);
+  // prologue: all of K tile 0, W0/X0 of K tile 1
+  issue_half(IC<0>{}); issue_half(IC<1>{}); issue_half(IC<2>{}); issue_half(IC<3>{});
+  issue_half(IC<0>{}); issue_half(IC<1>{});
+  if (total > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  seed_acc(0);
+  RGBM_BARRIER();
+  if (grp == 1) RGBM_BARRIER();              // the second group runs one barrier behind the first from here on
   int k = 0, kt = 0;
-  if (n_my > 0) seed_acc(0);
   for (int g = 0; g < total; ++g) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step g (and any epilogue stores) have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its fragment reads of step g-1 have returned
-    RGBM_BARRIER();              // step g is complete in LDS; every wave is done with the other stage
-    if (g + 1 < total) issue((g + 1) & 1);
-    compute(g & 1);
+    const uint4* S = lds3 + (g & 1) * STAGE;
+    // pieces requested per phase: W256_DIST digits (phases 1..4, sum 8).  Pieces 0-3 (X1, W1 of K tile g+1) may go in any phase;
+    // pieces 4-7 refill the W0 / X0 slots of THIS stage, read in phase 1, so they go in phases 3-4.
+    constexpr int D1 = W256_DIST / 1000, D2 = W256_DIST / 100 % 10, D3 = W256_DIST / 10 % 10, D4 = W256_DIST % 10;
+    static_assert(D1 + D2 + D3 + D4 == 8 && D1 + D2 <= 4, "piece schedule");
+    // phase 1: W half 0 x X half 0
+    read_w(S, 0);
+    read_x(S, 0, b0f);
+    issue_seq(IC<0>{}, IC<D1>{});
+    RGBM_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(0, 0, b0f, [&]() {});
+    RGBM_BARRIER();
+    // phase 2: W half 0 x X half 1
+    read_x(S, 1, b1f);
+    issue_seq(IC<D1>{}, IC<D1 + D2>{});
+    RGBM_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(0, 1, b1f, [&]() {});
+    RGBM_BARRIER();
+    // phase 3: W half 1 x X half 1
+    read_w(S, 1);
+    issue_seq(IC<D1 + D2>{}, IC<D1 + D2 + D3>{});
+    RGBM_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    quadrant(1, 1, b1f, [&]() {});
+    RGBM_BARRIER();
+    // phase 4: W half 1 x X half 0 (both in registers)
+    issue_seq(IC<D1 + D2 + D3>{}, IC<8>{});
+    if (W256_ABL & 32) {}
+    else if (kt == 0 || g + 2 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores of the last epilogue are counted too
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               // all of K tile g+1 has landed
+    RGBM_BARRIER();
+    quadrant(1, 0, b0f, [&]() {});
+    RGBM_BARRIER();
     if (++kt == KT) {
       epilogue(k);
       kt = 0;
       if (++k < n_my) seed_acc(k);
     }
   }
+  if (grp == 0) RGBM_BARRIER();              // pairs with the second group's last barrier
 }
 
 template <typename T>
@@ -1846,7 +1965,10 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
       if (uni && (al & 15ull) == 0ull && d.Cout % 256 == 0 && d.Cin % 64 == 0 && d.KT >= 2 && (g_debug_flags & 8192) && !(g_debug_flags & 64))
         return launch_w256<T>(d, s);
     }
-    if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) return launch_ws<T>(d, s);
+    if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) {
+      if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) return launch_ws<T, true>(d, s);
+      return launch_ws<T, false>(d, s);
+    }
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
   // 33..64 output channels, bf16, no residual, >= 2 K tiles, 16-byte aligned output rows: three-role persistent kernel

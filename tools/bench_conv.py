@@ -18,12 +18,17 @@ r = torch.randn(N, H, W, Cout, generator=g).bfloat16().cuda() if res else None
 fp = lambda t: t.numpy().ctypes.data_as(C.c_void_p)
 pad = dil * (k // 2)
 flops = 2.0 * N * H * W * Cout * Cin * k * k
+first = None
 for f in flags:
     lib.rgbm_debug_flags(f)
     def run():
         _lib.check(lib.rgbm_conv_nd(_lib.BF16, _lib.ptr(x), N, 1, H, W, Cin, Cin, fp(w), Cout, Cout, 1, k, k, 1, 1, 0, pad, dil, 0,
                                     fp(bias), None, None, _lib.ptr(r), 1 if res else 0, 1, 0.0, _lib.ptr(out), _lib.stream_ptr()), "conv_nd")
-    run(); torch.cuda.synchronize()
+    out.zero_(); run(); torch.cuda.synchronize()
+    if first is None:
+        first = out.float().clone()
+    else:
+        print(f"flags {f}: max |out - out(flags {flags[0]})| = {float((out.float() - first).abs().max()):.3e}  (max |out| {float(first.abs().max()):.2f})")
     lib.rgbm_prof_start()
     for _ in range(3): run()
     torch.cuda.synchronize()
