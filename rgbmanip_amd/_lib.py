@@ -18,7 +18,7 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
 
 # rows of rgbm_prof_stop (include/rgbm.h): (kernel name as rocprofv3 prints it, arithmetic dtype)
-PROF_ROWS = 32
+PROF_ROWS = 36
 PROF_KERNELS = [
     ("conv_igemm_glds_kernel<float, 16, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 32, 256>", "fp32"),
     ("conv_igemm_glds_kernel<float, 64, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 128, 128>", "fp32"),
@@ -27,7 +27,7 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<float, ...> (conv1..conv11)", "fp32"), ("conv3d_tile_kernel<unsigned short, ...> (conv1..conv11)", "bf16"),
     ("conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "fp32"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "bf16"),
-    ("conv_igemm_ws_kernel<float, ...>", "fp32"), ("conv_igemm_ws_kernel<unsigned short, false> (128 channels x 256 pixels)", "bf16"),    # + conv_igemm_v3_kernel for non-uniform taps
+    ("conv_igemm_ws_kernel<float, ...>", "fp32"), ("conv_igemm_ws_kernel<unsigned short, false, false> (128 channels x 256 pixels)", "bf16"),    # + conv_igemm_v3_kernel for non-uniform taps
     ("conv0_sweep_kernel (conv0 + fused plane sweep)", "bf16"), ("conv_igemm_ws64_kernel", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 6, 8, 8, 1, false, false> (conv0 on a materialised volume)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 8, 16, 2, 8, 8, 2, false, false> (conv1)", "bf16"),
@@ -42,7 +42,10 @@ PROF_KERNELS = [
 ] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
      ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<bx3_t>", "bf16x3"),
      ("conv_igemm_w256_kernel<unsigned short> (experimental, debug flag 8192)", "bf16"),
-     ("conv_igemm_ws_kernel<unsigned short, true> (256 channels x 128 pixels)", "bf16")]
+     ("conv_igemm_ws_kernel<unsigned short, true, false> (256 channels x 128 pixels)", "bf16"),
+     ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
+     ("unused", "bf16"), ("unused", "bf16"), ("unused", "bf16")]
+assert len(PROF_KERNELS) == PROF_ROWS
 
 
 class RgbmError(RuntimeError):

@@ -604,9 +604,22 @@ __device__ __forceinline__ void decode_row(const ConvDesc& d, unsigned m, unsign
 // WIDE: the tile is 256 channels x 128 pixels instead of 128 x 256 (same LDS, same MFMA count, same 12 pieces per request wave):
 // for Cout % 256 == 0 it halves the gathered-pixel bytes that cross L2 -> LDS at the price of twice the weight bytes, and the
 // weight slice of a K tile is the same 32 KB for every workgroup of the chip while the pixel rows are a stream from HBM
-template <typename T, bool WIDE>
+//
+// RH (row halo; with WIDE, 16-bit types; 2-D 3x3, stride 1, pad = dilation <= 4, Cin a multiple of 64): the gathered pixel rows are
+// what this kernel pays for — they stream from HBM / MALL through L2 while the weight slice of a K tile is the same for every
+// workgroup of the chip (X from the zero page: -29 % time; W from the zero page: -8 %, for equal bytes) — and the three kw taps
+// of one kernel row read the same pixels shifted by 0, dil, 2*dil GEMM rows.  So the K order becomes (kh, channel block, kw),
+// ONE X slot of 128 + 2*dil rows serves the three steps of a (kh, channel block) group (the multiply waves read their B fragments
+// at row offset kw*dil; lanes whose neighbour falls off the image row read a zero row), and only the weights are staged per step:
+// 17 X pieces per three steps instead of 48.  Two rings: 3 W slots of 32 KB, 3 X slots of 17 KB (a group's pixels are requested
+// over the three steps two groups ahead).
+template <typename T, bool WIDE, bool RH>
 __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
+  static_assert(!RH || (WIDE && sizeof(T) == 2), "row-halo variant: 256 x 128 tile, 16-bit storage");
   constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
+  constexpr int XROWS = 136;                 // RH: rows of an X slot (BPIX + 2 * 4, whole 8-row pieces)
+  constexpr int WSLOT = BCH * 8, XSLOT = XROWS * 8;              // RH: uint4 slots of a W / X ring slot
+  constexpr int XBASE = 3 * WSLOT, ZROW = XBASE + 3 * XSLOT;     // RH: X ring, then one row of zeros
   constexpr int E = 16 / sizeof(T);
   constexpr int BK = 8 * E;
   constexpr int XR = BPIX / 32;              // 8 gathered rows per request thread
@@ -639,11 +652,115 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   // Per-channel bias table in LDS behind the ring (launch_ws reserves it): the multiply waves must not wait on vmcnt for
   // anything they do not need — on gfx9 the counter also covers their own output stores, in order, so a global bias read
   // after a tile's stores costs a full store round trip (measured: 5 us per tile).
-  float* lbias = reinterpret_cast<float*>(lds3 + 3 * STAGE);
+  float* lbias = reinterpret_cast<float*>(lds3 + (RH ? ZROW + 8 : 3 * STAGE));
   const bool bias_lds = d.bias != nullptr && d.bias_stride == 0 && d.Cout <= 2048;
   if (bias_lds)
     for (int i = tid; i < d.Cout; i += 768) lbias[i] = d.bias[i];
+  if (RH && tid < 8) lds3[ZROW + tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
+
+  if constexpr (RH) {
+    if (wave >= 8) {
+      // ---------------------------------------------------------------- request waves, row-halo variant
+      // W stream: step g+2 (8 pieces per wave and step) behind barrier g; X stream: group g/3 + 2, its 17 pieces dealt
+      // round-robin to the four waves (5 / 4 / 4 / 4) and requested over the group's three steps as 2, 2, 1|0 pieces per wave.
+      const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
+      const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
+      const int pw = wave - 8;
+      const int j = lane & 7, r8 = lane >> 3;
+      const int dil = d.dilw;
+      const int NCC = d.Cin >> 6;
+      const int ngroups = total / 3;
+      const char* wrowp[8];
+      const char* xrowp[5];
+      unsigned xmask[5];
+      const char* zero = reinterpret_cast<const char*>(g_zero_page);
+      const unsigned ldsb = __builtin_amdgcn_readfirstlane(lds_addr(lds3));
+      auto enter_tile_w = [&](int k) {
+        int pix_tile, ch_tile;
+        tile_of(k, pix_tile, ch_tile);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (pw + 4 * i) * 8 + r8;
+          wrowp[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
+        }
+      };
+      auto enter_tile_x = [&](int k) {
+        int pix_tile, ch_tile;
+        tile_of(k, pix_tile, ch_tile);
+        const long long p0 = (long long)pix_tile * BPIX;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int xr = (pw + 4 * i) * 8 + r8;            // LDS row xr holds GEMM row m = p0 - dil + xr (of kernel row kh)
+          const long long m = p0 - dil + xr;
+          unsigned mk = 0;
+          long long pix0 = 0;
+          if (pw + 4 * i < XROWS / 8 && xr < BPIX + 2 * dil && m >= 0 && m < d.M) {
+            unsigned n, qd, qh, qw;
+            decode_row(d, (unsigned)m, n, qd, qh, qw);
+            for (int kh = 0; kh < 3; ++kh) mk |= (unsigned)((unsigned)((int)qh + (kh - 1) * dil) < (unsigned)d.Hi) << kh;
+            pix0 = ((long long)n * d.Hi + ((int)qh - dil)) * d.Wi + (int)qw;      // input pixel of kernel row 0
+          }
+          xmask[i] = mk;
+          xrowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((xr >> 1) & 7)) * E) * 2ll;
+        }
+      };
+      // W stream state: (kh, cc, kw) of the next step to request, its tile and global step; X stream: (kh, cc) of the group
+      int wkh = 0, wcc = 0, wkw = 0, wtile = 0, wg = 0;
+      int xkh = 0, xcc = 0, xtile = 0, xg = 0;
+      auto issue_w = [&]() {
+        if (wg >= total) return 0;
+        if (wkh == 0 && wcc == 0 && wkw == 0) enter_tile_w(wtile);
+        const unsigned sbase = ldsb + (unsigned)(wg % 3) * (WSLOT * 16);
+        const long long woff = ((long long)(wkh * 3 + wkw) * d.Cin + wcc * 64) * 2ll;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(wrowp[i] + woff, sbase + ((pw + 4 * i) * 64) * 16);
+        if (++wkw == 3) { wkw = 0; if (++wcc == NCC) { wcc = 0; if (++wkh == 3) { wkh = 0; ++wtile; } } }
+        ++wg;
+        return 8;
+      };
+      // pieces [i0, i1) of this wave's share of X group xg; part 2 closes the group
+      auto issue_x = [&](auto i0c, auto i1c, bool last) {
+        constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
+        if (xg >= ngroups) return 0;
+        if (i0 == 0 && xkh == 0 && xcc == 0) enter_tile_x(xtile);
+        const unsigned sbase = ldsb + (unsigned)(XBASE + (xg % 3) * XSLOT) * 16;
+        const long long xoff = ((long long)xkh * dil * d.Wi * d.Cin + xcc * 64) * 2ll;
+        int n = 0;
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+          if (pw + 4 * i < XROWS / 8) {                    // wave-uniform (piece 16 exists for the first wave only)
+            const char* src = ((xmask[i] >> xkh) & 1u) ? xrowp[i] + xoff : zero;
+            glds16(src, sbase + ((pw + 4 * i) * 64) * 16);
+            ++n;
+          }
+        }
+        if (last) { if (++xcc == NCC) { xcc = 0; if (++xkh == 3) { xkh = 0; ++xtile; } } ++xg; }
+        return n;
+      };
+      auto issue_x_all = [&]() { issue_x(IC<0>{}, IC<2>{}, false); issue_x(IC<2>{}, IC<4>{}, false); issue_x(IC<4>{}, IC<5>{}, true); };
+      issue_x_all();                          // group 0
+      issue_x_all();                          // group 1
+      issue_w();                              // step 0
+      int after = issue_w();                  // step 1: what is allowed to be in flight behind step 0's operands
+      for (int g = 0; g < total; ++g) {
+        // everything requested before the last request of step g's weights has landed when at most `after` pieces are in flight
+        if (after >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (after == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (after == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RGBM_BARRIER();            // step g's operands are in LDS; the W slot of step g-1 and (every third step) the X slot of group g/3 - 1 are free
+        const int ph = g % 3;
+        int nx = 0;
+        if (ph == 0) nx = issue_x(IC<0>{}, IC<2>{}, false);
+        else if (ph == 1) nx = issue_x(IC<2>{}, IC<4>{}, false);
+        else nx = issue_x(IC<4>{}, IC<5>{}, true);
+        const int nw = issue_w();             // step g+2
+        after = nw == 0 ? 0 : nx + nw;        // nothing behind the last weights: drain
+      }
+      return;
+    }
+  }
 
   if (wave >= 8) {
     // ------------------------------------------------------------------ request waves
@@ -763,6 +880,26 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
       bf[b] = X[row * 8 + (cidx ^ ((row >> 1) & 7))];
     }
   };
+  // RH: W slot ws, X slot xs read at row offset kw * dil; edge lanes (bit b of eLm / eRm) read the zero row
+  unsigned eLm = 0, eRm = 0;
+  const int rh_dil = RH ? d.dilw : 0;
+  auto load_half_rh = [&](int ws, int xs, int kw, int s, uint4 (&af)[FM], uint4 (&bf)[FN]) {
+    const uint4* W = lds3 + ws * WSLOT;
+    const uint4* X = lds3 + XBASE + xs * XSLOT;
+    const int cidx = s * 4 + lg;
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+      const int row = wch + (lr >> 2) * 16 + a * 4 + (lr & 3);
+      af[a] = W[row * 8 + (cidx ^ swz_w(row))];
+    }
+    const unsigned em = kw == 0 ? eLm : (kw == 2 ? eRm : 0u);
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const int row = wpix + b * 16 + lr + kw * rh_dil;
+      const uint4* src = ((em >> b) & 1u) ? lds3 + ZROW + cidx : X + row * 8 + (cidx ^ ((row >> 1) & 7));
+      bf[b] = *src;
+    }
+  };
   auto mma_half = [&](const uint4 (&af)[FM], const uint4 (&bf)[FN]) {
 #pragma unroll
     for (int a = 0; a < FM; ++a)
@@ -772,6 +909,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
   int st = 0;
+  int xs = 0, kw = 0;                        // RH: X slot and kernel column of the current step
   auto tile_interior = [&](int pix_tile, int ch_tile) {
     return (d.bias == nullptr || bias_lds) && (long long)(pix_tile + 1) * BPIX <= d.M && (ch_tile + 1) * BCH <= d.Cout &&
            d.act != ACT_TANH && !(IG_ABL & 32);
@@ -797,7 +935,36 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
           for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if constexpr (std::is_same<T, bx3_t>::value) {
+    if constexpr (RH) {
+      {
+        int pt, ct;
+        tile_of(k, pt, ct);
+        eLm = eRm = 0;
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+          const long long m = (long long)pt * BPIX + wpix + b * 16 + lr;
+          unsigned n, qd, qh, qw;
+          decode_row(d, m < d.M ? (unsigned)m : 0u, n, qd, qh, qw);
+          eLm |= (unsigned)((int)qw - rh_dil < 0) << b;
+          eRm |= (unsigned)((int)qw + rh_dil >= d.Wi) << b;
+        }
+      }
+      for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RGBM_BARRIER();
+        load_half_rh(st, xs, kw, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt > 0) mma_half(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_half_rh(st, xs, kw, 1, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st == 2 ? 0 : st + 1;
+        if (++kw == 3) { kw = 0; xs = xs == 2 ? 0 : xs + 1; }
+      }
+      mma_half(af1, bf1);
+    } else if constexpr (std::is_same<T, bx3_t>::value) {
       // split pairs: the two half-tile chunks of a lane (channels 4*lg.. and 16 + 4*lg..) together are the 8 k values of
       // one 16x16x32 operand — hi parts and lo parts separately — so a K tile (32 channels) is 16 x 3 full-rate MFMAs
       // (lo*hi, hi*lo, hi*hi; 16 independent accumulators between two uses of the same one)
@@ -986,10 +1153,10 @@ static void make_fastdiv(int dvs, unsigned& m, int& sh) {
   m = (unsigned)(((1ull << sh) + (unsigned long long)dvs - 1ull) / (unsigned long long)dvs);
 }
 
-template <typename T, bool WIDE>
+template <typename T, bool WIDE, bool RH>
 static int launch_ws(ConvDesc d, hipStream_t s) {
   constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
-  constexpr size_t LDS = 3 * (BCH + BPIX) * 8 * sizeof(uint4) + 2048 * sizeof(float);      // K-tile ring + per-channel bias table
+  constexpr size_t LDS = (RH ? (3 * (size_t)(BCH + 136) * 8 + 8) : 3 * (size_t)(BCH + BPIX) * 8) * sizeof(uint4) + 2048 * sizeof(float);      // K-tile ring(s) + per-channel bias table
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
   const long long ntiles = (long long)d.n_pix_tiles * d.n_ch_tiles;
@@ -999,7 +1166,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   static int n_cu = 0;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE>), (int)LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH>), (int)LDS)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));
@@ -1008,8 +1175,8 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, WIDE && sizeof(T) == 2 ? 31 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE>), dim3((unsigned)grid), dim3(768), LDS, s, d);
+  prof_begin_launch(s, RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE, RH>), dim3((unsigned)grid), dim3(768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1966,8 +2133,15 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
         return launch_w256<T>(d, s);
     }
     if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) {
-      if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) return launch_ws<T, true>(d, s);
-      return launch_ws<T, false>(d, s);
+      if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) {
+        if constexpr (sizeof(T) == 2) {
+          // row-halo variant: measured 18 % SLOWER than the plain wide tile on a box where the kernel is issue-bound (the shifted B
+          // rows cost ~70 VALU per step in the multiply waves); kept behind a switch for boxes where the L2 -> LDS path is the limit
+          if ((g_debug_flags & 131072) && conv_rowhalo_ok(d) && d.Kpad == 9 * d.Cin && d.KT == 9 * (d.Cin >> 6)) return launch_ws<T, true, true>(d, s);
+        }
+        return launch_ws<T, true, false>(d, s);
+      }
+      return launch_ws<T, false, false>(d, s);
     }
     return uni ? launch_v3<T, true>(d, s) : launch_v3<T, false>(d, s);
   }
