@@ -68,6 +68,11 @@ CONV2D_CASES = [
     ("ws64_rowhalo_res_pre", 3, 64, 150, 151, 64, 3, 1, 1, 1, False, 1, 1),
     ("ws64_1x1_res_post_prelu", 5, 128, 120, 121, 64, 1, 1, 0, 1, True, 2, 2),
     ("ws64_cout48_res_pre", 3, 128, 149, 150, 48, 3, 1, 1, 1, True, 1, 1),
+    # Cout a multiple of 256: the 256-channel x 128-pixel tile of conv_igemm_ws_kernel (ragged last pixel tile; straight-line and
+    # generic epilogues)
+    ("wide_res_pre_512", 2, 64, 182, 181, 512, 3, 1, 1, 1, False, 1, 1),
+    ("wide_1x1_res_post_prelu", 2, 128, 182, 181, 256, 1, 1, 0, 1, True, 2, 2),
+    ("wide_dil4_tanh_bias", 2, 64, 182, 181, 256, 3, 1, 4, 4, True, 3, 0),
 ]
 
 
@@ -95,6 +100,32 @@ def test_conv2d(case, dtype):
     assert y.shape == ref.shape
     assert torch.isfinite(y).all()
     assert rel_err(y, ref) < TOL[dtype], name
+
+
+@pytest.mark.parametrize("flags", [131072, 8192, 65536], ids=["wide_rowhalo", "w256_pingpong", "narrow_tile"])
+@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16], ids=["bf16", "fp16"])
+def test_conv2d_switchable_igemm_variants(flags, dtype):
+    """The implicit-GEMM variants behind rgbm_debug_flags (the row-halo wide tile and the 256 x 256 two-group kernel are opt-in
+    experiments, the 128 x 256 tile is the fallback of the wide one) stay correct: same case, same tolerance as the default."""
+    from gpu_util import conv_nd, rel_err
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    N, Cin, H, W, Cout, dil = 2, 128, 182, 181, 256, 2
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, 1, dil, dil)
+    res = _q(torch.randn(ref.shape, generator=g), dtype)
+    ref = F.relu(ref + res)
+    try:
+        lib.rgbm_debug_flags(flags)
+        y = conv_nd(dtype, x, w, stride=1, pad=dil, dil=dil, bias=b, res=res, res_mode=1, act=1)
+    finally:
+        lib.rgbm_debug_flags(0)
+    y0 = conv_nd(dtype, x, w, stride=1, pad=dil, dil=dil, bias=b, res=res, res_mode=1, act=1)
+    assert rel_err(y, ref) < TOL[dtype] and rel_err(y0, ref) < TOL[dtype]
+    if flags != 131072:      # same K order as the default kernel: identical sums
+        assert torch.equal(y, y0)
 
 
 @pytest.mark.parametrize("name", ["l2_3x3_s2", "up_prelu", "ws128_res_pre", "ws128_1x1_s1", "ws64_prelu_bias", "ws64_rowhalo_dil2",
