@@ -362,3 +362,54 @@ def align_case(case: int, P: int = 1024):
     if case % 5 == 4:
         pts[:, 0] = -pts[:, 0]
     return nocs, pts
+
+
+# --------------------------------------------------------------------------- a deterministic vec env for PPO.run
+class StubVecEnv:
+    """A closed-form stand-in for `MultiVecEnv` with the interface `PPO.run` uses (`reset`, `step`, `get_state`, `num_envs`, the three
+    spaces): smooth dynamics in float32 on the CPU, per-env episode lengths, a reward, and an info dict with reward terms and the
+    specially handled "success_rate" key.  The SAME class drives the reference's `PPO.run` when the golden file is generated
+    (tools/make_goldens.py::gen_ppo_run) and the product's in tests/test_gpu_ppo.py, so both see identical environment arithmetic;
+    every action it receives is recorded in `action_log`."""
+
+    def __init__(self, num_envs, box, seed=0):
+        import torch
+        g = np.random.default_rng(4242 + seed)
+        self.num_envs = num_envs
+        self.observation_space, self.state_space, self.action_space = box(-1.5, 1.5, (60,)), box(-1.5, 1.5, (75,)), box(-1.5, 1.5, (12,))
+        self.Wa = torch.from_numpy((g.normal(size=(12, 75)) * 0.3).astype(np.float32))
+        self.Ws = torch.from_numpy((g.normal(size=(75, 75)) * (0.5 / np.sqrt(75.0))).astype(np.float32))
+        self.Po = torch.from_numpy((g.normal(size=(75, 60)) * (1.0 / np.sqrt(75.0))).astype(np.float32))
+        self.s0 = torch.from_numpy(g.uniform(-0.5, 0.5, size=(num_envs, 75)).astype(np.float32))
+        self.ep_len = torch.tensor([5 + (e % 7) for e in range(num_envs)], dtype=torch.int64)
+        self.s = self.s0.clone()
+        self.cnt = torch.zeros(num_envs, dtype=torch.int64)
+        self.action_log = []
+
+    def _obs(self):
+        import torch
+        return torch.tanh(self.s @ self.Po)
+
+    def reset(self):
+        self.s = self.s0.clone()
+        self.cnt.zero_()
+        return self._obs()
+
+    def get_state(self):
+        return self.s.clone()
+
+    def step(self, actions):
+        import torch
+        a = actions.detach().to("cpu", torch.float32)
+        self.action_log.append(a.clone())
+        a = a.clamp(-1.5, 1.5)
+        self.s = 0.85 * self.s + 0.15 * torch.tanh(a @ self.Wa + self.s @ self.Ws)
+        self.cnt += 1
+        dist = (self.s[:, :3] ** 2).sum(1)
+        rew = 1.0 - dist + 0.05 * a.mean(1)
+        done = self.cnt >= self.ep_len
+        infos = {"REW:dist": dist.clone(), "REW:act": a.abs().mean(1), "successes": (rew > 0.8).float(),
+                 "success_rate": (dist < 0.2).float()}
+        self.s = torch.where(done[:, None], self.s0, self.s)
+        self.cnt = torch.where(done, torch.zeros_like(self.cnt), self.cnt)
+        return self._obs(), rew, done.to(torch.int64), infos

@@ -295,6 +295,69 @@ def gen_ppo(out_dir):
     np.savez_compressed(os.path.join(out_dir, "ppo.npz"), **save)
 
 
+def gen_ppo_run(out_dir):
+    """`PPO.run` of the reference (ppo.py:203-312, log: 356-447) for two learning iterations on rgbmanip_amd.synth.StubVecEnv:
+    the class as shipped, a recording SummaryWriter, the policy noise reproduced from the seed.  Saved: the noise draws, every
+    action the env received, every scalar `log()` wrote, the parameters and learning rate at the end."""
+    from algo.ppo.ppo import PPO
+    from rgbmanip_amd import synth
+
+    cfg = yaml.safe_load(open(os.path.join(REF, "cfg/controller/rl.yaml")))
+    cfg["learn"].update(device="cpu", log_dir="/tmp/rgbm_gold_logs", save_dir="/tmp/rgbm_gold_saves", print_log=True, testing=False)
+    # schedule "fixed": with the shipped "adaptive" schedule the first minibatches of an on-policy rollout have KL = +-1e-7 (the
+    # stored and the current policy are the same), and `kl_mean > 0.0` (ppo.py:485) then decides by rounding noise whether the
+    # learning rate starts to grow 1.5x per step: the reference's own trajectory changes with the BLAS thread count.  The adaptive
+    # rule itself is pinned by gen_ppo (KL well away from zero).
+    cfg["learn"].update(schedule="fixed", learning_rate=3.0e-4)
+    N, iters = 32, 2
+    T = cfg["learn"]["num_transitions_per_env"]
+    env = synth.StubVecEnv(N, _Box, seed=0)
+    ppo = PPO(env, cfg)
+    ppo.actor_critic.load_state_dict({k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()}, strict=True)
+    scalars = {}
+
+    class Rec:
+        def add_scalar(self, tag, value, step=None, *a, **k):
+            scalars.setdefault(tag, []).append((float(step) if step is not None else -1.0, float(value)))
+    ppo.writer = Rec()
+    # `RolloutStorage.get_statistics` (storage.py:66-72) does `done = self.dones.cpu(); done[-1] = 1`.  On the reference's own device
+    # (rl.yaml: cuda) `.cpu()` is a copy; with device="cpu", as here, it is the storage tensor itself, and the GAE that run() computes
+    # next would see every env's last transition as terminal.  Keep the cuda behaviour: restore the tensor after the call.
+    stats0 = ppo.storage.get_statistics
+
+    def stats_without_aliasing():
+        keep = ppo.storage.dones.clone()
+        out = stats0()
+        ppo.storage.dones.copy_(keep)
+        return out
+    ppo.storage.get_statistics = stats_without_aliasing
+    torch.manual_seed(777)
+    ppo.run(iters, log_interval=1, save_interval=1000)
+    n_calls = iters * (T + 1)
+    torch.manual_seed(777)
+    eps = torch.stack([torch.randn(N, 12) for _ in range(n_calls)])
+    acts = torch.stack(env.action_log)
+    assert acts.shape[0] == iters * T
+    # the draws are the policy's noise: the first action is mu + std^2 * eps0 of the initial policy
+    ppo0 = PPO(synth.StubVecEnv(N, _Box, seed=0), cfg)
+    ppo0.actor_critic.load_state_dict({k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()}, strict=True)
+    with torch.no_grad():
+        mu0 = ppo0.actor_critic.act_inference(env.reset())
+        recon = mu0 + torch.exp(2 * ppo0.actor_critic.log_std) * eps[0]
+    err = (recon - acts[0]).abs().max().item()
+    print("ppo_run: first action reconstructed from the seeded noise, max err", err)
+    assert err < 1e-6
+    save = {"eps": eps.numpy(), "actions": acts.numpy(), "lr_after": np.array(ppo.step_size),
+            "params_after": torch.cat([p.detach().reshape(-1) for p in ppo.actor_critic.state_dict().values()]).numpy()}
+    # tags whose x axis is wall-clock time are recorded by the reference too; their values duplicate Train/mean_*: keep the rest
+    for tag, rows in scalars.items():
+        if tag.endswith("/time"):
+            continue
+        save["scalar:" + tag] = np.array([v for _, v in rows], dtype=np.float64)
+        print(f"  {tag}: {[round(v, 5) for _, v in rows]}")
+    np.savez_compressed(os.path.join(out_dir, "ppo_run.npz"), **save)
+
+
 def gen_control(out_dir):
     """View queue / encoders / view selection of the reference ControlInterface (rl_pose.py:14-223) on the seeded view
     stream of rgbmanip_amd.synth.control_view: the class is imported as shipped; only the modules it drags in for the
@@ -476,7 +539,7 @@ if __name__ == "__main__":
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "control", "control_step", "align"]
+    which = sys.argv[1:] or ["adapose", "postproc", "ppo", "ppo_run", "control", "control_step", "align"]
     net_out = inp = None
     if "adapose" in which or "postproc" in which:
         net_out, inp = gen_adapose(out_dir)
@@ -484,6 +547,8 @@ if __name__ == "__main__":
         gen_postproc(out_dir, net_out, inp)
     if "ppo" in which:
         gen_ppo(out_dir)
+    if "ppo_run" in which:
+        gen_ppo_run(out_dir)
     if "control" in which:
         gen_control(out_dir)
     if "control_step" in which:
