@@ -99,10 +99,11 @@ def ppo_update(sd, roll, returns, advantages, cfg, step_size, adam_state=None, l
             kl = torch.sum(sig - osig + (torch.square(osig.exp()) + torch.square(omu - mu))
                            / (2.0 * torch.square(sig.exp())) - 0.5, dim=-1)
             kl_mean = kl.mean()
-            if kl_mean > cfg["desired_kl"] * 2.0:
-                step_size = max(cfg["min_lr"], step_size / 1.5)
-            elif kl_mean < cfg["desired_kl"] / 2.0 and kl_mean > 0.0:
-                step_size = min(cfg["max_lr"], step_size * 1.5)
+            if cfg.get("desired_kl") is not None and cfg.get("schedule", "adaptive") == "adaptive":      # ppo.py:480
+                if kl_mean > cfg["desired_kl"] * 2.0:
+                    step_size = max(cfg["min_lr"], step_size / 1.5)
+                elif kl_mean < cfg["desired_kl"] / 2.0 and kl_mean > 0.0:
+                    step_size = min(cfg["max_lr"], step_size * 1.5)
             ratio = torch.exp(logp - flat["actions_log_prob"][sl].squeeze(1))
             a = advf[sl].squeeze(1)
             surr = torch.max(-a * ratio, -a * torch.clamp(ratio, 1.0 - clip, 1.0 + clip)).mean()

@@ -261,3 +261,42 @@ def test_resize_restatement_pinned_by_torch_interpolate():
         from rgbmanip_amd import estimator
         np.testing.assert_allclose(estimator._resize_linear(img, 224), ref, rtol=0, atol=1e-4)
         assert np.array_equal(estimator._resize_nearest(mask, 224), refm)
+
+
+def test_ppo_run_restatement_matches_reference_run(golden_dir):
+    """The oracle's act / compute_returns / ppo_update chained the way `PPO.run` chains them (ppo.py:203-312) reproduce the
+    reference's own two-iteration run on the closed-form env: every action, the parameters after 64 optimiser steps."""
+    import copy
+    from oracle import ppo_ref
+    from rgbmanip_amd import synth
+    from rgbmanip_amd.config import RL_CONTROLLER_CFG
+    from rgbmanip_amd.spaces import Box
+    g = np.load(os.path.join(golden_dir, "ppo_run.npz"))
+    N, T = 32, 16
+    env = synth.StubVecEnv(N, Box, seed=0)
+    sd = {k: torch.from_numpy(v) for k, v in synth.policy_state_dict(seed=0).items()}
+    eps = torch.from_numpy(g["eps"])
+    lc = copy.deepcopy(RL_CONTROLLER_CFG["learn"])
+    lc.update(schedule="fixed", learning_rate=3.0e-4)
+    obs, st, adam, c = env.reset(), env.get_state(), None, 0
+    keys = ("observations", "states", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma")
+    for it in range(2):
+        roll = {k: [] for k in keys}
+        for t in range(T):
+            a, logp, v, mu, sig = ppo_ref.act(sd, obs, eps[c])
+            c += 1
+            nobs, rew, done, _ = env.step(a)
+            for k, val in zip(keys, (obs, st, a, rew.view(-1, 1), done.view(-1, 1), v, logp.view(-1, 1), mu, sig)):
+                roll[k].append(val.clone())
+            obs, st = nobs, env.get_state()
+        roll = {k: torch.stack(v) for k, v in roll.items()}
+        lastv = ppo_ref.act(sd, obs, eps[c])[2]
+        c += 1
+        ret, adv = ppo_ref.compute_returns(roll["rewards"], roll["dones"], roll["values"], lastv, lc["gamma"], lc["lam"])
+        mvl, msl, _, adam = ppo_ref.ppo_update(sd, roll, ret, adv, lc, lc["learning_rate"], adam_state=adam)
+        assert abs(mvl - g["scalar:Loss/value_function"][it]) < 1e-4 * abs(mvl)
+        assert abs(msl - g["scalar:Loss/surrogate"][it]) < 1e-4 * abs(msl) + 1e-7
+    acts = torch.stack(env.action_log).numpy()
+    assert np.abs(acts - g["actions"]).max() < 2e-6
+    flat = torch.cat([p.reshape(-1) for p in sd.values()]).numpy()
+    assert np.abs(flat - g["params_after"]).max() / np.abs(g["params_after"]).max() < 1e-5
