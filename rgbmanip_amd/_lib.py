@@ -40,11 +40,11 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<unsigned short, 32, 16, 2, 8, 8, 1, true, false> (conv9)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, true, false> (conv11)", "bf16"),
 ] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
-     ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<bx3_t>", "bf16x3"),
+     ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false> (128 channels x 256 pixels)", "bf16x3"),
      ("conv_igemm_w256_kernel<unsigned short> (experimental, debug flag 8192)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, false> (256 channels x 128 pixels)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
-     ("unused", "bf16"), ("unused", "bf16"), ("unused", "bf16")]
+     ("conv_igemm_ws_kernel<rgbm::bx3_t, true, false> (256 channels x 128 pixels)", "bf16x3"), ("unused", "bf16"), ("unused", "bf16")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 
