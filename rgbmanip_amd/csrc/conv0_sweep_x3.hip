@@ -128,13 +128,20 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     // after chunk k of plane z has been blended out of the same registers; each blend waits for exactly its 4 oldest loads
     // (28 stay in flight).  The asm results must not be touched before X3_WAIT(k), which names them as in/out.
 #define X3_GATHER(K, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
+#if defined(X3_ABL) && (X3_ABL & 1)      // timing experiment: every lane gathers the same 16 bytes (no address divergence, no cache traffic)
+#define X3_GATHER4(K, C) do { X3_GATHER(K, 0, zoff); X3_GATHER(K, 1, zoff); X3_GATHER(K, 2, zoff); X3_GATHER(K, 3, zoff); } while (0)
+#elif defined(X3_ABL) && (X3_ABL & 2)    // timing experiment: no gathers at all
+#define X3_GATHER4(K, C) do { } while (0)
+#else
 #define X3_GATHER4(K, C) do { X3_GATHER(K, 0, (C).off[0]); X3_GATHER(K, 1, (C).off[1]); X3_GATHER(K, 2, (C).off[2]); X3_GATHER(K, 3, (C).off[3]); } while (0)
+#endif
 #if X3_DBG & 1
 #define X3_WAITB(K) X3_WAIT(K, 0)
 #else
 #define X3_WAITB(K) X3_WAIT(K, 28)
 #endif
 #define X3_WAIT(K, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+    const unsigned zoff = 0u; (void)zoff;
     int pg = 0;                                          // planes produced so far (ring slot = pg % 3)
     for (int k = 0; k < n_my; ++k) {
       int n, h0, w0;
@@ -277,6 +284,11 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
                  : "v"(sa), "n"(X3_BOFF(TP, F0)), "n"(X3_BOFF(TP, F0) + 64), "n"(X3_BOFF(TP, F0 + 1)), "n"(X3_BOFF(TP, F0 + 1) + 64) : "memory");
 #define X3_LDW(SET, TP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(AL[SET]) : "v"(wa), "n"((TP) * 1024) : "memory");
 #define X3_MFMA(ACC, A, BB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(BB))
+#ifdef X3_SINGLE      // timing experiment only: the hi x hi products alone (a third of the matrix work, wrong results)
+#define X3_MMA12(I)                                                                                                  \
+    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][0]);                \
+    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][2]);
+#else
 #define X3_MMA12(I)                                                                                                  \
     X3_MFMA(Xn[2 * ((I) % 2)], A01l[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], AL[((I) / 2) % 3], B[(I) % 3][0]);           \
     X3_MFMA(Xn[2 * ((I) % 2) + 1], A01l[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], AL[((I) / 2) % 3], B[(I) % 3][2]);   \
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][3]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][3]);        \
     X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][0]);                \
     X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][2]);
+#endif
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
       A01h[s] = ld_u4v(d.wgt + (s * 16 + lr) * 4 + lg);
