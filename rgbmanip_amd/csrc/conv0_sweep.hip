@@ -24,7 +24,7 @@
 #include "prof.h"
 
 #ifndef SW_ABL
-#define SW_ABL 0      // ablation builds only (tools/abl_sweep.sh): 1 no blend, 2 no MFMA, 4 no gathers
+#define SW_ABL 0      // ablation builds only (tools/abl_sweep.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel
 #endif
 
 namespace rgbm {
@@ -249,6 +249,10 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       c.off[1] = (r0 + (unsigned)xc1) * 64u;
       c.off[2] = (r1 + (unsigned)xc0) * 64u;
       c.off[3] = (r1 + (unsigned)xc1) * 64u;
+#if SW_ABL & 8        // timing experiment: groups of 4 lanes gather the same pixel (16 instead of 64 lines per instruction)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c.off[q] = (unsigned)__builtin_amdgcn_ds_bpermute((lane & ~3) * 4, (int)c.off[q]);
+#endif
     };
 
     // One register set of 16 x 16 B: chunk k (its 4 corners) of plane z+1 is requested right after chunk k of plane z

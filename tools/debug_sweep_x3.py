@@ -46,3 +46,7 @@ for kd in range(3):
     print(f"if kd={kd} taps were missing: err {float((y - alt).abs().max() / sc):.4f}")
 bad = (e / sc > 1e-3)
 print("bad voxels", int(bad.sum()), "of", bad.numel())
+idx = bad.nonzero()
+import collections
+print("bad (view, ch, d, h, w) samples:", idx[:12].tolist())
+print("distinct (v,d,h,w):", sorted(set((int(a), int(c), int(d_), int(e_)) for a, b, c, d_, e_ in idx.tolist()))[:40])
