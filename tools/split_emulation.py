@@ -93,6 +93,11 @@ MODES = {
     "f16x3_ftz":       lambda: run("f16 split x3 (denormals flushed), all convs", Emu("f16", True), Emu("f16", True)),
     "f16x3_3d1":       lambda: run("f16x3 2-D convs, f16 single-term 3-D convs", Emu("f16"), Emu("f16", False, 1, 1)),
     "f16x3_3dx1":      lambda: run("f16x3 2-D, 3-D: x single-term, w split", Emu("f16"), Emu("f16", False, 1, 2)),
+    # two products per value pair instead of three: one operand split, the other a single 16-bit term
+    "f16_xs_w1":       lambda: run("f16: x split, w single term, all convs", Emu("f16", False, 2, 1), Emu("f16", False, 2, 1)),
+    "f16_x1_ws":       lambda: run("f16: x single term, w split, all convs", Emu("f16", False, 1, 2), Emu("f16", False, 1, 2)),
+    "bf16_xs_w1":      lambda: run("bf16: x split, w single term, all convs", Emu("bf16", False, 2, 1), Emu("bf16", False, 2, 1)),
+    "f16_xs_w1_2d":    lambda: run("f16: 2-D x split / w single, 3-D f16x3", Emu("f16", False, 2, 1), Emu("f16")),
     "f16x3_2dx1":      lambda: run("2-D: x single-term w split, 3-D f16x3", Emu("f16", False, 1, 2), Emu("f16")),
 }
 
