@@ -34,13 +34,17 @@ def test_errors_are_reported_not_swallowed():
     assert b"workspace_bytes" in lib.rgbm_last_error()
 
 
-def test_sweep_x3_asm_gathers_keep_their_registers():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("src", ["conv0_sweep_x3.hip", "conv0_sweep.hip"])
+def test_sweep_asm_gathers_keep_their_registers(src):
     """hipcc must not copy or re-home a register whose inline-asm load is still in flight (tools/check_asm_gathers.py explains how it
     did while conv0_sweep_x3.hip's cooperative producers were written); the check reads the ISA of the current sources."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_gathers.py"),
-                        os.path.join(root, "rgbmanip_amd", "csrc", "conv0_sweep_x3.hip")], capture_output=True, text=True, timeout=600)
+                        os.path.join(root, "rgbmanip_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "16 rolling gather destinations" in r.stdout
+    assert "plane loop lines" in r.stdout

@@ -1,4 +1,4 @@
-"""Build-time check of the split-pair plane-sweep kernel's inline-asm gathers (conv0_sweep_x3.hip, cooperative producers).
+"""Build-time check of the plane-sweep kernels' inline-asm gathers (conv0_sweep.hip, conv0_sweep_x3.hip).
 
 The sweep kernels keep `global_load_dwordx4` instructions issued from inline asm in flight across loop iterations and count them by
 hand.  For the compiler an asm output is final the moment the asm statement is issued, so nothing in the language stops it from
@@ -7,8 +7,8 @@ register is reused under the landing load) or (b) sinking a consumer below the r
 made before the wait.  Both happened while the cooperative producers of conv0_sweep_x3.hip were written (a memory fault from wild
 gather offsets; one voxel group wrong from run to run).  The source is now shaped so that hipcc has no reason to do either; this
 script checks the ISA it actually produced:
-  * every gather destination tuple is used by the same number of gather instructions (prologue + loop body name the same registers),
-  * no v_mov reads or writes a gather destination inside the producer region.
+  * the prologue gathers name destination tuples that the plane loop names too (no re-homing between prologue and loop),
+  * no v_mov reads or writes a gather destination inside the producers' plane loop.
 usage: check_asm_gathers.py <file.hip> [extra hipcc flags...]   (exit code 1 on a finding)"""
 import collections
 import os
@@ -28,27 +28,40 @@ def regs(tok):
 
 
 def check(asm_text):
+    """For every conv0_sweep* kernel: the loop that holds the rolling gathers (>= 16 saddr-form global_load_dwordx4) must not contain
+    a v_mov that reads or writes one of their destination registers, and every prologue gather (same form, outside the loop) must
+    name a destination tuple that the loop names too."""
     findings = []
-    for name in re.findall(r'^(_Z\S*conv0_sweep_x3\S*):', asm_text, re.M):      # the 16-bit kernel shares registers between its roles: not checkable this way
+    for name in re.findall(r'^(_Z\S*conv0_sweep\S*):', asm_text, re.M):
         a = asm_text.index(name + ':')
         body = asm_text[a:asm_text.index('.Lfunc_end', a)].split('\n')
-        gl = [(i, l.split()[1].rstrip(',')) for i, l in enumerate(body) if 'global_load_dwordx4' in l and ', s[' in l]
-        cnt = collections.Counter(t for _, t in gl)
-        rolling = {t: c for t, c in cnt.items() if c >= 2}
-        if not rolling:
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
+        loops = []
+        for i, l in enumerate(body):
+            m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        is_gather = lambda l: 'global_load_dwordx4' in l and ', s[' in l
+        cands = [(y - x, x, y) for x, y in loops if sum(is_gather(l) for l in body[x:y + 1]) >= 16]
+        if not cands:
             continue
-        if len(set(rolling.values())) != 1:
-            findings.append(f"{name[:50]}: gather destinations are not used uniformly: {sorted(rolling.items())}")
+        _, x, y = min(cands)                     # the innermost such loop: the producers' plane loop
+        inside = [l.split()[1].rstrip(',') for l in body[x:y + 1] if is_gather(l)]
         dest = set()
-        for t in rolling:
+        for t in inside:
             dest |= regs(t)
-        lo = min(i for i, t in gl if t in rolling)
-        hi = max(i for i, t in gl if t in rolling)
-        for i in range(max(lo - 5, 0), min(hi + 60, len(body))):
+        for i in range(x, y + 1):
             l = body[i].strip()
             if l.startswith('v_mov') and any(regs(o) & dest for o in l.split()[1:]):
                 findings.append(f"{name[:50]}: line {i}: {l}")
-        print(f"{name[:60]}: {len(rolling)} rolling gather destinations x {set(rolling.values())} uses, {len(dest)} registers checked")
+        # prologue gathers: the 16 / 32 requests in front of the loop (the last saddr gathers before it)
+        before = [l.split()[1].rstrip(',') for l in body[max(0, x - 400):x] if is_gather(l)]
+        pro = [t for t in before if regs(t) & dest]
+        stray = [t for t in pro if t not in set(inside)]
+        if stray:
+            findings.append(f"{name[:50]}: prologue gathers into tuples the loop does not use: {stray}")
+        print(f"{name[:60]}: plane loop lines {x}..{y}, {len(inside)} gathers in the loop into {len(set(inside))} tuples, "
+              f"{len(pro)} prologue gathers, {len(dest)} registers checked")
     return findings
 
 
