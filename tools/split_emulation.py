@@ -98,6 +98,8 @@ MODES = {
     "f16_x1_ws":       lambda: run("f16: x single term, w split, all convs", Emu("f16", False, 1, 2), Emu("f16", False, 1, 2)),
     "bf16_xs_w1":      lambda: run("bf16: x split, w single term, all convs", Emu("bf16", False, 2, 1), Emu("bf16", False, 2, 1)),
     "f16_xs_w1_2d":    lambda: run("f16: 2-D x split / w single, 3-D f16x3", Emu("f16", False, 2, 1), Emu("f16")),
+    "f16_2d1_3dx3":    lambda: run("2-D f16 single term (x and w), 3-D f16x3", Emu("f16", False, 1, 1), Emu("f16")),
+    "bf16x3_2df16":    lambda: run("2-D f16 single term (x and w), 3-D bf16x3", Emu("f16", False, 1, 1), Emu("bf16")),
     "f16x3_2dx1":      lambda: run("2-D: x single-term w split, 3-D f16x3", Emu("f16", False, 1, 2), Emu("f16")),
 }
 
