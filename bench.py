@@ -50,6 +50,12 @@ def make_inputs(B, device, unique=16):
     return out, dev
 
 
+def _mark(msg):
+    """Progress marker on stderr (RGBM_BENCH_TRACE=1): which leg a rank is in, for diagnosing multi-rank stalls."""
+    if os.environ.get("RGBM_BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')} t={time.perf_counter():.1f}] {msg}", file=sys.stderr, flush=True)
+
+
 def tree_hash():
     """sha256 (first 16 hex digits) over the library sources: PMC measurements are only valid for the tree
     they were taken on (tools/pmc_traffic.py stamps the same value into profiles/hbm_traffic.json)."""
@@ -263,6 +269,7 @@ def main():
     n_valid = int(valid.sum().item())
     finite = bool(torch.isfinite(bbox).all().item())
 
+    _mark("timed region done")
     # ---- accuracy of the benched mode and throughput + accuracy of the modes that meet north_star's 1e-4 gate (not part of `value`) ----
     acc_res, modes_res = None, None
     if rank == 0 and not args.no_accuracy:
@@ -290,6 +297,7 @@ def main():
             del mnet2
             torch.cuda.empty_cache()
 
+    _mark("accuracy / modes legs done")
     # ---- SURVEY 8f-1 leg (not part of `value`): device-side prepare_model_input on 480x640 frames, vs the host numpy path ----
     prep_res = None
     if rank == 0 and not args.no_prepare:
@@ -325,6 +333,7 @@ def main():
                     "note": "480x640x3 f32 frame + mask -> 224x224 normalised crop, 1024 choose indices, cropped intrinsics (interface_v5.py:58-170)"}
         del frames, masks
 
+    _mark("prepare leg done")
     # ---- configs[4] leg (not part of `value`): mixed-object batch, 4 heads, sorted by head and sharded over the ranks ----
     mixed_res = None
     if not args.no_mixed:
@@ -356,6 +365,7 @@ def main():
                      "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head"}
         del mnet
 
+    _mark("mixed leg done")
     # ---- PPO leg: AdaPose-in-the-loop rollout (synthetic vec-env stand-in) + HIP learn phase, cfg/controller/rl.yaml ----
     ppo_res = None
     if args.ppo_envs > 0:
@@ -387,6 +397,7 @@ def main():
                    "optimizer_steps": 32, "env": env_name,
                    "lr_after": ppo.step_size}
 
+    _mark("ppo leg done")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
