@@ -274,7 +274,7 @@ def main():
     acc_res, modes_res = None, None
     if rank == 0 and not args.no_accuracy:
         acc_res = accuracy_vs_golden(net, device)
-    if rank == 0 and not args.no_modes:
+    if rank == 0 and world == 1 and not args.no_modes:      # N = 1 information; at N > 1 the other ranks would idle at the next barrier meanwhile
         modes_res = {}
         for md in ("bf16x3", "fp32"):
             if md == args.dtype:
