@@ -277,7 +277,12 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * f32/bf16, 14 conv0_sweep_kernel (bf16), 15 conv_igemm_ws64_kernel (bf16), 16..25 conv3d_tile_kernel bf16 per layer (conv0..conv6, conv7, conv9, conv11;
  * row 8 then holds only the f32 3-D layers and row 9 stays empty), others unused; columns {launches, total ms, algorithmic FLOPs, algorithmic bytes}.
  * stop synchronises on the recorded events. */
-/* ablation switches for kernel benchmarking only (0 = normal operation) */
+/* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):
+ *      4  register-staged implicit GEMM (conv_igemm.hip) instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
+ *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
+ *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
+ *   4096  fp16 nets: halo-tile conv0 instead of the plane sweep          8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
+ *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental) */
 int rgbm_debug_flags(int flags);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);
