@@ -282,7 +282,8 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
  *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
  *   4096  fp16 nets: halo-tile conv0 instead of the plane sweep          8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
- *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental) */
+ *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
+ * 262144  generic tile instead of the 64 x 256 four-wave ws tile */
 int rgbm_debug_flags(int flags);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);

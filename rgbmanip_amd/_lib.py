@@ -44,7 +44,8 @@ PROF_KERNELS = [
      ("conv_igemm_w256_kernel<unsigned short> (experimental, debug flag 8192)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, false> (256 channels x 128 pixels)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
-     ("conv_igemm_ws_kernel<rgbm::bx3_t, true, false> (256 channels x 128 pixels)", "bf16x3"), ("unused", "bf16"), ("unused", "bf16")]
+     ("conv_igemm_ws_kernel<rgbm::bx3_t, true, false> (256 channels x 128 pixels)", "bf16x3"),
+     ("conv_igemm_ws_kernel<..., false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"), ("unused", "bf16")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 

@@ -613,10 +613,16 @@ __device__ __forceinline__ void decode_row(const ConvDesc& d, unsigned m, unsign
 // at row offset kw*dil; lanes whose neighbour falls off the image row read a zero row), and only the weights are staged per step:
 // 17 X pieces per three steps instead of 48.  Two rings: 3 W slots of 32 KB, 3 X slots of 17 KB (a group's pixels are requested
 // over the three steps two groups ahead).
-template <typename T, bool WIDE, bool RH>
-__global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
+// SLIM: a 64-channel x 256-pixel tile with FOUR multiply waves (8 waves, 512 threads; 10 pieces per request wave and K tile) for
+// layers with at most 64 output channels in the storage types that have no ws64 kernel (split pairs, fp32) and for 16-bit
+// layers that kernel does not take (residual adds): the role split of this kernel instead of the do-it-all generic tile.
+template <typename T, bool WIDE, bool RH, bool SLIM>
+__global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const ConvDesc d) {
   static_assert(!RH || (WIDE && sizeof(T) == 2), "row-halo variant: 256 x 128 tile, 16-bit storage");
-  constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
+  static_assert(!SLIM || (!WIDE && !RH), "slim tile: plain ring only");
+  constexpr int NMW = SLIM ? 4 : 8;          // multiply waves; four request waves follow
+  constexpr int NTH = (NMW + 4) * 64;
+  constexpr int BCH = SLIM ? 64 : WIDE ? 256 : 128, BPIX = (WIDE && !SLIM) ? 128 : 256;
   constexpr int XROWS = 136;                 // RH: rows of an X slot (BPIX + 2 * 4, whole 8-row pieces)
   constexpr int WSLOT = BCH * 8, XSLOT = XROWS * 8;              // RH: uint4 slots of a W / X ring slot
   constexpr int XBASE = 3 * WSLOT, ZROW = XBASE + 3 * XSLOT;     // RH: X ring, then one row of zeros
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   constexpr int FM = 4, FN = 4;
   constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (48 KB)
   extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
-  static_assert(NP == 12, "the counted waits below assume 12 pieces per tile");
+  static_assert(NP == (SLIM ? 10 : 12), "the counted waits below assume 12 (slim: 10) pieces per tile");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -655,18 +661,18 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   float* lbias = reinterpret_cast<float*>(lds3 + (RH ? ZROW + 8 : 3 * STAGE));
   const bool bias_lds = d.bias != nullptr && d.bias_stride == 0 && d.Cout <= 2048;
   if (bias_lds)
-    for (int i = tid; i < d.Cout; i += 768) lbias[i] = d.bias[i];
+    for (int i = tid; i < d.Cout; i += NTH) lbias[i] = d.bias[i];
   if (RH && tid < 8) lds3[ZROW + tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
   if constexpr (RH) {
-    if (wave >= 8) {
+    if (wave >= NMW) {
       // ---------------------------------------------------------------- request waves, row-halo variant
       // W stream: step g+2 (8 pieces per wave and step) behind barrier g; X stream: group g/3 + 2, its 17 pieces dealt
       // round-robin to the four waves (5 / 4 / 4 / 4) and requested over the group's three steps as 2, 2, 1|0 pieces per wave.
       const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
       const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
-      const int pw = wave - 8;
+      const int pw = wave - NMW;
       const int j = lane & 7, r8 = lane >> 3;
       const int dil = d.dilw;
       const int NCC = d.Cin >> 6;
@@ -762,15 +768,15 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     }
   }
 
-  if (wave >= 8) {
+  if (wave >= NMW) {
     // ------------------------------------------------------------------ request waves
 #ifdef WS_PRIO
     if (WS_PRIO == 3) __builtin_amdgcn_s_setprio(2);
 #endif
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
-    const int pw = wave - 8;
-    const int tp = tid - 512;
+    const int pw = wave - NMW;
+    const int tp = tid - NMW * 64;
     const int j = tp & 7;
     const int r0 = tp >> 3;                  // 0..31
     const int js = j ^ ((r0 >> 1) & 7);
@@ -841,8 +847,9 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
     if (total > 1) issue(1);
     int st = 0;
     for (int g = 0; g < total; ++g) {
-      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step g landed; step g+1 may still fly
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (g + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (SLIM) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step g landed; step g+1 may still fly
       RGBM_BARRIER();            // step g is complete in LDS; the stage of step g-1 is free
       if (g + 2 < total) issue(st == 0 ? 2 : st - 1);
       st = st == 2 ? 0 : st + 1;
@@ -857,8 +864,8 @@ __global__ __launch_bounds__(768) void conv_igemm_ws_kernel(const ConvDesc d) {
   if (WS_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if (WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #endif
-  const int wch = WIDE ? (wave >> 1) * 64 : (wave >> 2) * 64;
-  const int wpix = WIDE ? (wave & 1) * 64 : (wave & 3) * 64;
+  const int wch = SLIM ? 0 : WIDE ? (wave >> 1) * 64 : (wave >> 2) * 64;
+  const int wpix = (WIDE && !SLIM) ? (wave & 1) * 64 : (wave & 3) * 64;
   const int lr = lane & 15, lg = lane >> 4;
   // Fragment reads run half a K tile ahead of the MFMAs that consume them (two register sets): after the barrier of
   // step g the first-half fragments are requested, the second half of the previous step is multiplied out of registers
@@ -1153,9 +1160,9 @@ static void make_fastdiv(int dvs, unsigned& m, int& sh) {
   m = (unsigned)(((1ull << sh) + (unsigned long long)dvs - 1ull) / (unsigned long long)dvs);
 }
 
-template <typename T, bool WIDE, bool RH>
+template <typename T, bool WIDE, bool RH, bool SLIM = false>
 static int launch_ws(ConvDesc d, hipStream_t s) {
-  constexpr int BCH = WIDE ? 256 : 128, BPIX = WIDE ? 128 : 256;
+  constexpr int BCH = SLIM ? 64 : WIDE ? 256 : 128, BPIX = (WIDE && !SLIM) ? 128 : 256;
   constexpr size_t LDS = (RH ? (3 * (size_t)(BCH + 136) * 8 + 8) : 3 * (size_t)(BCH + BPIX) * 8) * sizeof(uint4) + 2048 * sizeof(float);      // K-tile ring(s) + per-channel bias table
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
   d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
@@ -1166,7 +1173,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   static int n_cu = 0;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH>), (int)LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), (int)LDS)) return rc;
   if (n_cu == 0) {
     int dev = 0;
     RGBM_CHECK_HIP(hipGetDevice(&dev));
@@ -1175,8 +1182,8 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : WIDE && std::is_same<T, bx3_t>::value ? 33 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE, RH>), dim3((unsigned)grid), dim3(768), LDS, s, d);
+  prof_begin_launch(s, SLIM ? 34 : RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : WIDE && std::is_same<T, bx3_t>::value ? 33 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), dim3((unsigned)grid), dim3(SLIM ? 512 : 768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
@@ -2151,6 +2158,12 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     if (conv_ws64_eligible(d, BF16)) return launch_ws64<T>(d, s);
   }
   RGBM_REQUIRE(d.w2 == nullptr, "a fused 1x1 needs the ws64 kernel (check conv_ws64_eligible first)");
+  // 33..64 output channels where there is no ws64 kernel (split pairs, fp32) or it does not apply (residual adds): the
+  // role-specialised kernel with a 64 x 256 tile and four multiply waves
+  if (conv_ch_tile(d.Cout) == 64 && uni && d.M >= 256 * 256 && d.M < (1ll << 31) && !(g_debug_flags & (8 | 64 | 262144))) {
+    const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
+    if ((al & 15ull) == 0ull) return launch_ws<T, false, false, true>(d, s);
+  }
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
 }
 
