@@ -122,6 +122,9 @@ int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* mask_dev, c
 /* Per-env mask extent for the controller's view queue.
  * Replaces: the np.nonzero / np.where loop of ControlInterface.add_view   models/controller/rl_pose.py:130-149
  * mask [N,H,W] u8 -> ext [N,4] i32 = (row min, col min, row max, col max), (2H, 2W, 0, 0) for an empty mask; count [N]. */
+/* Projection matrices the network takes (interface_v5.py:264-270): P = eye(4), P[:3, :] = Kcrop @ E[:3, :] in fp64, stored as
+ * float32.  Kcrop_dev [N][3][3] f64 (rgbm_prepare_inputs' Kcrop_out), E_dev [N][4][4] f64, P_dev [N][4][4] f32. */
+int rgbm_projection(const double* Kcrop_dev, const double* E_dev, float* P_dev, int N, void* stream);
 int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -241,6 +244,11 @@ int rgbm_conv_nd(int dtype, const void* in_dev, int N, int D, int H, int W, int 
  * post-activation residual res_dev (same layout as out). */
 int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N, int D, int H, int W, const float* w_host,
                      const float* bn_scale_host, const float* bn_shift_host, const void* res_dev, void* out_dev, void* stream);
+/* PSPUpsample (pspnet.py:100-107: x2 bilinear align_corners=True -> Conv2d 3x3 pad 1 + bias -> activation) as the network runs
+ * it: a 1x1 GEMM at the low resolution with the nine taps stacked on the output channels (z_scratch_dev: V*h*w*9*Cout elements
+ * of `dtype`), then the tap-combining kernel.  in_dev [V][h][w][Cin], w_host [Cout][Cin][3][3], out_dev [V][2h][2w][Cout]. */
+int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, int Cin, const float* w_host, int Cout,
+                          const float* bias_host, int act, float slope, void* z_scratch_dev, void* out_dev, void* stream);
 int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream);
 int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
                             void* stream);
@@ -271,12 +279,20 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
                        size_t* n_elems, void* stream);
 
 /* Live per-kernel timing for bench.py's roofline figure: between start and stop every convolution launch is
- * bracketed by HIP events recorded on its own stream.  stats: host double[32*4], one row per kernel family:
- * 0..7 conv_igemm_glds_kernel<dtype, BCH> (row = dtype*4 + {0:16,1:32,2:64,3:128}-channel tile), 8/9 conv3d_tile_kernel
- * f32/bf16 (conv1..conv11), 10/11 conv3d_tile_kernel conv0 + fused plane sweep f32/bf16, 12/13 conv_igemm_v3_kernel
- * f32/bf16, 14 conv0_sweep_kernel (bf16), 15 conv_igemm_ws64_kernel (bf16), 16..25 conv3d_tile_kernel bf16 per layer (conv0..conv6, conv7, conv9, conv11;
- * row 8 then holds only the f32 3-D layers and row 9 stays empty), others unused; columns {launches, total ms, algorithmic FLOPs, algorithmic bytes}.
+ * bracketed by HIP events recorded on its own stream.  stats: host double[RGBM_PROF_ROWS * 4], one row per kernel family,
+ * columns {launches, total ms, algorithmic FLOPs, algorithmic bytes}; rgbm_prof_rows() returns RGBM_PROF_ROWS of the
+ * library that is loaded (size the buffer from it when binding dynamically).  Rows:
+ *  0..7   conv_igemm_glds_kernel<dtype, BCH> (row = dtype*4 + {0:16,1:32,2:64,3:128}-channel tile; dtype 0 f32, 1 16-bit)
+ *  8 / 9  conv3d_tile_kernel f32 / (unused)          10 / 11  conv3d_tile_kernel conv0 + fused plane sweep f32 / 16-bit
+ *  12 / 13 conv_igemm_ws_kernel 128 x 256 tile (and conv_igemm_v3_kernel) f32 / 16-bit
+ *  14     conv0_sweep_kernel (16-bit)                15  conv_igemm_ws64_kernel (16-bit)
+ *  16..25 conv3d_tile_kernel 16-bit per layer (conv0..conv6, conv7, conv9, conv11)
+ *  26..29 bf16x3: generic implicit GEMM, 3-D layers, conv0 + plane sweep, ws 128 x 256 tile
+ *  30     conv_igemm_w256_kernel (experimental)      31 / 32  ws 256 x 128 tile 16-bit / its row-halo variant
+ *  33     ws 256 x 128 tile bf16x3                   34 / 35 / 36  ws 64 x 256 four-multiply-wave tile bf16x3 / 16-bit / f32
+ *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  unused
  * stop synchronises on the recorded events. */
+#define RGBM_PROF_ROWS 40
 /* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):
  *      4  register-staged implicit GEMM (conv_igemm.hip) instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
@@ -285,6 +301,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile */
 int rgbm_debug_flags(int flags);
+int rgbm_prof_rows(void);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);
 

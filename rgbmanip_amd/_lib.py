@@ -18,7 +18,7 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
 
 # rows of rgbm_prof_stop (include/rgbm.h): (kernel name as rocprofv3 prints it, arithmetic dtype)
-PROF_ROWS = 36
+PROF_ROWS = 40          # == RGBM_PROF_ROWS (include/rgbm.h); load() checks it against rgbm_prof_rows()
 PROF_KERNELS = [
     ("conv_igemm_glds_kernel<float, 16, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 32, 256>", "fp32"),
     ("conv_igemm_glds_kernel<float, 64, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 128, 128>", "fp32"),
@@ -45,7 +45,11 @@ PROF_KERNELS = [
      ("conv_igemm_ws_kernel<unsigned short, true, false> (256 channels x 128 pixels)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
      ("conv_igemm_ws_kernel<rgbm::bx3_t, true, false> (256 channels x 128 pixels)", "bf16x3"),
-     ("conv_igemm_ws_kernel<..., false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"), ("unused", "bf16")]
+     ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"),
+     ("conv_igemm_ws_kernel<unsigned short, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16"),
+     ("conv_igemm_ws_kernel<float, false, false, true> (64 channels x 256 pixels, four multiply waves)", "fp32"),
+     ("upconv_combine_kernel<16-bit> (PSPUpsample tap combination)", "bf16"), ("upconv_combine_kernel<4-byte> (PSPUpsample tap combination)", "bf16x3"),
+     ("unused", "bf16")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 
@@ -104,6 +108,7 @@ SIGNATURES = {
     "rgbm_conv_nd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                           _vp, _i, _i, _f, _vp, _vp]),
     "rgbm_conv3d_tile": (_i, [_i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_upsample_conv3x3": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
     "rgbm_maxpool3x3s2": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -112,6 +117,7 @@ SIGNATURES = {
     "rgbm_conv0_sweep_dt": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_prepare_inputs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_prepare_inputs_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_projection": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rgbm_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rgbm_lookat_quat": (_i, [_vp, _i, _i, _vp, _vp]),
     "rgbm_control_action_to_pose": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp, _vp]),
@@ -120,6 +126,7 @@ SIGNATURES = {
     "rgbm_synth_camera": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_synth_render": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_debug_flags": (_i, [_i]),
+    "rgbm_prof_rows": (_i, []),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),
 }
@@ -140,6 +147,8 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.rgbm_prof_rows() != PROF_ROWS:
+        raise RgbmError(f"{LIB_PATH}: rgbm_prof_rows() = {lib.rgbm_prof_rows()}, this binding expects {PROF_ROWS} (stale build?)")
     _lib = lib
     return lib
 

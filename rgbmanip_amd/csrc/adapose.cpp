@@ -104,6 +104,11 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
     GET(sl, p + "1.weight");
     const std::string bn = p + "0.bias";
     if (int rc = init_conv2d(*u.L, dtype, sd, p + "0.weight", bn.c_str(), u.cin, u.cout, 3, 1, 1, 1, ACT_PRELU, sl->data[0], u.cin)) return rc;
+    UpConvLayer* uc = u.L == &up1 ? &up1c : u.L == &up2 ? &up2c : nullptr;
+    if (uc) {
+      GET(w, p + "0.weight"); GET(b, bn);
+      if (int rc = uc->init(dtype, u.cin, u.cout, w->data, b->data, ACT_PRELU, sl->data[0])) return rc;
+    }
   }
   if (int rc = init_conv2d(fin, dtype, sd, "img_extractor.final.weight", "img_extractor.final.bias", 64, 32, 1, 1, 0, 1, ACT_NONE, 0.f, 64)) return rc;
 
@@ -194,6 +199,7 @@ void AdaPose::destroy() {
   for (int i = 0; i < n_blocks; ++i) { blocks[i].c1.destroy(); blocks[i].c2.destroy(); if (blocks[i].has_ds) blocks[i].ds.destroy(); }
   for (auto& l : psp) l.destroy();
   up1.destroy(); up2.destroy(); up3.destroy(); fin.destroy();
+  up1c.destroy(); up2c.destroy();
   for (auto& l : c3d) l.destroy();
   for (auto& l : dc) l.destroy();
   inst.destroy();
@@ -328,10 +334,20 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
     if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, Sb, Sb, 128, nullptr, 0, nullptr, 0, s)) return rc;
     if (int rc = launch_resize_bilinear_ac(dtype, bf.stage[i], bf.cat, V, Sb, Sb, 128, H, W, 1024, 512 + 128 * i, s)) return rc;
   }
-  if (int rc = launch_resize_bilinear_ac(dtype, bf.cat, bf.ups, V, H, W, 1024, 2 * H, 2 * W, 1024, 0, s)) return rc;
-  if (int rc = up1.run(bf.ups, bf.u1, V, 1, 2 * H, 2 * W, 256, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_resize_bilinear_ac(dtype, bf.u1, bf.ups, V, 2 * H, 2 * W, 256, 4 * H, 4 * W, 256, 0, s)) return rc;
-  if (int rc = up2.run(bf.ups, bf.u2, V, 1, 4 * H, 4 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  // up_1 / up_2: 1x1 GEMM at the low resolution (nine taps stacked on the output channels, z in `ups`: 9/16 of the up-sampled
+  // tensor it replaces) + tap combination; or, for A/B, the x2 resize followed by the 3x3 conv on the up-sampled grid
+  if (upconv & 1) {
+    if (int rc = up1c.run(bf.cat, bf.ups, bf.u1, V, H, W, 256, s)) return rc;
+  } else {
+    if (int rc = launch_resize_bilinear_ac(dtype, bf.cat, bf.ups, V, H, W, 1024, 2 * H, 2 * W, 1024, 0, s)) return rc;
+    if (int rc = up1.run(bf.ups, bf.u1, V, 1, 2 * H, 2 * W, 256, nullptr, 0, nullptr, 0, s)) return rc;
+  }
+  if (upconv & 2) {
+    if (int rc = up2c.run(bf.u1, bf.ups, bf.u2, V, 2 * H, 2 * W, 64, s)) return rc;
+  } else {
+    if (int rc = launch_resize_bilinear_ac(dtype, bf.u1, bf.ups, V, 2 * H, 2 * W, 256, 4 * H, 4 * W, 256, 0, s)) return rc;
+    if (int rc = up2.run(bf.ups, bf.u2, V, 1, 4 * H, 4 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  }
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
   // up_3 + final: one launch on the bf16 path (the 64-channel up_3 output then never reaches HBM: `u3` is not written)
   if (int rc = up3.run_then_1x1(fin, bf.ups, bf.u3, 64, bf.feat, 32, V, 1, 8 * H, 8 * W, fuse_final != 0, nullptr, s)) return rc;

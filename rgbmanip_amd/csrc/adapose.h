@@ -34,6 +34,8 @@ struct AdaPose {
   Block blocks[16];
   int n_blocks = 0;
   ConvLayer psp[4], up1, up2, up3, fin;
+  UpConvLayer up1c, up2c;       // up_1 / up_2 as a low-resolution 1x1 GEMM + tap combination (upconv.hip)
+  int upconv = 3;               // bit 0: up_1, bit 1: up_2 through UpConvLayer (0 = x2 resize + 3x3 conv on the up-sampled grid, for A/B and tests)
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
   struct Tile3d { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0; };
   Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11

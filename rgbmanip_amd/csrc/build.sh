@@ -6,7 +6,7 @@ OUT=${1:-..}
 mkdir -p build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip; do
+for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip upconv.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip; do
   [ -f "$f" ] || continue
   EXTRA=""
   # files that must round like numpy / torch elementwise ops: no mul+add -> fma contraction

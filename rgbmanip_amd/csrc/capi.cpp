@@ -64,6 +64,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "igemm_conv6") { RGBM_REQUIRE(value == 0 || value == 1, "igemm_conv6"); h->net.igemm_conv6 = value; }
   else if (k == "fuse_final") { RGBM_REQUIRE(value == 0 || value == 1, "fuse_final"); h->net.fuse_final = value; }
   else if (k == "sparse_tail") { RGBM_REQUIRE(value == 0 || value == 1, "sparse_tail"); h->net.sparse_tail = value; }
+  else if (k == "upconv") { RGBM_REQUIRE(value >= 0 && value <= 3, "upconv"); h->net.upconv = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   return 0;
@@ -175,6 +176,17 @@ int rgbm_conv_nd(int dtype, const void* in_dev, int N, int D, int H, int W, int 
   return rc;
 }
 
+int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, int Cin, const float* w_host, int Cout,
+                          const float* bias_host, int act, float slope, void* z_scratch_dev, void* out_dev, void* stream) {
+  RGBM_REQUIRE(in_dev && w_host && z_scratch_dev && out_dev, "upsample_conv3x3 arguments");
+  UpConvLayer L;
+  int rc = L.init(dtype, Cin, Cout, w_host, bias_host, act, slope);
+  if (!rc) rc = L.run(in_dev, z_scratch_dev, out_dev, V, h, w, Cout, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  L.destroy();
+  return rc;
+}
+
 int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream) {
   return launch_maxpool3x3s2(dtype, in_dev, out_dev, V, H, W, C, (hipStream_t)stream);
 }
@@ -195,6 +207,7 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 
 #include "prof.h"
 extern "C" {
+int rgbm_prof_rows(void) { return rgbm::kProfVariants; }
 int rgbm_prof_start(void) { return rgbm::prof_start(); }
 int rgbm_prof_stop(double* stats) {
   RGBM_REQUIRE(stats != nullptr, "prof_stop arguments");
@@ -286,6 +299,10 @@ extern "C" int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* 
   RGBM_REQUIRE(frame_map_dev, "prepare_inputs_indexed frame_map");
   return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, frame_map_dev, N, H, W, S, P, seed, img_out, choose_out, pts2d_out,
                                Kcrop_out, window_out, valid_out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int rgbm_projection(const double* Kcrop_dev, const double* E_dev, float* P_dev, int N, void* stream) {
+  return launch_projection(Kcrop_dev, E_dev, P_dev, N, (hipStream_t)stream);
 }
 
 extern "C" int rgbm_mask_extent(const uint8_t* mask_dev, int N, int H, int W, int32_t* ext_out, int32_t* count_out, void* stream) {

@@ -1182,7 +1182,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, SLIM ? 34 : RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : WIDE && std::is_same<T, bx3_t>::value ? 33 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
+  prof_begin_launch(s, SLIM ? (std::is_same<T, bx3_t>::value ? 34 : sizeof(T) == 2 ? 35 : 36) : RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : WIDE && std::is_same<T, bx3_t>::value ? 33 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), dim3((unsigned)grid), dim3(SLIM ? 512 : 768), LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());

@@ -19,6 +19,11 @@ int launch_homography(const float* P_views, float* out, int V, int B, hipStream_
 int launch_build_volume(int dtype, const void* feat, const float* homog, const float* depths, void* vol, int v0, int Vc, int V,
                         int B, int D, int H, int W, hipStream_t s);
 
+// upconv.hip — tap-combining half of PSPUpsample evaluated as a low-resolution 1x1 GEMM (layers.h, UpConvLayer):
+// z [V][h][w][9*Co] (tap-major) -> out [V][2h][2w][ldo] = act(bias + sum_t bilinear(z_t)(p + t))
+int launch_upconv_combine(int dtype, const void* z, const float* bias, void* out, int V, int h, int w, int Co, int ldo, int act,
+                          float slope, hipStream_t s);
+
 int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_t s);
 
 // head_kernels.hip
@@ -76,6 +81,7 @@ int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const dou
 int launch_umeyama_ransac(const float* nocs, const float* depth, const int* choose, const double* Kc, const double* E1,
                           double* bbox, double* srt, int* valid, int B, int P, int img, unsigned seed, hipStream_t s);
 
+int launch_projection(const double* Kc, const double* E, float* P, int n, hipStream_t s);      // prepare.hip
 int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext, int* count, hipStream_t s);
 
 // postproc.hip

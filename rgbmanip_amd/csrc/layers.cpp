@@ -1,4 +1,5 @@
 #include "layers.h"
+#include "kernels.h"
 
 #include <string.h>
 
@@ -249,6 +250,31 @@ int ConvLayer::run_then_1x1(const ConvLayer& next, const void* in, void* mid, in
   int Do, Ho, Wo;
   out_dims(Di, Hi, Wi, Do, Ho, Wo);
   return next.run(mid, out2, N, Do, Ho, Wo, ldo2, nullptr, RES_NONE, nullptr, 0, s);
+}
+
+int UpConvLayer::init(int dtype, int Cin, int Cout_, const float* w, const float* bias_h, int act_, float slope_) {
+  Cout = Cout_; act = act_; slope = slope_;
+  RGBM_REQUIRE(Cout % dtype_chunk(dtype) == 0, "upconv Cout must be a multiple of the 16-byte chunk");
+  std::vector<float> wz((size_t)9 * Cout * Cin);
+  for (int t = 0; t < 9; ++t)
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c) wz[((size_t)t * Cout + o) * Cin + c] = w[((size_t)o * Cin + c) * 9 + t];
+  ConvGeom g;
+  g.Cin = Cin; g.Cout = 9 * Cout; g.act = ACT_NONE;
+  if (int rc = gemm.init(dtype, g, wz.data(), nullptr, nullptr, nullptr, Cin, 9 * Cout)) return rc;
+  if (bias_h) { if (upload_f32(bias_h, Cout, &bias)) return -2; }
+  return 0;
+}
+
+void UpConvLayer::destroy() {
+  gemm.destroy();
+  if (bias) (void)hipFree(bias);
+  bias = nullptr;
+}
+
+int UpConvLayer::run(const void* in, void* z, void* out, int V, int h, int w, int ldo, hipStream_t s) const {
+  if (int rc = gemm.run(in, z, V, 1, h, w, 9 * Cout, nullptr, RES_NONE, nullptr, 0, s)) return rc;
+  return launch_upconv_combine(gemm.dtype, z, bias, out, V, h, w, Cout, ldo, act, slope, s);
 }
 
 }  // namespace rgbm

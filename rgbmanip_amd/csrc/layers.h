@@ -61,6 +61,21 @@ struct ConvLayer {
                  const float* bias_override, int bias_stride, int cls) const;
 };
 
+// PSPUpsample (x2 bilinear align_corners -> conv3x3 pad 1 + bias -> activation; pspnet.py:100-107) as a 1x1 GEMM at the low
+// resolution with the nine taps stacked on the output channels, followed by the tap-combining kernel (upconv.hip)
+struct UpConvLayer {
+  ConvLayer gemm;                // 1x1: Cin -> 9*Cout rows in (tap, channel) order, no bias, no activation
+  float* bias = nullptr;         // [Cout] fp32 or null
+  int Cout = 0, act = ACT_NONE;
+  float slope = 0.f;
+  // w: [Cout][Cin][3][3] (nn.Conv2d layout)
+  int init(int dtype, int Cin, int Cout, const float* w, const float* bias_h, int act, float slope);
+  void destroy();
+  size_t scratch_elems(int V, int h, int w) const { return (size_t)V * h * w * 9 * Cout; }
+  // in [V][h][w][Cin] -> z scratch [V][h][w][9*Cout] -> out [V][2h][2w][ldo]
+  int run(const void* in, void* z, void* out, int V, int h, int w, int ldo, hipStream_t s) const;
+};
+
 // device upload helpers
 int upload_packed(const std::vector<float>& w, int dtype, void** dev);      // host fp32 -> device array in storage type dtype
 int upload_f32(const float* host, size_t n, float** dev);

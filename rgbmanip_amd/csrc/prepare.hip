@@ -227,6 +227,26 @@ __global__ __launch_bounds__(PRE_THREADS) void mask_extent_kernel(const unsigned
 
 }  // namespace
 
+// P = eye(4); P[:3, :] = K' @ E[:3, :] in fp64 (interface_v5.py:264-267: numpy float64, dot products summed left to right), stored
+// as the float32 the network takes (interface_v5.py:269-270).  One thread per matrix.
+__global__ void projection_kernel(const double* __restrict__ Kc, const double* __restrict__ E, float* __restrict__ P, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* k = Kc + (size_t)i * 9;
+  const double* e = E + (size_t)i * 16;
+  float* p = P + (size_t)i * 16;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) p[r * 4 + c] = (float)((k[r * 3 + 0] * e[c] + k[r * 3 + 1] * e[4 + c]) + k[r * 3 + 2] * e[8 + c]);
+  p[12] = 0.f; p[13] = 0.f; p[14] = 0.f; p[15] = 1.f;
+}
+
+int launch_projection(const double* Kc, const double* E, float* P, int n, hipStream_t s) {
+  RGBM_REQUIRE(Kc && E && P && n > 0, "projection arguments");
+  hipLaunchKernelGGL(projection_kernel, dim3((n + 127) / 128), dim3(128), 0, s, Kc, E, P, n);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext, int* count, hipStream_t s) {
   RGBM_REQUIRE(mask && ext && count && N > 0 && H > 0 && W > 0, "mask_extent arguments");
   hipLaunchKernelGGL(mask_extent_kernel, dim3(N), dim3(PRE_THREADS), 0, s, mask, H, W, ext, count);

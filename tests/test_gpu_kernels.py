@@ -598,3 +598,68 @@ def test_resize_x2_kernel_identical_to_generic(dtype, shape):
     assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8))
     ref = F.interpolate(x.float().cpu().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     assert (outs[0].float().cpu() - ref).abs().max() < (1e-5 if dtype == _lib.F32 else 4e-2)
+
+
+UPCONV_CASES = [
+    # name, V, Cin, h, w, Cout, act      (PSPUpsample, pspnet.py:100-107: x2 bilinear align_corners -> conv3x3 pad 1 + bias -> PReLU)
+    ("up_small", 2, 64, 6, 8, 32, 2),                 # generic 1x1 GEMM tiles, rectangular image
+    ("up_1_shape", 1, 1024, 28, 28, 256, 2),           # the layer's own channel counts at one view
+    ("up_2_ws", 6, 256, 56, 56, 64, 2),                # M = 18816 rows per view x 6 >= 65536: the persistent GEMM kernel writes z
+    ("up_relu_none", 1, 32, 5, 4, 16, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", UPCONV_CASES, ids=[c[0] for c in UPCONV_CASES])
+def test_upsample_conv3x3_commuted(case, dtype):
+    """rgbm_upsample_conv3x3 (1x1 GEMM at the low resolution with the nine taps stacked on the output channels + the
+    tap-combining kernel, upconv.hip) against F.interpolate(x2, bilinear, align_corners=True) -> F.conv2d(3x3, pad 1) + bias ->
+    activation on the CPU, operands rounded to the storage type."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, empty_out, host_f32
+    name, V, Cin, h, w, Cout, act = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    x = _q(torch.randn(V, Cin, h, w, generator=g).relu(), dtype)
+    wt = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5), dtype)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    slope = 0.25
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), wt, bias, 1, 1)
+    ref = _act(ref, act, slope)
+    xd = to_channels_last(x, dtype)
+    z = empty_out((V, h, w, 9 * Cout), dtype)
+    out = empty_out((V, 2 * h, 2 * w, Cout), dtype)
+    wa, wp = host_f32(wt)
+    ba, bp = host_f32(bias)
+    torch.cuda.synchronize()
+    _lib.check(lib.rgbm_upsample_conv3x3(dtype, _lib.ptr(xd), V, h, w, Cin, wp, Cout, bp, act, slope, _lib.ptr(z), _lib.ptr(out),
+                                         _lib.stream_ptr()), "rgbm_upsample_conv3x3")
+    torch.cuda.synchronize()
+    got = from_channels_last(out, Cout)
+    assert torch.isfinite(got).all()
+    # the z planes are rounded to the storage type once more than in the reference order (like the up-sampled input was before)
+    tol = {_lib.F32: 2e-5, _lib.BF16: 2.5e-2, _lib.F16: 4e-3, _lib.BF16X3: 4e-5}[dtype]
+    err = rel_err(got, ref)
+    print(name, dtype, "upconv rel err", err)
+    assert err < tol, (name, dtype, err)
+
+
+def test_upsample_conv3x3_zero_padding_and_edges():
+    """The conv's zero padding lives on the UP-SAMPLED grid: a constant input with a single-tap kernel makes every border output
+    that reaches outside lose exactly that tap (fp32, exact reference)."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, empty_out, host_f32
+    lib = _lib.load()
+    V, Cin, h, w, Cout = 1, 4, 4, 6, 4
+    x = torch.ones(V, Cin, h, w) + torch.arange(h * w, dtype=torch.float32).view(1, 1, h, w) * 0.125
+    for t in range(9):
+        wt = torch.zeros(Cout, Cin, 3, 3)
+        wt[:, :, t // 3, t % 3] = torch.eye(Cout, Cin)
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), wt, None, 1, 1)
+        xd = to_channels_last(x, _lib.F32)
+        z = empty_out((V, h, w, 9 * Cout), _lib.F32)
+        out = empty_out((V, 2 * h, 2 * w, Cout), _lib.F32)
+        wa, wp = host_f32(wt)
+        _lib.check(lib.rgbm_upsample_conv3x3(_lib.F32, _lib.ptr(xd), V, h, w, Cin, wp, Cout, None, 0, 0.0, _lib.ptr(z), _lib.ptr(out),
+                                             _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got = from_channels_last(out, Cout)
+        assert float((got - ref).abs().max()) < 2e-6, (t, float((got - ref).abs().max()))
