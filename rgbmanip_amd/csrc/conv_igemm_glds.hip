@@ -790,9 +790,14 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     auto enter_tile = [&](int k) {
       int pix_tile, ch_tile;
       tile_of(k, pix_tile, ch_tile);
-#pragma unroll
-      for (int i = 0; i < XR; ++i) {
-        const long long m = (long long)pix_tile * BPIX + r0 + 32 * i;
+      // The eight lanes (r0, j = 0..7) of a row group need the same XR row descriptors (GEMM rows r0 + 32*i): lane j decodes
+      // row i = j once and the group exchanges them, instead of every lane decoding all XR rows (3 divisions, 7 bound tests and
+      // two 64-bit products each: ~800 instructions per lane and tile, on the critical path of the first request of a tile —
+      // with that work skipped a 4-K-tile launch ran 29 % faster, a 36-K-tile layer3 conv 7 %)
+      long long mybase = 0;
+      unsigned mymask = 0;
+      if (j < XR) {
+        const long long m = (long long)pix_tile * BPIX + r0 + 32 * j;
         int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
         if (m < d.M) {
           unsigned n, qd, qh, qw;
@@ -802,13 +807,18 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
           xh0 = (int)qh * d.sh - d.ph;
           xw0 = (int)qw * d.sw - d.pw;
         }
-        unsigned mk = 0;
-        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
-        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
-        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
-        rmask[i] = mk;
+        for (int kk = 0; kk < d.KD; ++kk) mymask |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+        for (int kk = 0; kk < d.KH; ++kk) mymask |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+        for (int kk = 0; kk < d.KW; ++kk) mymask |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
         const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
-        rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+        mybase = pix0 * d.Cin * (long long)sizeof(T);
+      }
+      const int grp = (tp & 63) & 56;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const long long b = __shfl(mybase, grp | i, 64);
+        rmask[i] = (unsigned)__shfl((int)mymask, grp | i, 64);
+        rowp[i] = reinterpret_cast<const char*>(in) + b + (long long)(js * E) * (long long)sizeof(T);
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
@@ -820,7 +830,8 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 
     int ikt = 0, itile = 0;                  // K tile / tile index of the next request
     auto issue = [&](int stage) {
-      if (ikt == 0) enter_tile(itile);
+      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile(itile);
+      if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
       const long long soff =
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-      if (sum == 12345.678f) out[tid] = (T)1;
+      if (sum == 12345.678f) reinterpret_cast<unsigned short*>(out)[tid] = 1;
       continue;
     }
 #endif
@@ -1022,10 +1033,19 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     long long obase[FN];
     int nn[FN];
     bool pok[FN];
+    // every layer but the sub-pixel classes of the transposed convs enumerates its output tensor in storage order: GEMM row m IS
+    // output pixel m, and the four coordinate divisions per lane and tile are only needed for a per-sample bias
+    const bool dense_out = d.osd == 1 && d.osh == 1 && d.osw == 1 && d.opd == 0 && d.oph == 0 && d.opw == 0 && d.Dq == d.Do &&
+                           d.Hq == d.Ho && d.Wq == d.Wo;
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
       const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
       pok[b] = m < d.M;
+      if (dense_out && (interior || d.bias_stride == 0)) {
+        nn[b] = 0;
+        obase[b] = (pok[b] ? m : 0ll) * d.ldo;
+        continue;
+      }
       unsigned n, qd, qh, qw;
       decode_row(d, pok[b] ? (unsigned)m : 0u, n, qd, qh, qw);
       nn[b] = (int)n;
@@ -1043,12 +1063,18 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     // instructions, ~100 branches and 8 dependent bias round trips per wave and tile, measured as 9 us per tile with
     // the matrix pipe idle.
     if (interior) {
-      const float slope = d.slope;
-      auto fast = [&](auto actc, auto resc) {
-        constexpr int ACT = decltype(actc)::value, RES = decltype(resc)::value;
-        // residual reads of the whole tile are requested before the first store (see the vmcnt note above); with 32-bit
-        // elements that would be 64 registers, so those go in two halves
-        constexpr int GRP = sizeof(T) == 2 ? FN : 2;
+      // One activation expression for none / ReLU / PReLU: y = v < 0 ? max(v, -FLT_MAX) * nslope : v with nslope = 1 / 0 / slope
+      // (the clamp keeps -inf * 0 from becoming NaN; a NaN fails the compare and passes through, like torch).  Specialised on
+      // (activation, residual mode) as nine instantiations, hipcc hoisted the 64 compares of a lane in front of the dispatch
+      // and kept their masks in 128 SGPRs (spilled to VGPR lanes with s_nop-padded v_writelane / v_readlane).
+      const float nslope = d.act == ACT_RELU ? 0.f : d.act == ACT_PRELU ? d.slope : 1.f;
+      auto fast = [&](auto resc) {
+        constexpr int RES = decltype(resc)::value;
+        // the residual reads of TWO pixel fragments are requested before their first store (see the vmcnt note above).  All four
+        // at once (32 registers in the 16-bit types) pushed the kernel over its 168 registers: hipcc then spilled an ACCUMULATOR
+        // out of the last MFMA block of every tile and reloaded it in the epilogue behind `s_waitcnt vmcnt(0)` — a scratch round
+        // trip (~2 us) with the matrix pipe idle, per tile
+        constexpr int GRP = 2;
 #pragma unroll
         for (int bh = 0; bh < FN; bh += GRP) {
           uint4 rr[NQ][GRP];
@@ -1073,8 +1099,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
                 for (int e = 0; e < CHK; ++e) v[e] += rv[e];
               }
 #pragma unroll
-              for (int e = 0; e < CHK; ++e)
-                v[e] = ACT == ACT_RELU ? (v[e] < 0.f ? 0.f : v[e]) : ACT == ACT_PRELU ? (v[e] < 0.f ? v[e] * slope : v[e]) : v[e];
+              for (int e = 0; e < CHK; ++e) v[e] = v[e] < 0.f ? __builtin_fmaxf(v[e], -3.402823466e38f) * nslope : v[e];
               if (RES == RES_POST_ACT) {
 #pragma unroll
                 for (int e = 0; e < CHK; ++e) v[e] += rv[e];
@@ -1085,14 +1110,9 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
           }
         }
       };
-      auto by_res = [&](auto actc) {
-        if (d.res_mode == RES_NONE) fast(actc, IC<RES_NONE>{});
-        else if (d.res_mode == RES_PRE_ACT) fast(actc, IC<RES_PRE_ACT>{});
-        else fast(actc, IC<RES_POST_ACT>{});
-      };
-      if (d.act == ACT_RELU) by_res(IC<ACT_RELU>{});
-      else if (d.act == ACT_PRELU) by_res(IC<ACT_PRELU>{});
-      else by_res(IC<ACT_NONE>{});
+      if (d.res_mode == RES_NONE) fast(IC<RES_NONE>{});
+      else if (d.res_mode == RES_PRE_ACT) fast(IC<RES_PRE_ACT>{});
+      else fast(IC<RES_POST_ACT>{});
       continue;
     }
 #pragma unroll
@@ -1856,7 +1876,8 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
 
     int ikt = 0, itile = 0;
     auto issue = [&](int stage) {
-      if (ikt == 0) enter_tile(itile);
+      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile(itile);
+      if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
       const long long soff =
