@@ -787,15 +787,21 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));      // this wave's first piece, stage 0
 
-    auto enter_tile = [&](int k) {
+    // The eight lanes (r0, j = 0..7) of a row group need the same XR row descriptors (GEMM rows r0 + 32*i): lane j decodes
+    // row i = j once and the group exchanges them, instead of every lane decoding all XR rows (3 divisions, 7 bound tests and
+    // two 64-bit products each: ~800 instructions per lane and tile, on the critical path of the first request of a tile —
+    // with that work skipped a 4-K-tile launch ran 29 % faster, a 36-K-tile layer3 conv 7 %).  The decode of tile k+1 runs right
+    // behind the LAST request of tile k (prepare_tile), i.e. while that request flies; the first request of tile k+1 only pays
+    // the exchange (enter_tile).
+    long long mybase = 0;
+    unsigned mymask = 0;
+    int my_ch_tile = 0;
+    auto prepare_tile = [&](int k) {
       int pix_tile, ch_tile;
       tile_of(k, pix_tile, ch_tile);
-      // The eight lanes (r0, j = 0..7) of a row group need the same XR row descriptors (GEMM rows r0 + 32*i): lane j decodes
-      // row i = j once and the group exchanges them, instead of every lane decoding all XR rows (3 divisions, 7 bound tests and
-      // two 64-bit products each: ~800 instructions per lane and tile, on the critical path of the first request of a tile —
-      // with that work skipped a 4-K-tile launch ran 29 % faster, a 36-K-tile layer3 conv 7 %)
-      long long mybase = 0;
-      unsigned mymask = 0;
+      my_ch_tile = ch_tile;
+      mybase = 0;
+      mymask = 0;
       if (j < XR) {
         const long long m = (long long)pix_tile * BPIX + r0 + 32 * j;
         int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
@@ -813,6 +819,8 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
         mybase = pix0 * d.Cin * (long long)sizeof(T);
       }
+    };
+    auto enter_tile = [&]() {
       const int grp = (tp & 63) & 56;
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
@@ -823,14 +831,14 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
         const int row = r0 + 32 * i;
-        wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
+        wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(my_ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
       }
       tkd = tkh = tkw = tc = 0;
     };
 
     int ikt = 0, itile = 0;                  // K tile / tile index of the next request
     auto issue = [&](int stage) {
-      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile(itile);
+      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile();
       if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
@@ -851,9 +859,10 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         tc = 0;
         if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
       }
-      if (++ikt == KT) { ikt = 0; ++itile; }
+      if (++ikt == KT) { ikt = 0; ++itile; if (itile < n_my) prepare_tile(itile); }
     };
 
+    if (total > 0) prepare_tile(0);
     if (total > 0) issue(0);
     if (total > 1) issue(1);
     int st = 0;
@@ -1846,11 +1855,16 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
     int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));
 
-    auto enter_tile = [&](int k) {
+    // row descriptors: decoded once per 8-lane row group and exchanged, the next tile's behind the last request of the current
+    // one (see conv_igemm_ws_kernel)
+    long long mybase = 0;
+    unsigned mymask = 0;
+    auto prepare_tile = [&](int k) {
       const int pix_tile = tile_of(k);
-#pragma unroll
-      for (int i = 0; i < XR; ++i) {
-        const long long m = (long long)pix_tile * BPIX + r0 + 32 * i;
+      mybase = 0;
+      mymask = 0;
+      if (j < XR) {
+        const long long m = (long long)pix_tile * BPIX + r0 + 32 * j;
         int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
         if (m < d.M) {
           unsigned n, qd, qh, qw;
@@ -1860,13 +1874,20 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
           xh0 = (int)qh * d.sh - d.ph;
           xw0 = (int)qw * d.sw - d.pw;
         }
-        unsigned mk = 0;
-        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
-        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
-        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
-        rmask[i] = mk;
+        for (int kk = 0; kk < d.KD; ++kk) mymask |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
+        for (int kk = 0; kk < d.KH; ++kk) mymask |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
+        for (int kk = 0; kk < d.KW; ++kk) mymask |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
         const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
-        rowp[i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + js * E) * (long long)sizeof(T);
+        mybase = pix0 * d.Cin * (long long)sizeof(T);
+      }
+    };
+    auto enter_tile = [&]() {
+      const int grp = (tp & 63) & 56;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const long long bb = __shfl(mybase, grp | i, 64);
+        rmask[i] = (unsigned)__shfl((int)mymask, grp | i, 64);
+        rowp[i] = reinterpret_cast<const char*>(in) + bb + (long long)(js * E) * (long long)sizeof(T);
       }
       tkd = tkh = tkw = tc = 0;
     };
@@ -1876,7 +1897,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
 
     int ikt = 0, itile = 0;
     auto issue = [&](int stage) {
-      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile(itile);
+      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile();
       if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
@@ -1897,9 +1918,10 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
         tc = 0;
         if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
       }
-      if (++ikt == KT) { ikt = 0; ++itile; }
+      if (++ikt == KT) { ikt = 0; ++itile; if (itile < n_my) prepare_tile(itile); }
     };
 
+    if (total > 0) prepare_tile(0);
     if (total > 0) issue(0);
     if (total > 1) issue(1);
     int st = 0;
