@@ -105,7 +105,7 @@ int rgbm_adapose_postprocess_ransac(int B, int P, int img_size, uint32_t seed, c
  * pts2d [N,P,2] f32 (optional, may be NULL), Kcrop [N,3,3] f64 (crop-adjusted intrinsics), window [N,4] i32
  * (rmin,rmax,cmin,cmax), valid [N] i32 (0 where the reference returns None: empty mask / empty resized mask; such
  * frames get finite dummy outputs).  scratch: N*S*S bytes.  The P-subset is drawn by a seeded hash instead of the
- * reference's global np.random.shuffle (same distribution, reproducible).  H, W >= 40; S*S <= 65536.
+ * reference's global np.random.shuffle (same distribution, reproducible).  H, W >= 440 (the reference's crop window is up to 440 pixels wide, interface_v5.py:63-88); S*S <= 65536.
  * ---------------------------------------------------------------------------------------------------------- */
 int rgbm_prepare_inputs(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, int N, int H, int W, int S, int P,
                         uint32_t seed, float* img_out, int32_t* choose_out, float* pts2d_out, double* Kcrop_out,
@@ -294,13 +294,16 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * stop synchronises on the recorded events. */
 #define RGBM_PROF_ROWS 40
 /* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):
- *      4  register-staged implicit GEMM (conv_igemm.hip) instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
+ *      4  (experiments build) register-staged implicit GEMM instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
  *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
- *   4096  fp16 nets: halo-tile conv0 instead of the plane sweep          8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
+ *   4096  halo-tile conv0 instead of the plane-sweep kernels             8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile */
 int rgbm_debug_flags(int flags);
+/* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
+ * flags are then ignored */
+int rgbm_has_experiments(void);
 int rgbm_prof_rows(void);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);

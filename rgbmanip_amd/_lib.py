@@ -127,6 +127,7 @@ SIGNATURES = {
     "rgbm_synth_render": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_debug_flags": (_i, [_i]),
     "rgbm_prof_rows": (_i, []),
+    "rgbm_has_experiments": (_i, []),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),
 }

@@ -377,11 +377,13 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     // never materialises: algorithmic bytes = features in + c0 out
     d.algo_bytes = ((layer == 10 ? (double)Vc * Hi * Wi * t3d[li].Cin : (double)Vc * Di * Hi * Wi * t3d[li].Cin) +
                     (double)Vc * Do * Ho * Wo * t3d[li].Cout * (res ? 2 : 1)) * (double)dtype_size(dtype);
-    if (layer == 10 && cost_impl == 3 && b16 && sweep_w && !(dtype == F16 && (g_debug_flags & 4096))) {
+    // debug flag 4096: the halo-tile conv0 instead of either depth-sweeping kernel, in every storage type (the runtime way out
+    // should a compiler update bring the sweep kernels' hand-counted asm gathers out of step)
+    if (layer == 10 && cost_impl == 3 && b16 && sweep_w && !(g_debug_flags & 4096)) {
       d.wgt = sweep_w;
       return launch_conv0_sweep(d, dtype, s);
     }
-    if (layer == 10 && cost_impl == 3 && dtype == BF16X3 && sweep_w) {
+    if (layer == 10 && cost_impl == 3 && dtype == BF16X3 && sweep_w && !(g_debug_flags & 4096)) {
       d.wgt = sweep_w;
       d.feat = bf.featf;
       return launch_conv0_sweep_x3(d, s);

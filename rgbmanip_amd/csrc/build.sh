@@ -5,6 +5,11 @@ cd "$(dirname "$0")"
 OUT=${1:-..}
 mkdir -p build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+# RGBM_EXPERIMENTS=1 build.sh also compiles the experiment kernels (256 x 256 two-group implicit GEMM, row-halo variant of the
+# 256 x 128 tile, register-staged implicit GEMM: all measured slower than what ships; debug flags 8192 / 131072 / 4 select them)
+if [ "${RGBM_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DRGBM_EXPERIMENTS"; fi
+echo "$FLAGS" > build/.flags.new 2>/dev/null || true
+if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o; cp build/.flags.new build/.flags; fi
 pids=()
 for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip upconv.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip; do
   [ -f "$f" ] || continue
@@ -20,6 +25,19 @@ for f in layers.cpp adapose.cpp capi.cpp prof.cpp; do
   hipcc $FLAGS -x hip -c "$f" -o build/${f%.cpp}.o &
   pids+=($!)
 done
+# The plane-sweep kernels keep inline-asm gathers in flight across loop iterations and count them by hand: what hipcc made of
+# THESE sources is checked (no copy / re-homing of an in-flight gather register, tools/check_asm_gathers.py) whenever one of them
+# was recompiled; a finding fails the build.
+chk=()
+for f in conv0_sweep.hip conv0_sweep_x3.hip; do
+  if [ ! -f build/${f%.hip}.asm_ok ] || [ "$f" -nt build/${f%.hip}.asm_ok ] || [ common.h -nt build/${f%.hip}.asm_ok ]; then
+    ( python3 ../../tools/check_asm_gathers.py "$f" > build/${f%.hip}.asm_log 2>&1 && touch build/${f%.hip}.asm_ok ) &
+    chk+=("$!:$f")
+  fi
+done
 for p in "${pids[@]}"; do wait $p; done
+for c in "${chk[@]}"; do
+  if ! wait ${c%%:*}; then echo "check_asm_gathers FAILED for ${c#*:}"; cat build/$(basename ${c#*:} .hip).asm_log; exit 1; fi
+done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librgbm_hip.so" build/*.o
 echo "built $OUT/librgbm_hip.so"

@@ -208,6 +208,13 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 #include "prof.h"
 extern "C" {
 int rgbm_prof_rows(void) { return rgbm::kProfVariants; }
+int rgbm_has_experiments(void) {
+#ifdef RGBM_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 int rgbm_prof_start(void) { return rgbm::prof_start(); }
 int rgbm_prof_stop(double* stats) {
   RGBM_REQUIRE(stats != nullptr, "prof_stop arguments");

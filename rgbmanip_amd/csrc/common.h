@@ -44,6 +44,8 @@ int fail(const char* what, const char* file, int line);
 // hipFuncAttributeMaxDynamicSharedMemorySize for `fn` on the current device: raised whenever a launch needs more than was set
 // for that (device, kernel) so far (a once-per-process flag would leave a second device, or a later wider launch, without it)
 int ensure_dynamic_lds(const void* fn, int bytes);
+// CU count of the current device, a multiple of 8 (one resident workgroup per CU for the persistent kernels); cached per device
+int persistent_grid_cus(int* n_cu);
 
 static inline size_t dtype_size(int dt) { return (dt == F32 || dt == BF16X3) ? 4 : 2; }
 static inline int dtype_chunk(int dt) { return 16 / (int)dtype_size(dt); }      // elements per 16-byte chunk

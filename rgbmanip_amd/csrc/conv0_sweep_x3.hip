@@ -624,15 +624,9 @@ int launch_conv0_sweep_x3(const Conv3dTileDesc& t, hipStream_t s) {
   const long long ntiles = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31), "conv0 sweep grid out of range");
   d.n_tiles = (int)ntiles;
-  static int n_cu = 0;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_x3_kernel), X3_LDS)) return rc;
-  if (n_cu == 0) {
-    int dev = 0;
-    RGBM_CHECK_HIP(hipGetDevice(&dev));
-    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = n_cu / 8 * 8;                       // one resident workgroup per CU; a multiple of the 8 XCDs
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = 0;
+  if (int rc = persistent_grid_cus(&n_cu)) return rc;
   // the tile order assumes a grid that is a multiple of 8 (XCD = block % 8); small launches round up and idle blocks exit
   int grid = ntiles < n_cu ? (int)((ntiles + 7) / 8 * 8) : n_cu;
   prof_begin_launch(s, t.prof_variant, t.algo_flops, t.algo_bytes);

@@ -26,6 +26,7 @@ namespace rgbm {
 extern int g_debug_flags;
 int launch_conv_glds(const ConvDesc& d, int dtype, hipStream_t s);
 
+#ifdef RGBM_EXPERIMENTS      // the register-staged kernel (debug flag 4): superseded by the LDS-DMA kernels, kept for A/B
 template <typename T> struct Mma;
 template <> struct Mma<unsigned short> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   }
 }
 
+#endif  // RGBM_EXPERIMENTS
+
 int conv_ch_tile(int Cout) {
   if (Cout <= 16) return 16;
   if (Cout <= 32) return 32;
@@ -258,6 +261,7 @@ int conv_ch_tile(int Cout) {
 }
 int conv_bk(int dtype) { return 8 * dtype_chunk(dtype); }      // 128 bytes per row
 
+#ifdef RGBM_EXPERIMENTS
 template <typename T, int BCH, int BPIX>
 static int launch_one(ConvDesc d, hipStream_t s) {
   d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
@@ -282,6 +286,8 @@ static int launch_t(const ConvDesc& d, hipStream_t s) {
   }
 }
 
+#endif  // RGBM_EXPERIMENTS
+
 int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
   RGBM_REQUIRE(d.M > 0 && d.M < (1ll << 31), "conv M out of range");
   RGBM_REQUIRE(d.Cout % 4 == 0 && d.ldo % 4 == 0, "conv Cout/ldo must be multiples of 4");
@@ -293,9 +299,12 @@ int launch_conv(const ConvDesc& d, int dtype, hipStream_t s) {
   } else {
     RGBM_REQUIRE(d.ntaps == 1, "linear-K mode needs a single tap");
   }
-  if (!(g_debug_flags & 4)) return launch_conv_glds(d, dtype, s);      // default: LDS-DMA variant (conv_igemm_glds.hip)
-  return dtype == BF16 ? launch_t<unsigned short>(d, s) : dtype == F16 ? launch_t<f16_t>(d, s)
-         : dtype == BF16X3 ? launch_t<bx3_t>(d, s) : launch_t<float>(d, s);
+#ifdef RGBM_EXPERIMENTS
+  if (g_debug_flags & 4)
+    return dtype == BF16 ? launch_t<unsigned short>(d, s) : dtype == F16 ? launch_t<f16_t>(d, s)
+           : dtype == BF16X3 ? launch_t<bx3_t>(d, s) : launch_t<float>(d, s);
+#endif
+  return launch_conv_glds(d, dtype, s);      // the LDS-DMA kernels (conv_igemm_glds.hip)
 }
 
 }  // namespace rgbm

@@ -1201,15 +1201,9 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
-  static int n_cu = 0;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), (int)LDS)) return rc;
-  if (n_cu == 0) {
-    int dev = 0;
-    RGBM_CHECK_HIP(hipGetDevice(&dev));
-    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = n_cu / 8 * 8;                       // one resident workgroup per CU (144 KB LDS); a multiple of the 8 XCDs
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = 0;
+  if (int rc = persistent_grid_cus(&n_cu)) return rc;
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
   prof_begin_launch(s, SLIM ? (std::is_same<T, bx3_t>::value ? 34 : sizeof(T) == 2 ? 35 : 36) : RH ? 32 : WIDE && sizeof(T) == 2 ? 31 : WIDE && std::is_same<T, bx3_t>::value ? 33 : prof_row_ws<T>(), d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), dim3((unsigned)grid), dim3(SLIM ? 512 : 768), LDS, s, d);
@@ -1218,6 +1212,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   return 0;
 }
 
+#ifdef RGBM_EXPERIMENTS      // experiment kernels (slower than the shipped ones; kept with their parity tests): build with RGBM_EXPERIMENTS=1 build.sh
 // ---------------------------------------------------------------------------------------------------------
 // 256 x 256 tile, 8 waves of 128 channels x 64 pixels, two wave groups in ping-pong (layers whose output channels are a multiple
 // of 256: layer3, layer4, up_1 — 96 % of the implicit GEMM's flops).
@@ -1610,14 +1605,8 @@ static int launch_w256(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_w256_kernel<T>), (int)LDS)) return rc;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    RGBM_CHECK_HIP(hipGetDevice(&dev));
-    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = n_cu / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = 0;
+  if (int rc = persistent_grid_cus(&n_cu)) return rc;
   const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
   prof_begin_launch(s, 30, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL((conv_igemm_w256_kernel<T>), dim3((unsigned)grid), dim3(512), LDS, s, d);
@@ -1625,6 +1614,8 @@ static int launch_w256(ConvDesc d, hipStream_t s) {
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+#endif  // RGBM_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------
 // 256 pixel x 64 channel tile, bf16, three roles (layers with 33..64 output channels and no residual: up_2, up_3).
@@ -2105,16 +2096,10 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
-  static int n_cu = 0;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<false, T>), 160 * 1024)) return rc;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws64_kernel<true, T>), 160 * 1024)) return rc;
-  if (n_cu == 0) {
-    int dev = 0;
-    RGBM_CHECK_HIP(hipGetDevice(&dev));
-    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = n_cu / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = 0;
+  if (int rc = persistent_grid_cus(&n_cu)) return rc;
   const int grid = d.n_tiles < n_cu ? d.n_tiles : n_cu;
   prof_begin_launch(s, 15, d.algo_flops, d.algo_bytes);
   if (rh) hipLaunchKernelGGL((conv_igemm_ws64_kernel<true, T>), dim3((unsigned)grid), dim3(768), LDS, s, d);
@@ -2177,18 +2162,22 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
     // role-specialised (uniform taps, 16-byte aligned output / residual rows)
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
+#ifdef RGBM_EXPERIMENTS
     if constexpr (sizeof(T) == 2) {
       // 256 x 256 tiles for the layers whose channel count allows them (debug flag 8192 selects the 128 x 256 kernel for A/B)
       if (uni && (al & 15ull) == 0ull && d.Cout % 256 == 0 && d.Cin % 64 == 0 && d.KT >= 2 && (g_debug_flags & 8192) && !(g_debug_flags & 64))
         return launch_w256<T>(d, s);
     }
+#endif
     if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) {
       if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) {
+#ifdef RGBM_EXPERIMENTS
         if constexpr (sizeof(T) == 2) {
           // row-halo variant: measured 18 % SLOWER than the plain wide tile on a box where the kernel is issue-bound (the shifted B
           // rows cost ~70 VALU per step in the multiply waves); kept behind a switch for boxes where the L2 -> LDS path is the limit
           if ((g_debug_flags & 131072) && conv_rowhalo_ok(d) && d.Kpad == 9 * d.Cin && d.KT == 9 * (d.Cin >> 6)) return launch_ws<T, true, true>(d, s);
         }
+#endif
         return launch_ws<T, true, false>(d, s);
       }
       return launch_ws<T, false, false>(d, s);

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -22,14 +23,36 @@ static inline unsigned short host_f32_to_bf16(float f) {
 }
 
 int ensure_dynamic_lds(const void* fn, int bytes) {
-  static std::map<std::pair<int, const void*>, int> set_for;      // (device, kernel) -> bytes granted; launches come from one thread per device
+  // (device, kernel) -> bytes granted.  Several host threads may launch (one per device, or several streams of one device): the
+  // table is shared, so it is guarded
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> set_for;
   int dev = 0;
   RGBM_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
   int& have = set_for[std::make_pair(dev, fn)];
   if (bytes > have) {
     RGBM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     have = bytes;
   }
+  return 0;
+}
+
+// compute units of the CURRENT device rounded down to a multiple of the 8 XCDs (>= 8): the grid of the persistent kernels (one
+// resident workgroup per CU).  Cached per device.
+int persistent_grid_cus(int* n_cu) {
+  static std::mutex mu;
+  static std::map<int, int> per_dev;
+  int dev = 0;
+  RGBM_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int& n = per_dev[dev];
+  if (n == 0) {
+    RGBM_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    n = n / 8 * 8;
+    if (n < 8) n = 8;
+  }
+  *n_cu = n;
   return 0;
 }
 

@@ -189,12 +189,19 @@ class PPO:
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
         ep_reward = torch.zeros(self.num_envs, device=self.device)
         ep_len = torch.zeros(self.num_envs, device=self.device)
-        # finished-episode records of one iteration stay on the device ([T, N], NaN = no episode ended there) and reach
-        # the host in ONE copy after the rollout: the reference's per-step `.cpu()` (ppo.py:262-271) would synchronise
-        # the stream 16 times per iteration
+        # finished-episode records of one iteration stay on the device ([T, N] values + a boolean "an episode ended here" mask)
+        # and reach the host in ONE copy after the rollout: the reference's per-step `.cpu()` (ppo.py:262-271) would
+        # synchronise the stream 16 times per iteration.
+        # The reference never clears its `reward_sum` / `episode_length` lists (ppo.py:222-223, 268-269) and extends the two
+        # 100-entry deques with the CUMULATIVE lists every iteration (ppo.py:278-279): until 100 episodes have finished the
+        # deques hold duplicates, which `Train/mean_reward` / `Train/mean_episode_length` average over.  Reproduced here; only
+        # the last 100 entries of the cumulative lists can ever reach a maxlen-100 deque, so only those are kept.
+        # (On several ranks each rank keeps the statistics of its own envs; rank 0 logs its shard.)
         T_ = self.num_transitions_per_env
         fin_rew = torch.empty(T_, self.num_envs, device=self.device) if self.print_log else None
         fin_len = torch.empty(T_, self.num_envs, device=self.device) if self.print_log else None
+        fin_mask = torch.empty(T_, self.num_envs, dtype=torch.bool, device=self.device) if self.print_log else None
+        cum_rew, cum_len = [], []
         self.last_fps = 0.0
         for it in range(self.current_learning_iteration, num_learning_iterations):
             start = time.time()
@@ -212,7 +219,8 @@ class PPO:
                     ep_reward += rews.float().view(-1)
                     ep_len += 1
                     fin = dones.view(-1) > 0
-                    fin_rew[t_step] = torch.where(fin, ep_reward, torch.full_like(ep_reward, float("nan")))
+                    fin_mask[t_step] = fin
+                    fin_rew[t_step] = ep_reward
                     fin_len[t_step] = ep_len
                     ep_reward = torch.where(fin, torch.zeros_like(ep_reward), ep_reward)
                     ep_len = torch.where(fin, torch.zeros_like(ep_len), ep_len)
@@ -220,9 +228,10 @@ class PPO:
             torch.cuda.synchronize()
             collection_time = time.time() - start
             if self.print_log:      # same order as the reference's per-step extends: by step, then by env
-                done_at = ~torch.isnan(fin_rew)
-                rewbuffer.extend(fin_rew[done_at].cpu().tolist())
-                lenbuffer.extend(fin_len[done_at].cpu().tolist())
+                cum_rew = (cum_rew + fin_rew[fin_mask].cpu().tolist())[-100:]
+                cum_len = (cum_len + fin_len[fin_mask].cpu().tolist())[-100:]
+                rewbuffer.extend(cum_rew)
+                lenbuffer.extend(cum_len)
             mean_trajectory_length, mean_reward = self.storage.get_statistics()
             start = time.time()
             self.storage.compute_returns(last_values[:self.num_envs], self.gamma, self.lam, process_group=self.process_group)

@@ -218,6 +218,25 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
         assert _rel(got, ref) < 2e-2, ci
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+def test_halo_tile_conv0_runtime_switch(inputs, golden_dir, dtype):
+    """debug flag 4096 swaps the depth-sweeping conv0 kernels (hand-counted inline-asm gathers) for the halo-tile conv0 at run
+    time, in every storage type: the way out if a compiler update ever disturbs the sweep kernels.  Same gates as the default path."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    _lib.check(lib.rgbm_debug_flags(4096))
+    try:
+        out = _run(_net(dtype), inputs)
+    finally:
+        _lib.check(lib.rgbm_debug_flags(0))
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    gate = {"nocs": 2.7e-2, "depth": 1.0e-2, "r": 6.0e-3, "t": 3.5e-3, "s": 1.2e-3}
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+        assert errs[k] < (RTOL_FP32 if dtype == "bf16x3" else gate[k.split("_")[1]]), (k, errs)
+
+
 def test_bf16_fused_final_conv(inputs, oracle_taps):
     """up_3 + final in one launch (the store waves of conv_igemm_ws64_kernel multiply the staged bf16 tile by the 1x1
     weights) against the two-launch path: same bf16 operands, same fp32 accumulation, so the feature maps must agree to

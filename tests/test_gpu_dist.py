@@ -46,13 +46,18 @@ def _train_once(lo, hi):
                 world=ppo.world)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                      # RCCL: one device per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     per = N_TOTAL // world
     res = _train_once(rank * per, (rank + 1) * per)
     res["rank"] = rank
@@ -61,11 +66,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_the_single_process_update():
+def _two_rank_update(backend):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r["rank"])
@@ -84,3 +89,33 @@ def test_two_ranks_reproduce_the_single_process_update():
     for r in res:
         assert abs(r["mvl"] - one["mvl"]) < 1e-5 * abs(one["mvl"]) and abs(r["msl"] - one["msl"]) < 1e-5 + 1e-4 * abs(one["msl"])
         assert r["lr"] == one["lr"]
+
+
+def test_two_ranks_reproduce_the_single_process_update():
+    _two_rank_update("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL wants one device per rank: needs >= 2 GPUs")
+def test_two_ranks_over_rccl_reproduce_the_single_process_update():
+    """The same check with `backend="nccl"` (RCCL over xGMI), one rank per device — armed for boxes with >= 2 GPUs; the
+    advantage-statistics all-reduce and the flat-gradient all-reduce are then the real collectives of an 8-GPU run."""
+    _two_rank_update("nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
+def test_bench_two_gpus_smoke():
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one rank per GPU, RCCL): the line must
+    report both ranks and the nccl backend, and the weak-scaling value must cover both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "32", "--no-modes", "--ppo-envs", "32", "--ppo-iters", "1", "--no-prepare"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["dist_backend"] == "nccl"
+    assert line["config"]["parallelism"] == "dp2" and line["value"] > 0 and line["ppo"]["env_steps_per_sec"] > 0
