@@ -54,7 +54,10 @@ typedef struct rgbm_adapose_out {   /* device fp32, shapes of the reference's ou
 } rgbm_adapose_out;
 
 /* dtype: RGBM_F32 (parity mode), RGBM_BF16 (throughput mode) or RGBM_F16.
- * norm_mode: 0 = eval-mode BatchNorm3d folded into the convs (the parity oracle). */
+ * norm_mode: 0 = eval-mode BatchNorm3d folded into the convs (the default and the benchmarked path);
+ *            1 = per-sample statistics: every BatchNorm3d of the cost-regularisation net normalises a view's volume with that
+ *                volume's own biased mean / variance — what the reference as shipped computes (interface_v5.py:39-56 never calls
+ *                .eval() and runs one pose per call), with Dropout2d as identity.  Generic kernels, materialised volume. */
 int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode);
 int rgbm_adapose_destroy(rgbm_adapose_t* h);
 /* views per cost-volume chunk (default 512 = batch 256 in one chunk); bounds the workspace */

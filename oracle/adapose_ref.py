@@ -120,34 +120,42 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values):
 
 
 # ------------------------------------------------------------------ CostRegNet (network_v5.py:260-291)
-def _bn(x, sd, p):
+def _bn(x, sd, p, per_sample=False):
+    """eval mode: running statistics.  per_sample: the as-shipped train-mode BatchNorm3d at the batch size the
+    reference always runs (1, interface_v5.py:39-56 never calls .eval(); network_v5.py:17-28): every sample is normalised with
+    the biased mean / variance of its own D x H x W volume."""
     shape = (1, -1, 1, 1, 1)
+    if per_sample:
+        mean = x.mean(dim=(2, 3, 4), keepdim=True)
+        var = x.var(dim=(2, 3, 4), unbiased=False, keepdim=True)
+        return (x - mean) * torch.rsqrt(var + BN_EPS) * sd[p + "weight"].view(shape) + sd[p + "bias"].view(shape)
     inv = torch.rsqrt(sd[p + "running_var"] + BN_EPS) * sd[p + "weight"]
     return (x - sd[p + "running_mean"].view(shape)) * inv.view(shape) + sd[p + "bias"].view(shape)
 
 
-def conv3d_bn_relu(x, sd, p, stride):
-    """network_v5.py:22-28 — conv (no bias) -> BN3d(eval) -> ReLU."""
-    return F.relu(_bn(F.conv3d(x, sd[p + "conv.weight"], None, stride, 1), sd, p + "bn."))
+def conv3d_bn_relu(x, sd, p, stride, per_sample=False):
+    """network_v5.py:22-28 — conv (no bias) -> BN3d -> ReLU."""
+    return F.relu(_bn(F.conv3d(x, sd[p + "conv.weight"], None, stride, 1), sd, p + "bn.", per_sample))
 
 
-def deconv3d_bn_relu(x, sd, p):
-    """network_v5.py:246-252 — ConvTranspose3d(s2,p1,op1) -> BN3d(eval) -> ReLU."""
+def deconv3d_bn_relu(x, sd, p, per_sample=False):
+    """network_v5.py:246-252 — ConvTranspose3d(s2,p1,op1) -> BN3d -> ReLU."""
     y = F.conv_transpose3d(x, sd[p + "conv.weight"], None, 2, 1, 1)
-    return F.relu(_bn(y, sd, p + "bn."))
+    return F.relu(_bn(y, sd, p + "bn.", per_sample))
 
 
-def cost_reg_net(x, sd, p="cost_regularization.", taps=None, upto_conv11=False):
-    c0 = conv3d_bn_relu(x, sd, p + "conv0.", 1)
-    c1 = conv3d_bn_relu(c0, sd, p + "conv1.", 2)
-    c2 = conv3d_bn_relu(c1, sd, p + "conv2.", 1)
-    c3 = conv3d_bn_relu(c2, sd, p + "conv3.", 2)
-    c4 = conv3d_bn_relu(c3, sd, p + "conv4.", 1)
-    c5 = conv3d_bn_relu(c4, sd, p + "conv5.", 2)
-    c6 = conv3d_bn_relu(c5, sd, p + "conv6.", 1)
-    u7 = c4 + deconv3d_bn_relu(c6, sd, p + "conv7.")      # skip adds are post-ReLU (:287-289)
-    u9 = c2 + deconv3d_bn_relu(u7, sd, p + "conv9.")
-    u11 = c0 + deconv3d_bn_relu(u9, sd, p + "conv11.")
+def cost_reg_net(x, sd, p="cost_regularization.", taps=None, upto_conv11=False, norm_mode=0):
+    ps = norm_mode == 1
+    c0 = conv3d_bn_relu(x, sd, p + "conv0.", 1, ps)
+    c1 = conv3d_bn_relu(c0, sd, p + "conv1.", 2, ps)
+    c2 = conv3d_bn_relu(c1, sd, p + "conv2.", 1, ps)
+    c3 = conv3d_bn_relu(c2, sd, p + "conv3.", 2, ps)
+    c4 = conv3d_bn_relu(c3, sd, p + "conv4.", 1, ps)
+    c5 = conv3d_bn_relu(c4, sd, p + "conv5.", 2, ps)
+    c6 = conv3d_bn_relu(c5, sd, p + "conv6.", 1, ps)
+    u7 = c4 + deconv3d_bn_relu(c6, sd, p + "conv7.", ps)      # skip adds are post-ReLU (:287-289)
+    u9 = c2 + deconv3d_bn_relu(u7, sd, p + "conv9.", ps)
+    u11 = c0 + deconv3d_bn_relu(u9, sd, p + "conv11.", ps)
     if taps is not None:
         taps.update(c0=c0, c1=c1, c2=c2, c3=c3, c4=c4, c5=c5, c6=c6, u7=u7, u9=u9, u11=u11)
     if upto_conv11:
@@ -180,7 +188,7 @@ def ortho6d_to_mat(x_raw, y_raw):
     return torch.stack((x, y, z), dim=2)
 
 
-def view_heads(feat, fused, choose, depth_values, sd, taps=None, tag=""):
+def view_heads(feat, fused, choose, depth_values, sd, taps=None, tag="", norm_mode=0):
     """network_v5.py:432-465,485-499 for one view."""
     B, C, H, W = feat.shape
     D = depth_values.shape[1]
@@ -190,7 +198,7 @@ def view_heads(feat, fused, choose, depth_values, sd, taps=None, tag=""):
     nocs_feat = _mlp1d(nocs_feat, sd, "instance_color", (0,))
     nocs = torch.tanh(_mlp1d(nocs_feat, sd, "nocs_head", (0, 2, 4), last_act=False))     # [B,3,P]
 
-    prob_full = cost_reg_net(fused, sd, taps=taps).squeeze(1)                            # [B,D,H,W]
+    prob_full = cost_reg_net(fused, sd, taps=taps, norm_mode=norm_mode).squeeze(1)                            # [B,D,H,W]
     pre = torch.gather(prob_full.view(B, D, -1), 2, choose.unsqueeze(1).expand(B, D, P))
     prob = F.softmax(pre, dim=1)                                                          # [B,D,P]
     depth = torch.sum(prob * depth_values.view(B, D, 1), 1)                               # [B,P]
@@ -215,8 +223,9 @@ def view_heads(feat, fused, choose, depth_values, sd, taps=None, tag=""):
 
 
 @torch.no_grad()
-def adapose_forward(sd, img1, choose1, img2, choose2, P1, P2, depths, taps=None):
-    """Full forward; same argument order as network_v5.py:418. Returns the 10-entry dict."""
+def adapose_forward(sd, img1, choose1, img2, choose2, P1, P2, depths, taps=None, norm_mode=0):
+    """Full forward; same argument order as network_v5.py:418. Returns the 10-entry dict.  norm_mode 1: per-sample BatchNorm3d
+    statistics (the as-shipped train-mode behaviour at batch 1, Dropout2d still identity)."""
     t1 = {} if taps is not None else None
     feat1 = pspnet(img1, sd, taps=t1)
     feat2 = pspnet(img2, sd)
@@ -225,7 +234,7 @@ def adapose_forward(sd, img1, choose1, img2, choose2, P1, P2, depths, taps=None)
     fused1 = feat1.unsqueeze(2).repeat(1, 1, D, 1, 1) + warped2
     del warped2
     c1 = {} if taps is not None else None
-    n1, d1, r1, tt1, s1 = view_heads(feat1, fused1, choose1, depths, sd, taps=c1, tag="v1_")
+    n1, d1, r1, tt1, s1 = view_heads(feat1, fused1, choose1, depths, sd, taps=c1, tag="v1_", norm_mode=norm_mode)
     if taps is not None:
         taps.update({"v1_" + k: v for k, v in t1.items()})
         taps.update({("v1_" + k if not k.startswith("v1_") else k): v for k, v in c1.items()})
@@ -236,6 +245,6 @@ def adapose_forward(sd, img1, choose1, img2, choose2, P1, P2, depths, taps=None)
     warped1 = homo_warping(feat1, P1, P2, depths)
     fused2 = feat2.unsqueeze(2).repeat(1, 1, D, 1, 1) + warped1
     del warped1
-    n2, d2, r2, tt2, s2 = view_heads(feat2, fused2, choose2, depths, sd)
+    n2, d2, r2, tt2, s2 = view_heads(feat2, fused2, choose2, depths, sd, norm_mode=norm_mode)
     return {"view1_nocs": n1, "view2_nocs": n2, "view1_depth": d1, "view2_depth": d2,
             "view1_r": r1, "view1_t": tt1, "view1_s": s1, "view2_r": r2, "view2_t": tt2, "view2_s": s2}

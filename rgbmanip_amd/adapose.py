@@ -22,7 +22,8 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.
 
 class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
-                 cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None):
+                 cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None,
+                 norm_mode: int | str = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -43,7 +44,11 @@ class AdaPoseNet:
             descs.append(_lib.WeightDesc(name, a.ctypes.data, a.ndim, shape))
         arr = (_lib.WeightDesc * len(descs))(*descs)
         self._h = C.c_void_p()
-        _lib.check(self.lib.rgbm_adapose_create(C.byref(self._h), device, arr, len(descs), self.dtype, 0), "rgbm_adapose_create")
+        # norm_mode: 0 / "eval" = BatchNorm3d with running statistics (default); 1 / "per_sample" = the reference's as-shipped
+        # train-mode statistics at batch 1 (every view normalised with its own volume's mean / variance)
+        self.norm_mode = {"eval": 0, "per_sample": 1}.get(norm_mode, norm_mode)
+        _lib.check(self.lib.rgbm_adapose_create(C.byref(self._h), device, arr, len(descs), self.dtype, int(self.norm_mode)),
+                   "rgbm_adapose_create")
         if max_chunk_views:
             _lib.check(self.lib.rgbm_adapose_set_chunk(self._h, int(max_chunk_views)), "rgbm_adapose_set_chunk")
         if cost_impl is not None:

@@ -71,8 +71,9 @@ static int init_linear(ConvLayer& L, const StateDict& sd, const std::string& p, 
   return L.init(ldtype, g, w_override ? w_override : w->data, b->data, nullptr, nullptr, Cin_pad, Cout_pad);
 }
 
-int AdaPose::create(const StateDict& sd, int dtype_) {
+int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
   dtype = dtype_;
+  norm_mode = norm_mode_;
   const int E = dtype_chunk(dtype);
   img_cpad = E;                              // RGB padded to one 16-byte chunk
   const std::string fe = "img_extractor.feats.";
@@ -120,6 +121,23 @@ int AdaPose::create(const StateDict& sd, int dtype_) {
   if (int rc = init_conv3d_bn(dc[0], dtype, sd, cr + "conv7.", 64, 32, 2, true)) return rc;
   if (int rc = init_conv3d_bn(dc[1], dtype, sd, cr + "conv9.", 32, 16, 2, true)) return rc;
   if (int rc = init_conv3d_bn(dc[2], dtype, sd, cr + "conv11.", 16, 8, 2, true)) return rc;
+  if (norm_mode == 1) {
+    const char* nm[10] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"};
+    for (int i = 0; i < 10; ++i) {
+      const bool tr = i >= 7;
+      const int cin = tr ? (i == 7 ? 64 : i == 8 ? 32 : 16) : crc[i], cout = tr ? cin / 2 : crc[i + 1];
+      const std::string p = cr + nm[i] + ".";
+      GET(w, p + "conv.weight"); GET(gm, p + "bn.weight"); GET(bt, p + "bn.bias");
+      RGBM_REQUIRE(w->numel() == (long long)cout * cin * 27 && gm->numel() == cout && bt->numel() == cout, "weight shape " + p);
+      ConvGeom g;
+      g.Cin = cin; g.Cout = cout; g.KD = g.KH = g.KW = 3; g.sd = g.sh = g.sw = tr ? 2 : crs[i]; g.pd = g.ph = g.pw = 1;
+      g.transposed = tr; g.act = ACT_NONE;
+      ConvLayer& L = tr ? dc_raw[i - 7] : c3d_raw[i];
+      if (int rc = L.init(dtype, g, w->data, nullptr, nullptr, nullptr, cin, cout)) return rc;
+      if (upload_f32(gm->data, cout, &bn_gamma[i])) return -2;
+      if (upload_f32(bt->data, cout, &bn_beta[i])) return -2;
+    }
+  }
   {
     // halo-tiled versions of the same ten layers (conv3d_tile.hip)
     const char* nm[10] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"};
@@ -202,6 +220,9 @@ void AdaPose::destroy() {
   up1c.destroy(); up2c.destroy();
   for (auto& l : c3d) l.destroy();
   for (auto& l : dc) l.destroy();
+  for (auto& l : c3d_raw) l.destroy();
+  for (auto& l : dc_raw) l.destroy();
+  for (int i = 0; i < 10; ++i) { if (bn_gamma[i]) (void)hipFree(bn_gamma[i]); if (bn_beta[i]) (void)hipFree(bn_beta[i]); bn_gamma[i] = bn_beta[i] = nullptr; }
   inst.destroy();
   for (auto& l : nh) l.destroy();
   for (auto& l : npm) l.destroy();
@@ -218,7 +239,10 @@ void AdaPose::destroy() {
   for (int h = 0; h < 3; ++h) for (int l = 0; l < 3; ++l) { if (head_w[h][l]) (void)hipFree(head_w[h][l]); if (head_b[h][l]) (void)hipFree(head_b[h][l]); }
 }
 
-int AdaPose::chunk_views(int V) const { return V < max_chunk ? V : max_chunk; }
+int AdaPose::chunk_views(int V) const {
+  const int cap = norm_mode == 1 && max_chunk > 32 ? 32 : max_chunk;      // per-sample BN materialises the 32-channel volume (154 MB per view in fp32)
+  return V < cap ? V : cap;
+}
 
 // Shared by workspace_bytes() (base == nullptr) and forward(): identical allocation order => identical offsets.
 int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
@@ -274,7 +298,8 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   const int Vc = chunk_views(V);
   const int D = n_depth;
   const size_t vox = (size_t)D * S * S;
-  bf.vol = cost_impl >= 2 ? nullptr : A.alloc((size_t)Vc * vox * 32 * es);   // fused-warp conv0 never materialises it
+  bf.vol = (cost_impl >= 2 && norm_mode == 0) ? nullptr : A.alloc((size_t)Vc * vox * 32 * es);   // fused-warp conv0 never materialises it
+  bf.bn_scratch = norm_mode == 1 ? A.alloc(bn_scratch_bytes(Vc)) : nullptr;
   bf.c[0] = A.alloc((size_t)Vc * vox * 8 * es);
   bf.c[1] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
   bf.c[2] = A.alloc((size_t)Vc * (vox / 8) * 16 * es);
@@ -390,7 +415,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     }
     return launch_conv3d_tile(layer, dtype, d, s);
   };
-  for (int v0 = 0; cost_impl >= 1 && v0 < V; v0 += Vc0) {
+  for (int v0 = 0; norm_mode == 0 && cost_impl >= 1 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
     if (cost_impl == 1) {
       if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
@@ -420,6 +445,30 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;
     if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 1, s)) return rc;
   }
+  // norm_mode 1: every layer = un-normalised conv (generic implicit GEMM) -> per-view batch statistics -> normalise + ReLU (+ skip)
+  for (int v0 = 0; norm_mode == 1 && v0 < V; v0 += Vc0) {
+    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+    if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
+    auto layer = [&](int i, const void* in, void* out, const void* res, int Di, int Hi, int Wi, int C) -> int {
+      const ConvLayer& L = i >= 7 ? dc_raw[i - 7] : c3d_raw[i];
+      int Do, Ho, Wo;
+      L.out_dims(Di, Hi, Wi, Do, Ho, Wo);
+      if (int rc = L.run(in, out, Vc, Di, Hi, Wi, C, nullptr, RES_NONE, nullptr, 0, s)) return rc;
+      return launch_bn_per_sample(dtype, out, res, bn_gamma[i], bn_beta[i], bf.bn_scratch, Vc, (long long)Do * Ho * Wo, C, 1, s);
+    };
+    if (int rc = layer(0, bf.vol, bf.c[0], nullptr, D, S, S, 8)) return rc;
+    if (int rc = layer(1, bf.c[0], bf.c[1], nullptr, D, S, S, 16)) return rc;
+    if (int rc = layer(2, bf.c[1], bf.c[2], nullptr, D / 2, S / 2, S / 2, 16)) return rc;
+    if (int rc = layer(3, bf.c[2], bf.c[3], nullptr, D / 2, S / 2, S / 2, 32)) return rc;
+    if (int rc = layer(4, bf.c[3], bf.c[4], nullptr, D / 4, S / 4, S / 4, 32)) return rc;
+    if (int rc = layer(5, bf.c[4], bf.c[5], nullptr, D / 4, S / 4, S / 4, 64)) return rc;
+    if (int rc = layer(6, bf.c[5], bf.c[6], nullptr, D / 8, S / 8, S / 8, 64)) return rc;
+    if (int rc = layer(7, bf.c[6], bf.u7, bf.c[4], D / 8, S / 8, S / 8, 32)) return rc;
+    if (int rc = layer(8, bf.u7, bf.u9, bf.c[2], D / 4, S / 4, S / 4, 16)) return rc;
+    if (int rc = layer(9, bf.u9, bf.u11, bf.c[0], D / 2, S / 2, S / 2, 8)) return rc;
+    if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 0, s)) return rc;
+  }
+  if (norm_mode == 1) return 0;
   for (int v0 = 0; cost_impl == 0 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
     if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;

@@ -37,6 +37,12 @@ struct AdaPose {
   UpConvLayer up1c, up2c;       // up_1 / up_2 as a low-resolution 1x1 GEMM + tap combination (upconv.hip)
   int upconv = 3;               // bit 0: up_1, bit 1: up_2 through UpConvLayer (0 = x2 resize + 3x3 conv on the up-sampled grid, for A/B and tests)
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
+  // norm_mode 1 (per-sample BatchNorm3d: the as-shipped train-mode behaviour at batch 1): the same ten layers without
+  // BN / activation, their gamma / beta, and the in-place normalisation of bn_kernels.hip behind each of them
+  int norm_mode = 0;
+  ConvLayer c3d_raw[7], dc_raw[3];
+  float* bn_gamma[10] = {nullptr};
+  float* bn_beta[10] = {nullptr};
   struct Tile3d { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0; };
   Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11
   int igemm_conv6 = 1;          // bf16 + cost_impl 3: conv6 through the implicit-GEMM path instead of the halo-tile kernel
@@ -61,6 +67,7 @@ struct AdaPose {
     float *glob, *vbias, *pf2, *h1, *h2, *r6, *R, *tv, *sv;
     void *imgpad, *c1, *lb[4], *pooled[4], *stage[4], *cat, *ups, *u1, *u2, *u3;
     void *vol, *c[7], *u7, *u9, *u11;
+    void* bn_scratch;
   };
   struct Outputs {   // device fp32, reference shapes (network_v5.py:510-515)
     float *nocs1, *nocs2;   // [B,P,3]
@@ -69,7 +76,7 @@ struct AdaPose {
     float *t1, *t2, *s1, *s2;  // [B,3]
   };
 
-  int create(const StateDict& sd, int dtype);
+  int create(const StateDict& sd, int dtype, int norm_mode = 0);
   void destroy();
   size_t workspace_bytes(int B) const;
   int forward(int B, const float* img1, const float* img2, const int* choose1, const int* choose2, const float* P1,

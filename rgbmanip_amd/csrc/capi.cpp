@@ -25,7 +25,7 @@ const char* rgbm_last_error(void) { return last_error_cstr(); }
 int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* w, int n_w, int dtype, int norm_mode) {
   RGBM_REQUIRE(h != nullptr && w != nullptr && n_w > 0, "create arguments");
   RGBM_REQUIRE(dtype == RGBM_F32 || dtype == RGBM_BF16 || dtype == RGBM_F16 || dtype == RGBM_BF16X3, "dtype must be 0 (fp32), 1 (bf16), 2 (fp16) or 3 (bf16x3)");
-  RGBM_REQUIRE(norm_mode == 0, "only eval-mode (folded) BatchNorm is implemented");
+  RGBM_REQUIRE(norm_mode == 0 || norm_mode == 1, "norm_mode: 0 = eval-mode (folded) BatchNorm3d, 1 = per-sample statistics");
   RGBM_CHECK_HIP(hipSetDevice(device));
   StateDict sd;
   for (int i = 0; i < n_w; ++i) {
@@ -38,7 +38,7 @@ int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* 
   }
   rgbm_adapose* obj = new rgbm_adapose();
   obj->device = device;
-  int rc = obj->net.create(sd, dtype);
+  int rc = obj->net.create(sd, dtype, norm_mode);
   if (rc) { obj->net.destroy(); delete obj; return rc; }
   *h = obj;
   return 0;

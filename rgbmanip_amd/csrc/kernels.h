@@ -24,6 +24,11 @@ int launch_build_volume(int dtype, const void* feat, const float* homog, const f
 int launch_upconv_combine(int dtype, const void* z, const float* bias, void* out, int V, int h, int w, int Co, int ldo, int act,
                           float slope, hipStream_t s);
 
+// bn_kernels.hip — per-sample (train-mode, batch 1) BatchNorm3d + ReLU + skip add, in place on the un-normalised conv output
+size_t bn_scratch_bytes(int V);
+int launch_bn_per_sample(int dtype, void* y, const void* res, const float* gamma, const float* beta, void* scratch, int V,
+                         long long nvox, int C, int relu, hipStream_t s);
+
 int launch_to_f32(int dtype, const void* in, float* out, long long n, hipStream_t s);
 
 // head_kernels.hip

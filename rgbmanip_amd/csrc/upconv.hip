@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 template <typename T>
 int launch_t(const void* z, const float* bias, void* out, int V, int h, int w, int Co, int ldo, float nslope, float sy, float sx,
              hipStream_t s) {
-  constexpr int BR = 2, BC = 4, E = 4;
+#ifndef UPC_BC
+#define UPC_BC 4
+#endif
+  constexpr int BR = 2, BC = UPC_BC, E = 4;
   const long long total = (long long)V * ((2 * h + BR - 1) / BR) * ((2 * w + BC - 1) / BC) * (Co / E);
   RGBM_REQUIRE(total > 0 && total < (1ll << 31), "upconv combine grid out of range");
   RGBM_REQUIRE((2 * h) % BR == 0 && (2 * w) % BC == 0, "upconv combine: output size must be a multiple of the thread block shape");

@@ -115,7 +115,8 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 if logger is not None:
                     logger.warning("AdaPoseEstimator_v5: cfg.load is False -> synthetic (seeded) weights")
         self.dtype = dtype or cfg.get("hip_dtype", "bf16x3")      # the fastest mode inside north_star's 1e-4 (fp32: 4x slower, bf16: 2.4x faster at 1e-2)
-        self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device)
+        self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device,
+                                                                norm_mode=cfg.get("hip_norm_mode", "eval"))
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
         self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))

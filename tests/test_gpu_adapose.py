@@ -129,6 +129,20 @@ def test_bf16x3_matches_reference_golden(inputs, golden_dir):
         assert errs[k] < RTOL_FP32, (k, errs)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_per_sample_batchnorm_matches_reference_train_mode_golden(inputs, golden_dir, dtype):
+    """norm_mode = 1 (per-sample BatchNorm3d statistics: the reference as shipped, train mode at batch 1 with Dropout2d as identity)
+    against the reference's own outputs in that mode (tests/golden/adapose_b2_trainbn.npz), inside the fp32 gate — batched here
+    (B = 2), one pose per call there: every view is normalised with its own volume's statistics either way."""
+    g = np.load(os.path.join(golden_dir, "adapose_b2_trainbn.npz"))
+    out = _run(_net(dtype, norm_mode=1), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print(f"{dtype} norm_mode=1 vs reference train-mode golden:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all(), k
+        assert errs[k] < RTOL_FP32, (k, errs)
+
+
 def test_bf16x3_intermediates_vs_oracle(inputs, oracle_taps):
     """Stage taps of the split-pair mode against the oracle: every stage inside the fp32 gate."""
     _, taps = oracle_taps

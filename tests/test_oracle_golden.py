@@ -300,3 +300,22 @@ def test_ppo_run_restatement_matches_reference_run(golden_dir):
     assert np.abs(acts - g["actions"]).max() < 2e-6
     flat = torch.cat([p.reshape(-1) for p in sd.values()]).numpy()
     assert np.abs(flat - g["params_after"]).max() / np.abs(g["params_after"]).max() < 1e-5
+
+
+def test_oracle_per_sample_batchnorm_matches_reference_in_train_mode(golden_dir):
+    """norm_mode = 1 of the oracle against tests/golden/adapose_b2_trainbn.npz: the reference module in .train() with its Dropout2d
+    in .eval(), one pose per call (tools/make_goldens.py::gen_adapose_trainbn) — the as-shipped BatchNorm3d behaviour."""
+    import torch
+    from oracle import adapose_ref
+    from rgbmanip_amd import synth
+    g = np.load(os.path.join(golden_dir, "adapose_b2_trainbn.npz"))
+    sd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
+    inp = synth.adapose_inputs(2, seed=0)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    out = adapose_ref.adapose_forward(sd, t["img1"], t["choose1"], t["img2"], t["choose2"], t["P1"], t["P2"], t["depths"], norm_mode=1)
+    for k, v in out.items():
+        err = float(np.abs(v.numpy().astype(np.float64) - g[k]).max() / np.abs(g[k]).max())
+        assert err < 1e-5, (k, err)
+    # and it is a different function from the eval-mode network (depth moves by > 10 %)
+    g0 = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    assert np.abs(g["view1_depth"] - g0["view1_depth"]).max() / np.abs(g0["view1_depth"]).max() > 0.05

@@ -45,11 +45,15 @@ class Emu:
         self.q = q_f16 if fmt == "f16" else q_bf16
         self.ftz, self.xt, self.wt = ftz, x_terms, w_terms
         self.calls = 0
+        self.layer_terms = only            # {weight shape: (x_terms, w_terms)} for the layers that deviate from the default
 
     def op(self, fn, x, w, b, *a, **k):
         self.calls += 1
-        xh, xl = split(x, self.q, self.ftz, self.xt)
-        wh, wl = split(w, self.q, self.ftz, self.wt)
+        xt, wt = self.xt, self.wt
+        if self.layer_terms is not None and tuple(w.shape) in self.layer_terms:     # per-layer override, keyed by weight shape
+            xt, wt = self.layer_terms[tuple(w.shape)]
+        xh, xl = split(x, self.q, self.ftz, xt)
+        wh, wl = split(w, self.q, self.ftz, wt)
         y = fn(xh, wh, b, *a, **k)
         if xl is not None:
             y = y + fn(xl, wh, None, *a, **k)
@@ -102,6 +106,30 @@ MODES = {
     "bf16x3_2df16":    lambda: run("2-D f16 single term (x and w), 3-D bf16x3", Emu("f16", False, 1, 1), Emu("bf16")),
     "f16x3_2dx1":      lambda: run("2-D: x single-term w split, 3-D f16x3", Emu("f16", False, 1, 2), Emu("f16")),
 }
+
+# Round 3: per-layer term count — bf16 split pairs everywhere, TWO products (one operand single-term) only in
+# the layers of one group: layer4 = the five 512 -> 512 3x3 convs, layer3 = the eleven 256 -> 256 3x3 convs, up_1 = 1024 -> 256
+L4, L3, UP1 = (512, 512, 3, 3), (256, 256, 3, 3), (256, 1024, 3, 3)
+for nm, shp in (("layer4", L4), ("layer3", L3), ("up_1", UP1)):
+    MODES[f"bf16x3_{nm}_w1"] = (lambda shp=shp, nm=nm: run(f"bf16x3, {nm}: w single term (2 products)", Emu("bf16", only={shp: (2, 1)}), Emu("bf16")))
+    MODES[f"bf16x3_{nm}_x1"] = (lambda shp=shp, nm=nm: run(f"bf16x3, {nm}: x single term (2 products)", Emu("bf16", only={shp: (1, 2)}), Emu("bf16")))
+MODES["bf16x3_one_l4_w1"] = lambda: run("bf16x3, ONE layer4 conv (layer4.1.conv1): w single term", _OneCall("bf16", L4, (2, 1)), Emu("bf16"))
+
+
+class _OneCall(Emu):
+    """two products in the FIRST conv whose weight has the given shape only"""
+    def __init__(self, fmt, shape, terms):
+        super().__init__(fmt)
+        self.shape, self.terms, self.done = shape, terms, False
+
+    def op(self, fn, x, w, b, *a, **k):
+        if tuple(w.shape) == self.shape and not self.done:
+            self.done = True
+            self.layer_terms = {self.shape: self.terms}
+        else:
+            self.layer_terms = None
+        return super().op(fn, x, w, b, *a, **k)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
