@@ -97,6 +97,18 @@ int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, con
 int rgbm_adapose_postprocess_ransac(int B, int P, int img_size, uint32_t seed, const float* nocs1, const float* depth1,
                                     const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* srt,
                                     int32_t* valid, void* stream);
+/* Tail of AdaPoseEstimator_v5.predict for `direct_regression: False`, `use_depth: False` (interface_v5.py:340-346, lib/utils.py:121-195,
+ * lib/align.py:104-115): mutual NOCS matches of the two views -> epipolar gate -> DLT triangulation -> scale (median of pair ratios)
+ * -> EPnP-RANSAC (100 five-point hypotheses, reprojection error 3 px) on (nocs1 * scale, pixels of view 1) -> EPnP over the inliers
+ * -> VVS refinement over all points -> bbox in the world frame.  The OpenCV routines the reference calls are restated from their
+ * published algorithms; RANSAC subsets come from a seeded hash (pose b, iteration i, draw k: mix32(seed, 128 b + i, k) mod P, first
+ * five distinct).  nocs [B,P,3] f32; pts2d [B,P,2] f32 pixel coordinates in the ORIGINAL frame (prepare_model_input's view_pts2d);
+ * K [B,3,3] f64 original intrinsics; E1 / E2 [B,4,4] f64 world -> camera.  bbox_out [B,8,3] f64 (default bbox when no match / no
+ * consensus / non-finite); srt_out [B,13] f64 = scale, R (9), t (3); info_out [B,4] i32 = matches, RANSAC ok, inliers, hypotheses
+ * examined; valid_out [B] i32. */
+int rgbm_adapose_postprocess_pnp(int B, int P, uint32_t seed, const float* nocs1, const float* pts2d1, const float* nocs2,
+                                 const float* pts2d2, const double* K, const double* E1, const double* E2, double* bbox_out,
+                                 double* srt_out, int32_t* info_out, int32_t* valid_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Batched device-side input preparation.

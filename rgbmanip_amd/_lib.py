@@ -99,6 +99,7 @@ SIGNATURES = {
     "rgbm_adapose_fetch": (_i, [_vp, _i, _vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "rgbm_adapose_postprocess": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_adapose_postprocess_ransac": (_i, [_i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_adapose_postprocess_pnp": (_i, [_i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_gae": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "rgbm_adv_normalise": (_i, [_i64, _vp, _vp, _d, _vp]),
     "rgbm_policy_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -173,6 +173,27 @@ def postprocess_ransac(view1_nocs, view1_depth, view1_choose, K_crop, E1, img_si
     return bbox, srt, valid
 
 
+def postprocess_pnp(view1_nocs, view1_pts2d, view2_nocs, view2_pts2d, K, E1, E2, seed: int = 0, stream=None):
+    """Device tail of `predict` for `direct_regression: False`, `use_depth: False` (`interface_v5.py:340-346`, `lib/utils.py:121-195`,
+    `lib/align.py:104-115`): returns (bbox_world [B,8,3] f64, srt [B,13] f64 = scale, R, t, info [B,4] i32 = matches / RANSAC ok /
+    inliers / hypotheses examined, valid [B] i32) CUDA tensors.  pts2d: pixels of the chosen points in the ORIGINAL frame."""
+    lib = _lib.load()
+    dev = view1_nocs.device
+    B, P = view1_nocs.shape[:2]
+    f32 = lambda x: torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    f64 = lambda x: torch.as_tensor(x).to(device=dev, dtype=torch.float64).contiguous()  # noqa: E731
+    n1, p1, n2, p2 = f32(view1_nocs), f32(view1_pts2d), f32(view2_nocs), f32(view2_pts2d)
+    Kd, E1d, E2d = f64(K), f64(E1), f64(E2)
+    bbox = torch.empty(B, 8, 3, dtype=torch.float64, device=dev)
+    srt = torch.empty(B, 13, dtype=torch.float64, device=dev)
+    info = torch.empty(B, 4, dtype=torch.int32, device=dev)
+    valid = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.rgbm_adapose_postprocess_pnp(B, P, int(seed) & 0xFFFFFFFF, _lib.ptr(n1), _lib.ptr(p1), _lib.ptr(n2), _lib.ptr(p2),
+                                                _lib.ptr(Kd), _lib.ptr(E1d), _lib.ptr(E2d), _lib.ptr(bbox), _lib.ptr(srt), _lib.ptr(info),
+                                                _lib.ptr(valid), _lib.stream_ptr(stream)), "rgbm_adapose_postprocess_pnp")
+    return bbox, srt, info, valid
+
+
 def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None,
                    frame_map=None):
     """Batched device-side `AdaPoseEstimator_v5.prepare_model_input` (`interface_v5.py:58-170`).

@@ -308,6 +308,12 @@ extern "C" int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* 
                                Kcrop_out, window_out, valid_out, scratch, (hipStream_t)stream);
 }
 
+extern "C" int rgbm_adapose_postprocess_pnp(int B, int P, uint32_t seed, const float* nocs1, const float* pts2d1, const float* nocs2,
+                                            const float* pts2d2, const double* K, const double* E1, const double* E2, double* bbox_out,
+                                            double* srt_out, int32_t* info_out, int32_t* valid_out, void* stream) {
+  return launch_pnp_ransac(nocs1, pts2d1, nocs2, pts2d2, K, E1, E2, bbox_out, srt_out, info_out, valid_out, B, P, seed, (hipStream_t)stream);
+}
+
 extern "C" int rgbm_projection(const double* Kcrop_dev, const double* E_dev, float* P_dev, int N, void* stream) {
   return launch_projection(Kcrop_dev, E_dev, P_dev, N, (hipStream_t)stream);
 }

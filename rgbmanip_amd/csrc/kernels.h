@@ -87,6 +87,10 @@ int launch_umeyama_ransac(const float* nocs, const float* depth, const int* choo
                           double* bbox, double* srt, int* valid, int B, int P, int img, unsigned seed, hipStream_t s);
 
 int launch_projection(const double* Kc, const double* E, float* P, int n, hipStream_t s);      // prepare.hip
+// pnp.hip — the use_depth: False tail of predict (NOCS matches -> triangulation -> scale -> EPnP-RANSAC -> VVS -> world bbox)
+int launch_pnp_ransac(const float* nocs1, const float* pts1, const float* nocs2, const float* pts2, const double* K, const double* E1,
+                      const double* E2, double* bbox, double* srt, int* info, int* valid, int B, int P, unsigned seed, hipStream_t s);
+
 int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext, int* count, hipStream_t s);
 
 // postproc.hip

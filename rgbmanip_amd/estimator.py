@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .adapose import AdaPoseNet, postprocess, postprocess_ransac, prepare_inputs
+from .adapose import AdaPoseNet, postprocess, postprocess_pnp, postprocess_ransac, prepare_inputs
 
 DEFAULT_BBOX = np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]],
                           dtype=np.float64) + 10.0
@@ -101,9 +101,6 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
     def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0, net=None):
         """`net`: an already built `AdaPoseNet` to share (weights + workspace) instead of building one from `state_dict`."""
         super().__init__(env, cfg, logger)
-        if not cfg.get("direct_regression", True) and not cfg.get("use_depth", True):
-            raise NotImplementedError("direct_regression=False with use_depth=False is cv2.solvePnPRansac (interface_v5.py:340-346): "
-                                      "needs OpenCV, not provided")
         if net is not None:
             state_dict = {}
         elif state_dict is None:
@@ -171,6 +168,7 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                                         np.asarray(view2_extrinsic_batch)).cpu().numpy()
         out = np.repeat(DEFAULT_BBOX[None], n, axis=0)
         rows, img1, img2, ch1, ch2, P1, P2, K1, E1 = [], [], [], [], [], [], [], [], []
+        pt1, pt2, E2, K0 = [], [], [], []                    # the PnP branch also needs the pixels, the second extrinsic and the original K
         for i in range(n):
             self._frame = i
             if isinstance(self.rng, tuple):
@@ -189,13 +187,15 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             ch1.append(a[1]); ch2.append(b[1])
             P1.append(p1.astype(np.float32)); P2.append(p2.astype(np.float32))
             K1.append(a[3]); E1.append(np.asarray(view1_extrinsic_batch[i], dtype=np.float64))
+            pt1.append(a[2]); pt2.append(b[2]); E2.append(np.asarray(view2_extrinsic_batch[i], dtype=np.float64))
+            K0.append(np.asarray(camera_intrinsic_batch[i], dtype=np.float64))
         if not rows:
             return out
         B = len(rows)
         depths = np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (B, 1))
         ch1 = np.stack(ch1)
         pred = self.estimator(torch.stack(img1), ch1, torch.stack(img2), np.stack(ch2), np.stack(P1), np.stack(P2), depths)
-        bbox = self._bbox_tail(pred, ch1, np.stack(K1), np.stack(E1))
+        bbox = self._bbox_tail(pred, ch1, np.stack(K1), np.stack(E1), pts2d=(np.stack(pt1), np.stack(pt2)), E2=np.stack(E2), K=np.stack(K0))
         out[np.asarray(rows)] = bbox.cpu().numpy()
         return out
 
@@ -207,9 +207,10 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         S = self.cfg["img_size"]
         dev = self.estimator.device
         Kd = torch.as_tensor(K).to(dev)
-        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), Kd, S, 1024, self.prepare_seed)
-        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), Kd, S, 1024, self.prepare_seed + 1)
-        return self._estimate_prepared(a, b, E1, E2)
+        wp = self._pnp_branch()
+        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), Kd, S, 1024, self.prepare_seed, want_pts2d=wp)
+        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), Kd, S, 1024, self.prepare_seed + 1, want_pts2d=wp)
+        return self._estimate_prepared(a, b, E1, E2, Kd)
 
     def estimate_device_indexed(self, K, rgb_pool, mask_pool, E1, E2, map1, map2):
         """`estimate_device` reading the two views of sample i from entries map1[i] / map2[i] of a frame pool
@@ -217,11 +218,15 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         batches; a negative entry means "no such view" (the reference hands an all-zero frame over, which is skipped).
         K [N,3,3] (both views use it, interface_v5.py:213-227), E1 / E2 [N,4,4]."""
         S = self.cfg["img_size"]
-        a = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed, frame_map=map1)
-        b = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed + 1, frame_map=map2)
-        return self._estimate_prepared(a, b, E1, E2)
+        wp = self._pnp_branch()
+        a = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed, frame_map=map1, want_pts2d=wp)
+        b = prepare_inputs(rgb_pool, mask_pool, K, S, 1024, self.prepare_seed + 1, frame_map=map2, want_pts2d=wp)
+        return self._estimate_prepared(a, b, E1, E2, K)
 
-    def _estimate_prepared(self, a, b, E1, E2):
+    def _pnp_branch(self):
+        return not self.cfg.get("direct_regression", True) and not self.cfg.get("use_depth", True)
+
+    def _estimate_prepared(self, a, b, E1, E2, K=None):
         S = self.cfg["img_size"]
         dev = self.estimator.device
         E1d = torch.as_tensor(E1).to(device=dev, dtype=torch.float64)
@@ -235,18 +240,23 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             return P
         depths = torch.from_numpy(np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (n, 1))).to(dev)
         pred = self.estimator(a["img"], a["choose"], b["img"], b["choose"], proj(a["Kcrop"], E1d), proj(b["Kcrop"], E2d), depths)
-        bbox = self._bbox_tail(pred, a["choose"], a["Kcrop"], E1d)
+        bbox = self._bbox_tail(pred, a["choose"], a["Kcrop"], E1d, pts2d=(a.get("pts2d"), b.get("pts2d")), E2=E2d, K=K)
         ok = ((a["valid"] != 0) & (b["valid"] != 0)).view(n, 1, 1)
         return torch.where(ok, bbox, torch.from_numpy(DEFAULT_BBOX).to(dev).expand(n, 8, 3))
 
-    def _bbox_tail(self, pred, choose, Kcrop, E1):
+    def _bbox_tail(self, pred, choose, Kcrop, E1, pts2d=None, E2=None, K=None):
         """interface_v5.py:318-374: scale / translation from the regressed rotation (`direct_regression`, the shipped configs)
         or Umeyama-RANSAC between predicted NOCS and the back-projected predicted depth (`use_depth`), then the world box."""
         S = self.cfg["img_size"]
         if self.cfg.get("direct_regression", True):
             return postprocess(pred["view1_nocs"], pred["view1_depth"], pred["view1_r"], choose, Kcrop, E1, img_size=S)[0]
-        return postprocess_ransac(pred["view1_nocs"], pred["view1_depth"], choose, Kcrop, E1, img_size=S,
-                                  seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
+        if self.cfg.get("use_depth", True):
+            return postprocess_ransac(pred["view1_nocs"], pred["view1_depth"], choose, Kcrop, E1, img_size=S,
+                                      seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
+        # use_depth False (interface_v5.py:340-346): NOCS matches of the two views -> scale -> EPnP-RANSAC + VVS on the ORIGINAL
+        # intrinsics and the chosen points' pixels in the original frame
+        return postprocess_pnp(pred["view1_nocs"], pts2d[0], pred["view2_nocs"], pts2d[1], K, E1, E2,
+                               seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
 
     def predict(self, camera_intrinsic, rgb1, view1_mask, view1_extrinsic, rgb2, view2_mask, view2_extrinsic):
         return self.estimate([camera_intrinsic], [rgb1], [view1_mask], [view1_extrinsic], [rgb2], [view2_mask],

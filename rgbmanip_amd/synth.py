@@ -364,6 +364,53 @@ def align_case(case: int, P: int = 1024):
     return nocs, pts
 
 
+def pnp_case(case: int, P: int = 1024):
+    """Seeded two-view case for the `use_depth: False` (NOCS matches -> triangulation -> EPnP-RANSAC) branch of predict
+    (interface_v5.py:340-346): an object of scale s at pose (R_o, t_o) in the world, seen by two look-at cameras; per view the
+    predicted NOCS of P surface points (+ noise) and their pixels in the 480x640 frame.  View 2 re-observes most of view 1's
+    points (so that mutual nearest neighbours in NOCS space exist) in another order; a fraction of view 1's pixels are outliers.
+    case 3 has no common points (no match -> default bbox).  Returns a dict incl. the ground truth (scale, R, t) in camera 1."""
+    rng = np.random.default_rng(7300 + case)
+    dims = np.array([0.9, 0.5, 0.3], dtype=np.float32)
+    nocs = (rng.uniform(-0.5, 0.5, (P, 3)).astype(np.float32) * dims)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    s = float(rng.uniform(0.25, 0.5))
+    t_o = rng.uniform(-0.05, 0.05, 3) + np.array([0.0, 0.0, 0.4])
+    world = s * nocs.astype(np.float64) @ q.T + t_o
+    eye1 = t_o + np.array([0.75, 0.1, 0.25]) * rng.uniform(0.9, 1.1)
+    eye2 = eye1 + np.array([-0.1, 0.3, 0.05]) * rng.uniform(0.8, 1.2)
+    E1, E2 = _lookat_extrinsic(eye1, t_o), _lookat_extrinsic(eye2, t_o)
+    f = 240.0 / np.tan(0.5)
+    K = np.array([[f, 0, 320.0], [0, f, 240.0], [0, 0, 1.0]])
+
+    def project(E, X):
+        c = X @ E[:3, :3].T + E[:3, 3]
+        uv = c @ K.T
+        return uv[:, :2] / uv[:, 2:3]
+    noise = [0.0005, 0.001, 0.002, 0.001, 0.001][case % 5]
+    pix = [0.2, 0.4, 0.8, 0.4, 0.4][case % 5]
+    nocs1 = (nocs + rng.normal(0, noise, nocs.shape)).astype(np.float32)
+    pts1 = (project(E1, world) + rng.normal(0, pix, (P, 2))).astype(np.float32)
+    bad = rng.random(P) < [0.0, 0.1, 0.25, 0.1, 0.05][case % 5]
+    pts1[bad] = rng.uniform([100, 60], [540, 420], (int(bad.sum()), 2)).astype(np.float32)
+    perm = rng.permutation(P)
+    if case % 5 == 3:
+        nocs_b = (rng.uniform(-0.5, 0.5, (P, 3)).astype(np.float32) * dims) + np.float32(2.0)      # nothing in common with view 1
+        world_b = s * nocs_b.astype(np.float64) @ q.T + t_o
+    else:
+        nocs_b, world_b = nocs[perm], world[perm]
+        fresh = rng.random(P) < 0.3                      # 30 % of view 2 are other surface points
+        nocs_b = np.where(fresh[:, None], rng.uniform(-0.5, 0.5, (P, 3)).astype(np.float32) * dims, nocs_b).astype(np.float32)
+        world_b = np.where(fresh[:, None], s * nocs_b.astype(np.float64) @ q.T + t_o, world_b)
+    nocs2 = (nocs_b + rng.normal(0, noise, nocs_b.shape)).astype(np.float32)
+    pts2 = (project(E2, world_b) + rng.normal(0, pix, (P, 2))).astype(np.float32)
+    R_gt = E1[:3, :3] @ q
+    t_gt = E1[:3, :3] @ t_o + E1[:3, 3]
+    return dict(nocs1=nocs1, pts1=pts1, nocs2=nocs2, pts2=pts2, K=K, E1=E1, E2=E2, scale=s, R=R_gt, t=t_gt)
+
+
 # --------------------------------------------------------------------------- a deterministic vec env for PPO.run (SURVEY 8a-16)
 class StubVecEnv:
     """A closed-form stand-in for `MultiVecEnv` with the interface `PPO.run` uses (`reset`, `step`, `get_state`, `num_envs`, the three
