@@ -113,6 +113,7 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
   }
   if (int rc = init_conv2d(fin, dtype, sd, "img_extractor.final.weight", "img_extractor.final.bias", 64, 32, 1, 1, 0, 1, ACT_NONE, 0.f, 64)) return rc;
 
+
   const std::string cr = "cost_regularization.";
   const int crc[8] = {32, 8, 16, 16, 32, 32, 64, 64};
   const int crs[7] = {1, 2, 1, 2, 1, 2, 1};
@@ -237,6 +238,10 @@ void AdaPose::destroy() {
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
   for (int h = 0; h < 3; ++h) for (int l = 0; l < 3; ++l) { if (head_w[h][l]) (void)hipFree(head_w[h][l]); if (head_b[h][l]) (void)hipFree(head_b[h][l]); }
+}
+
+bool AdaPose::feat_f32_only() const {
+  return dtype == BF16X3 && cost_impl == 3 && sweep_w != nullptr && norm_mode == 0 && !(g_debug_flags & 4096);
 }
 
 int AdaPose::chunk_views(int V) const {
@@ -375,7 +380,9 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
   }
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
   // up_3 + final: one launch on the bf16 path (the 64-channel up_3 output then never reaches HBM: `u3` is not written)
-  if (int rc = up3.run_then_1x1(fin, bf.ups, bf.u3, 64, bf.feat, 32, V, 1, 8 * H, 8 * W, fuse_final != 0, nullptr, s)) return rc;
+  // bf16x3, default path: `final` writes the plain-fp32 feature map directly (no split-pair copy, no 6.6 GB conversion pass)
+  fin.out_plain_f32 = feat_f32_only();
+  if (int rc = up3.run_then_1x1(fin, bf.ups, bf.u3, 64, fin.out_plain_f32 ? (void*)bf.featf : bf.feat, 32, V, 1, 8 * H, 8 * W, fuse_final != 0, nullptr, s)) return rc;
   return 0;
 }
 
@@ -517,7 +524,8 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   const void* featg = bf.feat;
   int fdt = dtype;
   if (dtype == BF16X3) {
-    if (int rc = launch_bx3_to_f32(bf.feat, bf.featf, (long long)V * S * S * 32, s)) return rc;
+    if (!feat_f32_only())
+      if (int rc = launch_bx3_to_f32(bf.feat, bf.featf, (long long)V * S * S * 32, s)) return rc;
     featg = bf.featf; fdt = F32;
   }
   if (stop_after == 1) return 0;

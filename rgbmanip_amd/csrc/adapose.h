@@ -89,6 +89,9 @@ struct AdaPose {
   int pspnet(const Buffers& bf, int V, hipStream_t s) const;
   int cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const;
   int chunk_views(int V) const;
+  // bf16x3 on the default path: nothing reads the split-pair feature map (the sweep and the point heads gather from plain fp32), so
+  // `final` writes fp32 directly; the A/B paths (materialised volume, halo-tile conv0, per-sample BN) still want split pairs
+  bool feat_f32_only() const;
 };
 
 const char* last_error_cstr();

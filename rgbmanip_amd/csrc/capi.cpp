@@ -115,7 +115,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
   else if (nm == "u1") { src = bf.u1; cnt = V * (S / 4) * (S / 4) * 256; }
   else if (nm == "u2") { src = bf.u2; cnt = V * (S / 2) * (S / 2) * 64; }
   else if (nm == "u3") { src = bf.u3; cnt = V * S * S * 64; }
-  else if (nm == "feat") { src = bf.feat; cnt = V * S * S * 32; }
+  else if (nm == "feat") { src = bf.feat; cnt = V * S * S * 32; if (n.feat_f32_only()) { src = bf.featf; dt = F32; } }
   else if (nm == "vol") { src = bf.vol; cnt = Vc * D * S * S * 32; }
   else if (nm == "c0") { src = bf.c[0]; cnt = Vc * D * S * S * 8; }
   else if (nm == "c2") { src = bf.c[2]; cnt = Vc * (D / 2) * (S / 2) * (S / 2) * 16; }

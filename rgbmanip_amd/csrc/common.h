@@ -241,6 +241,7 @@ struct ConvDesc {
   // `out` is not written.  w2: [cout2_pad][kpad2] K-major bf16 rows of 64 input channels.
   const void* w2; const float* bias2; void* out2; int ldo2, cout2, kpad2, act2; float slope2;
   double algo_flops, algo_bytes;          // algorithmic work of this launch (profiling only)
+  int out_f32;                            // bf16x3 tensors, generic kernel only: write the result as PLAIN fp32 (same 4-byte slots) instead of split pairs
 };
 
 int launch_conv(const ConvDesc& d, int dtype, hipStream_t s);

@@ -335,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += rv[e];
       }
+      if constexpr (std::is_same<T, bx3_t>::value) {
+        // plain fp32 into the same 4-byte slots: the feature map the plane sweep and the point heads gather from
+        if (d.out_f32) { store4(reinterpret_cast<float*>(d.out) + o, v); continue; }
+      }
       store4(out + o, v);
     }
   }
@@ -2158,6 +2162,10 @@ static int launch_t_g(const ConvDesc& d, hipStream_t s) {
 template <typename T>
 static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   const bool uni = conv_uniform_taps(d, 8 * (16 / (int)sizeof(T))) && !(g_debug_flags & 16);
+  if (d.out_f32) {      // only the generic tile's epilogue knows the plain-fp32 output form
+    RGBM_REQUIRE((std::is_same<T, bx3_t>::value) && d.w2 == nullptr, "out_f32 is a bf16x3 option of the generic kernel");
+    return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
+  }
   // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
     // role-specialised (uniform taps, 16-byte aligned output / residual rows)

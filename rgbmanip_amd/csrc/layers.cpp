@@ -212,6 +212,7 @@ int ConvLayer::build_desc(ConvDesc& d, const void* in, void* out, int N, int Di,
   d.Cout = Cout_pad; d.ldo = ldo;
   d.Do = Do; d.Ho = Ho; d.Wo = Wo;
   d.act = g.act; d.slope = g.slope; d.res_mode = res ? res_mode : RES_NONE;
+  d.out_f32 = (out_plain_f32 && dtype == BF16X3) ? 1 : 0;
   const PackedConv& pc = packs[cls];
   d.wgt = pc.w;
   d.KD = pc.KD; d.KH = pc.KH; d.KW = pc.KW;

@@ -41,6 +41,7 @@ struct ConvLayer {
   float* bias = nullptr;         // [Cout_pad] fp32 or null
   std::vector<PackedConv> packs; // 1, or 8 for transposed
   std::vector<void*> owned;      // device allocations to free
+  mutable bool out_plain_f32 = false;    // (set per run by the owner) bf16x3 layers only: the output tensor is plain fp32 (for what gathers from it), see ConvDesc::out_f32
 
   // weights: [Cout][Cin][KD][KH][KW] (or [Cin][Cout][3][3][3] when transposed), optional per-Cout scale/shift
   // (folded BN) and bias.  Cin_pad: physical channel count of the input tensor.
