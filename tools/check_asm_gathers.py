@@ -54,6 +54,16 @@ def check(asm_text):
             l = body[i].strip()
             if l.startswith('v_mov') and any(regs(o) & dest for o in l.split()[1:]):
                 findings.append(f"{name[:50]}: line {i}: {l}")
+        # (round 3) no data-dependent control flow inside the plane loop: a wave-uniform branch around the blend (skip the arithmetic of
+        # a wave whose voxels all project outside the partner image) brought the run-to-run corruption back in a build-dependent
+        # way — one build re-homed gather registers at the join (caught above), another passed every register check and still
+        # produced wrong voxels until every counted wait was replaced by vmcnt(0).  Only the loop's back edge and EXEC-mask skips
+        # (s_cbranch_execz / execnz around `if (active lane)`) may branch here.
+        for i in range(x, y):
+            l = body[i].strip()
+            m = re.match(r's_cbranch_(?:vcc|scc)\w*\s+(\.LBB\d+_\d+)', l)
+            if m and x < labels.get(m.group(1), -1) <= y:          # target inside the loop and not its header: not the loop control
+                findings.append(f"{name[:50]}: line {i}: data-dependent branch inside the producers' plane loop: {l}")
         # prologue gathers: the 16 / 32 requests in front of the loop (the last saddr gathers before it)
         before = [l.split()[1].rstrip(',') for l in body[max(0, x - 400):x] if is_gather(l)]
         pro = [t for t in before if regs(t) & dest]
