@@ -264,6 +264,12 @@ int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N, int D, int
  * of `dtype`), then the tap-combining kernel.  in_dev [V][h][w][Cin], w_host [Cout][Cin][3][3], out_dev [V][2h][2w][Cout]. */
 int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, int Cin, const float* w_host, int Cout,
                           const float* bias_host, int act, float slope, void* z_scratch_dev, void* out_dev, void* stream);
+/* The PSPNet tail as the 16-bit / split-pair network runs it: up_3 (PSPUpsample 64 -> 64, PReLU `slope`) and `final`
+ * (pspnet.py:136, Conv2d 1x1 64 -> 32 + bias) in one kernel (upconv_final.hip).  in_dev [V][h][w][64] (h, w multiples of 8),
+ * w3_host [64][64][3][3], b3_host [64], wf_host [32][64], bf_host [32]; out_dev [V][2h][2w][32] in `dtype`, or plain fp32 when
+ * out_f32 (RGBM_BF16X3 only).  dtype RGBM_BF16 / RGBM_F16 / RGBM_BF16X3. */
+int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int w, const float* w3_host, const float* b3_host,
+                                float slope, const float* wf_host, const float* bf_host, void* out_dev, int out_f32, void* stream);
 int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream);
 int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
                             void* stream);
@@ -305,7 +311,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  26..29 bf16x3: generic implicit GEMM, 3-D layers, conv0 + plane sweep, ws 128 x 256 tile
  *  30     conv_igemm_w256_kernel (experimental)      31 / 32  ws 256 x 128 tile 16-bit / its row-halo variant
  *  33     ws 256 x 128 tile bf16x3                   34 / 35 / 36  ws 64 x 256 four-multiply-wave tile bf16x3 / 16-bit / f32
- *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  unused
+ *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  upconv_final_kernel
  * stop synchronises on the recorded events. */
 #define RGBM_PROF_ROWS 40
 /* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):

@@ -112,6 +112,11 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
     }
   }
   if (int rc = init_conv2d(fin, dtype, sd, "img_extractor.final.weight", "img_extractor.final.bias", 64, 32, 1, 1, 0, 1, ACT_NONE, 0.f, 64)) return rc;
+  if (dtype != F32) {
+    GET(w3, "img_extractor.up_3.conv.0.weight"); GET(b3, "img_extractor.up_3.conv.0.bias"); GET(s3, "img_extractor.up_3.conv.1.weight");
+    GET(wf, "img_extractor.final.weight"); GET(bfin, "img_extractor.final.bias");
+    if (int rc = tail.init(dtype, w3->data, b3->data, s3->data[0], wf->data, bfin->data)) return rc;
+  }
 
 
   const std::string cr = "cost_regularization.";
@@ -218,7 +223,7 @@ void AdaPose::destroy() {
   for (int i = 0; i < n_blocks; ++i) { blocks[i].c1.destroy(); blocks[i].c2.destroy(); if (blocks[i].has_ds) blocks[i].ds.destroy(); }
   for (auto& l : psp) l.destroy();
   up1.destroy(); up2.destroy(); up3.destroy(); fin.destroy();
-  up1c.destroy(); up2c.destroy();
+  up1c.destroy(); up2c.destroy(); tail.destroy();
   for (auto& l : c3d) l.destroy();
   for (auto& l : dc) l.destroy();
   for (auto& l : c3d_raw) l.destroy();
@@ -378,6 +383,9 @@ int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
     if (int rc = launch_resize_bilinear_ac(dtype, bf.u1, bf.ups, V, 2 * H, 2 * W, 256, 4 * H, 4 * W, 256, 0, s)) return rc;
     if (int rc = up2.run(bf.ups, bf.u2, V, 1, 4 * H, 4 * W, 64, nullptr, 0, nullptr, 0, s)) return rc;
   }
+  fin.out_plain_f32 = feat_f32_only();
+  if ((upconv & 4) && tail.ready())       // up_3 + final from the half-resolution tensor in one kernel: no up-sampled tensor, no z, no u3
+    return tail.run(bf.u2, fin.out_plain_f32 ? (void*)bf.featf : bf.feat, fin.out_plain_f32, V, 4 * H, 4 * W, s);
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
   // up_3 + final: one launch on the bf16 path (the 64-channel up_3 output then never reaches HBM: `u3` is not written)
   // bf16x3, default path: `final` writes the plain-fp32 feature map directly (no split-pair copy, no 6.6 GB conversion pass)

@@ -64,7 +64,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "igemm_conv6") { RGBM_REQUIRE(value == 0 || value == 1, "igemm_conv6"); h->net.igemm_conv6 = value; }
   else if (k == "fuse_final") { RGBM_REQUIRE(value == 0 || value == 1, "fuse_final"); h->net.fuse_final = value; }
   else if (k == "sparse_tail") { RGBM_REQUIRE(value == 0 || value == 1, "sparse_tail"); h->net.sparse_tail = value; }
-  else if (k == "upconv") { RGBM_REQUIRE(value >= 0 && value <= 3, "upconv"); h->net.upconv = value; }
+  else if (k == "upconv") { RGBM_REQUIRE(value >= 0 && value <= 7, "upconv"); h->net.upconv = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   return 0;
@@ -182,6 +182,17 @@ int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, in
   UpConvLayer L;
   int rc = L.init(dtype, Cin, Cout, w_host, bias_host, act, slope);
   if (!rc) rc = L.run(in_dev, z_scratch_dev, out_dev, V, h, w, Cout, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  L.destroy();
+  return rc;
+}
+
+int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int w, const float* w3_host, const float* b3_host,
+                                float slope, const float* wf_host, const float* bf_host, void* out_dev, int out_f32, void* stream) {
+  RGBM_REQUIRE(in_dev && w3_host && b3_host && wf_host && bf_host && out_dev, "upsample_conv3x3_final arguments");
+  UpConvFinal L;
+  int rc = L.init(dtype, w3_host, b3_host, slope, wf_host, bf_host);
+  if (!rc) rc = L.run(in_dev, out_dev, out_f32 != 0, V, h, w, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   L.destroy();
   return rc;

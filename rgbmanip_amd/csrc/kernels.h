@@ -23,6 +23,9 @@ int launch_build_volume(int dtype, const void* feat, const float* homog, const f
 // z [V][h][w][9*Co] (tap-major) -> out [V][2h][2w][ldo] = act(bias + sum_t bilinear(z_t)(p + t))
 int launch_upconv_combine(int dtype, const void* z, const float* bias, void* out, int V, int h, int w, int Co, int ldo, int act,
                           float slope, hipStream_t s);
+// up_3 + final of the PSPNet tail in one kernel (upconv_final.hip): x [V][h][w][64] -> out [V][2h][2w][32]
+int launch_upconv_final(int dtype, const void* x, const void* wz, const float* bias, float slope, const void* wf, const float* biasf,
+                        void* out, int out_f32, int V, int h, int w, hipStream_t s);
 
 // bn_kernels.hip — per-sample (train-mode, batch 1) BatchNorm3d + ReLU + skip add, in place on the un-normalised conv output
 size_t bn_scratch_bytes(int V);

@@ -301,4 +301,29 @@ int UpConvLayer::run(const void* in, void* z, void* out, int V, int h, int w, in
   return launch_upconv_combine(gemm.dtype, z, bias, out, V, h, w, Cout, ldo, act, slope, s);
 }
 
+int UpConvFinal::init(int dtype_, const float* w3, const float* b3, float slope_, const float* wfin, const float* bfin) {
+  RGBM_REQUIRE(dtype_ == BF16 || dtype_ == F16 || dtype_ == BF16X3, "upconv + final: 16-bit or split-pair storage");
+  dtype = dtype_; slope = slope_;
+  std::vector<float> z((size_t)9 * 64 * 64), f(wfin, wfin + 32 * 64);
+  for (int t = 0; t < 9; ++t)
+    for (int o = 0; o < 64; ++o)
+      for (int c = 0; c < 64; ++c) z[((size_t)t * 64 + o) * 64 + c] = w3[((size_t)o * 64 + c) * 9 + t];
+  if (int rc = upload_packed(z, dtype, &wz)) return rc;
+  if (int rc = upload_packed(f, dtype, &wf)) return rc;
+  if (upload_f32(b3, 64, &bias) || upload_f32(bfin, 32, &biasf)) return -2;
+  return 0;
+}
+
+void UpConvFinal::destroy() {
+  if (wz) (void)hipFree(wz);
+  if (wf) (void)hipFree(wf);
+  if (bias) (void)hipFree(bias);
+  if (biasf) (void)hipFree(biasf);
+  wz = wf = nullptr; bias = biasf = nullptr;
+}
+
+int UpConvFinal::run(const void* in, void* out, bool out_f32, int V, int h, int w, hipStream_t s) const {
+  return launch_upconv_final(dtype, in, wz, bias, slope, wf, biasf, out, out_f32 ? 1 : 0, V, h, w, s);
+}
+
 }  // namespace rgbm

@@ -77,6 +77,23 @@ struct UpConvLayer {
   int run(const void* in, void* z, void* out, int V, int h, int w, int ldo, hipStream_t s) const;
 };
 
+// PSPNet tail: up_3 (x2 bilinear -> conv3x3 64 -> 64 + bias -> PReLU) and `final` (conv1x1 64 -> 32 + bias) in ONE kernel
+// (upconv_final.hip): neither the up-sampled tensor, nor the tap-stacked z, nor up_3's output reach memory.  16-bit / split pairs.
+struct UpConvFinal {
+  void* wz = nullptr;            // [9 * 64][64] storage type, rows in (tap, channel) order
+  void* wf = nullptr;            // [32][64] storage type
+  float* bias = nullptr;         // [64] up_3 bias
+  float* biasf = nullptr;        // [32] final bias
+  float slope = 0.f;
+  int dtype = 0;
+  bool ready() const { return wz != nullptr; }
+  // w3 [64][64][3][3], b3 [64], wfin [32][64], bfin [32] (nn.Conv2d layouts)
+  int init(int dtype, const float* w3, const float* b3, float slope, const float* wfin, const float* bfin);
+  void destroy();
+  // in [V][h][w][64] -> out [V][2h][2w][32] (storage type, or plain fp32 when out_f32: split-pair path only)
+  int run(const void* in, void* out, bool out_f32, int V, int h, int w, hipStream_t s) const;
+};
+
 // device upload helpers
 int upload_packed(const std::vector<float>& w, int dtype, void** dev);      // host fp32 -> device array in storage type dtype
 int upload_f32(const float* host, size_t n, float** dev);

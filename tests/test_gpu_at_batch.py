@@ -125,12 +125,14 @@ def test_16bit_batch256_vs_oracle(inputs256, oracle256, dtype, gate):
         assert errs[k] < gate[k.split("_")[1]], (k, errs)
 
 
+@pytest.mark.parametrize("upconv", [3, 7])
 @pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
-def test_upconv_path_equals_resize_then_conv_at_batch(inputs256, dtype):
-    """up_1 / up_2 as low-resolution 1x1 GEMM + tap combination (the default) against the x2 resize + 3x3 conv on the up-sampled
-    grid (option upconv = 0) at B = 64: the same function in a different summation order."""
+def test_upconv_path_equals_resize_then_conv_at_batch(inputs256, dtype, upconv):
+    """up_1 / up_2 as low-resolution 1x1 GEMM + tap combination (upconv = 3), and additionally up_3 + final in the one-kernel
+    tail of upconv_final.hip (upconv = 7), against the x2 resize + 3x3 conv on the up-sampled grid (option upconv = 0) at
+    B = 64: the same function in a different summation order."""
     args = _dev_inputs(inputs256, 64)
-    a = {k: v.cpu().numpy() for k, v in _forward(_net(dtype), args).items()}
+    a = {k: v.cpu().numpy() for k, v in _forward(_net(dtype, options={"upconv": upconv}), args).items()}
     b = {k: v.cpu().numpy() for k, v in _forward(_net(dtype, options={"upconv": 0}), args).items()}
     tol = RTOL_FP32 if dtype == "bf16x3" else None
     for k in OUT_KEYS:

@@ -645,6 +645,70 @@ def test_upsample_conv3x3_commuted(case, dtype):
     assert err < tol, (name, dtype, err)
 
 
+TAIL_CASES = [("tail_one_tile", 1, 8, 8), ("tail_rect", 2, 8, 24), ("tail_multi", 3, 32, 16)]
+
+
+@pytest.mark.parametrize("dtype", [d for d in DTYPES if d != _lib.F32])
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_upsample_conv3x3_final_fused(case, dtype):
+    """rgbm_upsample_conv3x3_final (upconv_final.hip: up_3 + `final` of the PSPNet tail in one kernel, pspnet.py:100-107 and :136)
+    against interpolate -> conv3x3 + bias -> PReLU -> conv1x1 + bias on the CPU, operands rounded to the storage type; for
+    split pairs also the plain-fp32 output the sweep kernel reads."""
+    from gpu_util import to_channels_last, from_channels_last, rel_err, empty_out, host_f32
+    name, V, h, w = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    x = _q(torch.randn(V, 64, h, w, generator=g), dtype)
+    w3 = _q(torch.randn(64, 64, 3, 3, generator=g) / 24.0, dtype)
+    b3 = torch.randn(64, generator=g) * 0.1
+    wf = _q(torch.randn(32, 64, generator=g) / 8.0, dtype)
+    bfin = torch.randn(32, generator=g) * 0.1
+    slope = 0.25
+    y = F.prelu(F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), w3, b3, 1, 1), torch.tensor([slope]))
+    ref = F.conv2d(y, wf.view(32, 64, 1, 1), bfin)
+    xd = to_channels_last(x, dtype)
+    (_, w3p), (_, b3p), (_, wfp), (_, bfp) = keep = [host_f32(t) for t in (w3, b3, wf, bfin)]
+    # y is rounded to the storage type before the 1x1 (it is that kernel's matrix operand)
+    tol = {_lib.BF16: 2.5e-2, _lib.F16: 4e-3, _lib.BF16X3: 4e-5}[dtype]
+    for out_f32 in ((0, 1) if dtype == _lib.BF16X3 else (0,)):
+        out = torch.zeros(V, 2 * h, 2 * w, 32, dtype=torch.float32, device="cuda") if out_f32 else empty_out((V, 2 * h, 2 * w, 32), dtype)
+        torch.cuda.synchronize()
+        _lib.check(lib.rgbm_upsample_conv3x3_final(dtype, _lib.ptr(xd), V, h, w, w3p, b3p, slope, wfp, bfp, _lib.ptr(out), out_f32,
+                                                   _lib.stream_ptr()), "rgbm_upsample_conv3x3_final")
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2) if out_f32 else from_channels_last(out, 32)
+        assert torch.isfinite(got).all()
+        err = rel_err(got, ref)
+        print(name, dtype, out_f32, "fused tail rel err", err)
+        assert err < tol, (name, dtype, out_f32, err)
+
+
+def test_upsample_conv3x3_final_borders_fp16():
+    """Zero padding on the up-sampled grid and the clamped halo of border tiles: a single-tap identity up_3 kernel and an identity
+    `final` on a smooth ramp must reproduce the shifted up-sampled image at every border (fp16: the ramp is exact in it)."""
+    from gpu_util import to_channels_last, from_channels_last, empty_out, host_f32
+    lib = _lib.load()
+    V, h, w = 1, 16, 8
+    base = (torch.arange(h * w, dtype=torch.float32).view(1, 1, h, w) % 61) * 0.0625
+    x = base + torch.arange(64, dtype=torch.float32).view(1, 64, 1, 1) * 0.03125
+    x = x.half().float()
+    wf = torch.zeros(32, 64)
+    wf[:, :32] = torch.eye(32)
+    for t in range(9):
+        w3 = torch.zeros(64, 64, 3, 3)
+        w3[:, :, t // 3, t % 3] = torch.eye(64)
+        ref = F.conv2d(F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), w3, None, 1, 1),
+                       wf.view(32, 64, 1, 1))
+        xd = to_channels_last(x, _lib.F16)
+        out = empty_out((V, 2 * h, 2 * w, 32), _lib.F16)
+        (_, w3p), (_, b3p), (_, wfp), (_, bfp) = keep = [host_f32(a) for a in (w3, torch.zeros(64), wf, torch.zeros(32))]
+        _lib.check(lib.rgbm_upsample_conv3x3_final(_lib.F16, _lib.ptr(xd), V, h, w, w3p, b3p, 1.0, wfp, bfp, _lib.ptr(out), 0,
+                                                   _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got = from_channels_last(out, 32)
+        assert float((got - ref).abs().max()) < 6e-3, (t, float((got - ref).abs().max()))
+
+
 def test_upsample_conv3x3_zero_padding_and_edges():
     """The conv's zero padding lives on the UP-SAMPLED grid: a constant input with a single-tap kernel makes every border output
     that reaches outside lose exactly that tap (fp32, exact reference)."""
