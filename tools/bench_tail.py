@@ -38,3 +38,4 @@ for it in range(6):
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 print(os.environ.get("RGBM_HIP_LIB", "default"), sys.argv[1:], "ms:", " ".join(f"{t:.3f}" for t in ts), flush=True)
+
