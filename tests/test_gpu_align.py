@@ -90,5 +90,4 @@ def test_estimator_ransac_branch_end_to_end():
         want, _ = ar.bbox_world_ransac(pred["view1_nocs"][b].cpu().numpy(), pred["view1_depth"][b].cpu().numpy(), inp["choose1"][b],
                                        inp["K1"][b], inp["E1"][b], 224, ar.hash_sampler(5, b))
         np.testing.assert_allclose(got[b], want, rtol=0, atol=1e-8)
-    with pytest.raises(NotImplementedError):
-        AdaPoseEstimator_v5(None, dict(cfg, use_depth=False), None, state_dict={}, dtype="fp32")
+    # (`use_depth: False`, the PnP branch, is covered by tests/test_pnp.py)
