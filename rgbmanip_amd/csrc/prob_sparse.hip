@@ -9,9 +9,17 @@
 // One wave per chosen pixel.  The transposed conv is computed per output-parity class exactly like the halo-tile kernel
 // (conv3d_tile.hip, TR mode: 8 classes with 1..8 taps, two taps of 16 channels per 16x16x32 MFMA step, the same packed
 // weight fragments), but its B operand is gathered straight from u9 instead of a staged halo: lane (voxel, k-group) loads
-// the 16-byte half voxel its MFMA lane needs.  A class has 12, 24 or 48 neighbourhood voxels = 1..3 fragments.  The
-// 3 x 3 x D neighbourhood of u11 is kept in LDS in fp32 (never rounded to bf16, never written to HBM), then 24 lanes run
-// the 27-tap prob conv, and the wave reduces softmax and depth.
+// the 16-byte half voxel its MFMA lane needs.  A class has 12, 24 or 48 neighbourhood voxels = 1..3 fragments.  u11 itself
+// is never stored: the prob conv has ONE output channel, so a neighbourhood voxel (z, kh, kw) contributes to at most three
+// logits (z - 1, z, z + 1) through the channel dot products q_kd = sum_c wprob[kd][kh][kw][c] * u11[c]; the lanes that hold
+// the voxel's fp32 channels form those three numbers (12 FMAs + one cross-lane add) and only they go to LDS (3 x 9 x D
+// floats per wave instead of the 6.9 KB neighbourhood).  Then lane z adds its 27 partial sums in a fixed order, and the wave
+// reduces softmax and depth.
+//
+// What bounds it (round 3): the instruction stream.  About 2500 VALU + 1000 SALU instructions per point (index arithmetic and
+// bounds of every gather, the epilogue of every fragment), 512 points per SIMD: 2.9 ms whether 5 or 8 waves per SIMD are
+// resident and whichever XCD a point lands on.  A variant with the point's coordinates forced into SGPRs (readfirstlane),
+// buffer loads with out-of-range offsets instead of selects and branch-free index arithmetic measured 3.2 ms — not kept.
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -49,9 +57,9 @@ constexpr int PS_W11_OPS = 14 * 16 * 4;      // 16-byte weight operands of conv1
 }  // namespace
 
 template <typename T>
-__global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d) {
-  __shared__ __attribute__((aligned(16))) float U[4][PS_DMAX * 9 * 8];      // u11 on the 3x3xD neighbourhood, per wave
-  __shared__ float wp[27 * 8];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 6 : 5, 8))) void prob_sparse_kernel(const ProbSparseDesc d) {
+  __shared__ __attribute__((aligned(16))) float Q[4][PS_DMAX * 9 * 4];      // q_kd (kd = 0..2, one pad float) of the 3x3xD neighbourhood, per wave
+  __shared__ __attribute__((aligned(16))) float wp[27 * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   for (int i = tid; i < 27 * 8; i += 256) wp[i] = d.wprob[i];
@@ -63,9 +71,9 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
   const long long o = (long long)v * d.P + (pidx - (long long)vl * d.P);
   const int pix = active ? d.choose[o] : 0;
   const int y = pix / W, x = pix - y * W;
-  float* Uw = U[wave];
-  for (int i = lane * 4; i < D * 72; i += 256)                          // neighbours outside the image / volume: zero padding
-    *reinterpret_cast<f32x4*>(Uw + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* Qw = Q[wave];
+  for (int i = lane * 4; i < D * 36; i += 256)                          // neighbours outside the image / volume: zero padding
+    *reinterpret_cast<f32x4*>(Qw + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   constexpr bool X3 = std::is_same<T, bx3_t>::value;      // split pairs: 8 channels = two 16-byte chunks {hi, lo}, three products
@@ -134,15 +142,22 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc = mma16<T>(wq[((S0 + s) * 16 + lr) * 4 + lg], bv[s], acc);
       }
-      if (wr) {
-        f32x4 r;
+      {
+        // u11 channels ch..ch+3 of the lane's voxel -> their share of the three channel dot products; the other half of the
+        // channels sits 16 lanes away (lg ^ 1).  Lanes without a voxel (wr false) take part in the exchange with zeros.
+        const int col = wr ? (yy - y + 1) * 3 + (xx - x + 1) : 0;
+        float q[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[e] + d.bias11[ch + e];
           t = t < 0.f ? 0.f : t;                                        // NaN propagates, like torch.relu
-          r[e] = cv[e] + t;                                             // skip add is post-ReLU (network_v5.py:289)
+          const float u = cv[e] + t;                                    // skip add is post-ReLU (network_v5.py:289)
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) q[kd] = fmaf(u, wp[(kd * 9 + col) * 8 + ch + e], q[kd]);
         }
-        *reinterpret_cast<f32x4*>(Uw + ((oz * 3 + (yy - y + 1)) * 3 + (xx - x + 1)) * 8 + ch) = r;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) q[kd] += __shfl_xor(q[kd], 16);  // channels 0..3 + channels 4..7 (same order in both lanes)
+        if (wr && lg == 0) *reinterpret_cast<f32x4*>(Qw + (oz * 9 + col) * 4) = f32x4{q[0], q[1], q[2], 0.f};
       }
     }
   };
@@ -150,27 +165,18 @@ __global__ __launch_bounds__(256) void prob_sparse_kernel(const ProbSparseDesc d
   run_class(PC<4>{}); run_class(PC<5>{}); run_class(PC<6>{}); run_class(PC<7>{});
   __syncthreads();
 
-  // ---- prob conv at the D depths of this pixel (lane = depth), then softmax and depth regression across the wave ----
-  // lanes 0..D-1 take the first half of every tap plane's 72 values, lanes 32..32+D-1 the second half; one shuffle adds them
+  // ---- logits at the D depths of this pixel (lane = depth): 27 partial sums in a fixed order, then softmax and depth
+  // regression across the wave ----
   float logit = -INFINITY;
-  {
-    const int dz = lane & 31, half = lane >> 5;
+  if (lane < D) {
     float acc = 0.f;
-    if (dz < D) {
-      for (int kd = 0; kd < 3; ++kd) {
-        const int zz = dz + kd - 1;
-        if ((unsigned)zz >= (unsigned)D) continue;
-        const float* up = Uw + zz * 72 + half * 36;
-        const float* ww = wp + kd * 72 + half * 36;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int zz = lane + kd - 1;
+      if ((unsigned)zz >= (unsigned)D) continue;
 #pragma unroll
-        for (int i = 0; i < 36; i += 4) {
-          const f32x4 u = *reinterpret_cast<const f32x4*>(up + i);
-          acc += u[0] * ww[i] + u[1] * ww[i + 1] + u[2] * ww[i + 2] + u[3] * ww[i + 3];
-        }
-      }
+      for (int j = 0; j < 9; ++j) acc += Qw[(zz * 9 + j) * 4 + kd];
     }
-    acc += __shfl_xor(acc, 32);
-    if (lane < D) logit = acc;
+    logit = acc;
   }
   float m = logit;
 #pragma unroll
