@@ -302,23 +302,44 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
         }
       }
     } else {
-    if (!(d.dbg & 2))
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      int so;
-      bool pad;
-      step_off(s, so, pad);
-      uint4 af[FM];
-#pragma unroll
-      for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
+    if (!(d.dbg & 2)) {
+      // B operands of step s + 1 are read from LDS before the MFMAs of step s (two register sets).  Left alone hipcc emitted
+      // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma for every single MFMA, re-using one register quad: the LDS round trip (~120
+      // cycles) in front of each 16-cycle instruction — the tap loop ran at a quarter of the matrix rate.
+      uint4 bq[2][NF];
+      auto read_b = [&](int s, uint4 (&dst)[NF]) {
+        int so;
+        bool pad;
+        step_off(s, so, pad);
         // a padded tap must read the zero voxel itself: its weights are 0, but 0 * stale NaN bytes would poison acc
         const bool maybe_pad = (TPS > 1) && ((s + 1) * TPS > NT);
-        const int addr = (maybe_pad && pad) ? ZERO_OFF : base[f] + so;
-        const uint4 b = *reinterpret_cast<const uint4*>(halo + addr);
 #pragma unroll
-        for (int a = 0; a < FM; ++a) Mma3<T>::run(af[a], b, acc[a][f]);
+        for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const uint4*>(halo + ((maybe_pad && pad) ? ZERO_OFF : base[f] + so));
+      };
+      // A operands (packed weights, L2-resident): a ring PDA steps ahead (the scheduling barriers below would otherwise pin
+      // each load in the step that consumes it)
+      constexpr int PDA = NS < 4 ? NS : 4;
+      uint4 aq[PDA][FM];
+      auto load_a = [&](int s, uint4 (&dst)[FM]) {
+#pragma unroll
+        for (int a = 0; a < FM; ++a) dst[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
+      };
+#pragma unroll
+      for (int p = 0; p < PDA; ++p) load_a(p, aq[p]);
+      read_b(0, bq[0]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        uint4 af[FM];
+#pragma unroll
+        for (int a = 0; a < FM; ++a) af[a] = aq[s % PDA][a];
+        if (s + PDA < NS) load_a(s + PDA, aq[s % PDA]);
+        if (s + 1 < NS) read_b(s + 1, bq[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int a = 0; a < FM; ++a) Mma3<T>::run(af[a], bq[s & 1][f], acc[a][f]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     }
