@@ -44,7 +44,10 @@ template <> struct Mma3<bx3_t> {      // split pairs (common.h): one chunk = 4 k
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) { c = mma_bx3_k16(a, b, c); }
 };
 
-template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR>
+// WC: the four waves of a workgroup split as (4 / WC fragment groups) x (WC slices of the output channels).  A wave with all
+// output channels (WC = 1) loads FM packed weight operands per step for NF B operands; with WC > 1 it loads FM / WC for NF * WC —
+// the weights (every wave streams them from L2 for every tile) weigh less, the LDS-resident halo is read more often.
+template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, int WC = 1>
 struct C3Cfg {
   static constexpr int E = 16 / sizeof(T);
   static constexpr int BPT = CIN * sizeof(T);          // bytes per tap (= per voxel)
@@ -58,8 +61,9 @@ struct C3Cfg {
   static constexpr int NVH = HD * HH * HW;
   static constexpr int LDS_BYTES = (NVH + 1) * VS;     // +1: an all-zero voxel for padded taps
   static constexpr int NV = TD * TH * TW;
-  static constexpr int NF = NV / 64;                   // 16-voxel fragments per wave
-  static constexpr int FM = COUTP / 16;
+  static constexpr int NF = NV / 64 * WC;              // 16-voxel fragments per wave
+  static constexpr int FM = COUTP / 16 / WC;           // 16-channel row tiles per wave
+  static_assert(4 % WC == 0 && (COUTP / 16) % WC == 0, "the channel tiles must split over WC waves");
   static constexpr int SPT = BPT >= 64 ? BPT / 64 : 1; // MFMA steps per tap
   static constexpr int TPS = BPT >= 64 ? 1 : 64 / BPT; // taps per MFMA step
   static constexpr int GPT = 4 / TPS;                  // lane groups per tap inside one step
@@ -91,9 +95,9 @@ int g_debug_flags = 0;
 
 template <int N> struct IC { static constexpr int value = N; };
 
-template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP>
+template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP, int WC = 1>
 __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDesc d) {
-  using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR>;
+  using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WC>;
   constexpr int VS = Cfg::VS, CPV = Cfg::CPV, HH = Cfg::HH, HW = Cfg::HW, NVH = Cfg::NVH;
   constexpr int NF = Cfg::NF, FM = Cfg::FM, SPT = Cfg::SPT, TPS = Cfg::TPS, GPT = Cfg::GPT, E = Cfg::E;
   constexpr int ZERO_OFF = NVH * VS;
@@ -227,13 +231,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   int qd_[NF], qh_[NF], qw_[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    const int vt = (wave * NF + f) * 16 + lr;          // voxel index inside the tile, w fastest
+    const int vt = ((wave / WC) * NF + f) * 16 + lr;   // voxel index inside the tile, w fastest
     const int w_ = vt % TW, h_ = (vt / TW) % TH, d_ = vt / (TW * TH);
     base[f] = ((d_ * STRIDE * HH + h_ * STRIDE) * HW + w_ * STRIDE) * VS + (TPS == 1 ? lg * 16 : 0);
     qd_[f] = q0d + d_; qh_[f] = q0h + h_; qw_[f] = q0w + w_;
   }
 
-  const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(d.wgt) + lr * 64 + lg * 16;
+  const int co0 = (wave % WC) * FM * 16;              // this wave's slice of the output channels
+  const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(d.wgt) + (long long)co0 * 64 + lr * 64 + lg * 16;
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
 
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
 #pragma unroll
   for (int a = 0; a < FM; ++a)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[a][e] = (a * 16 + lg * 4 < d.Cout) ? d.bias[a * 16 + lg * 4 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bv[a][e] = (co0 + a * 16 + lg * 4 < d.Cout) ? d.bias[co0 + a * 16 + lg * 4 + e] : 0.f;
 
   auto run_pass = [&](auto pc) {
     constexpr int PASS = decltype(pc)::value;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
       opix[f] = (TR && d.out_classmajor) ? ((((long long)PASS * d.N + n) * d.Dq + qd_[f]) * d.Hq + qh_[f]) * d.Wq + qw_[f] : rpix;
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
-        const int ch = a * 16 + lg * 4;
+        const int ch = co0 + a * 16 + lg * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rv[f][a][e] = 0.f;
         if (res && fok[f] && ch < d.Cout) load4(res + rpix * d.Cout + ch, rv[f][a]);
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
       if (!fok[f]) continue;
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
-        const int ch = a * 16 + lg * 4;
+        const int ch = co0 + a * 16 + lg * 4;
         if (ch >= d.Cout) continue;
         float v[4] = {acc[a][f][0], acc[a][f][1], acc[a][f][2], acc[a][f][3]};
 #pragma unroll
@@ -441,15 +446,15 @@ void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int
   }
 }
 
-template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP>
+template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP, int WC = 1>
 static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
-  using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR>;
+  using Cfg = C3Cfg<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WC>;
   constexpr size_t LDS = Cfg::LDS_BYTES;
   static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
   d.ntd = (d.Dq + TD - 1) / TD; d.nth = (d.Hq + TH - 1) / TH; d.ntw = (d.Wq + TW - 1) / TW;
   const long long nblk = (long long)d.N * d.ntd * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv3d grid out of range");
-  auto kern = conv3d_tile_kernel<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WARP>;
+  auto kern = conv3d_tile_kernel<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WARP, WC>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)LDS)) return rc;
   d.dbg = g_debug_flags;
   prof_begin_launch(s, d.prof_variant, d.algo_flops, d.algo_bytes);
@@ -461,25 +466,25 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
 
 // layer ids: 0..6 = conv0..conv6, 7..9 = conv7/9/11 (transposed), 10 = conv0 with fused warp
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s) {
-#define C3_CASE(L, CIN, COUTP, TDB, THB, TWB, TDF, THF, TWF, STRIDE, TR, WARP)                                     \
+#define C3_CASE(L, CIN, COUTP, TDB, THB, TWB, TDF, THF, TWF, STRIDE, TR, WARP, WCB, WCF)                           \
   case L:                                                                                                          \
-    return dtype == BF16  ? launch_c3<unsigned short, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)           \
-           : dtype == F16 ? launch_c3<f16_t, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP>(d, s)                    \
-           : dtype == BF16X3 ? launch_c3<bx3_t, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s)                 \
-                          : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP>(d, s);
+    return dtype == BF16  ? launch_c3<unsigned short, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP, WCB>(d, s)      \
+           : dtype == F16 ? launch_c3<f16_t, CIN, COUTP, TDB, THB, TWB, STRIDE, TR, WARP, WCB>(d, s)               \
+           : dtype == BF16X3 ? launch_c3<bx3_t, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP, WCF>(d, s)            \
+                          : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP, 1>(d, s);
   switch (layer) {
-    //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp
-    C3_CASE(0, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, false)
-    C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true)
-    C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false)
-    C3_CASE(2, 16, 16, 6, 8, 8, 4, 8, 8, 1, false, false)
-    C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false)
-    C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false)
-    C3_CASE(5, 32, 64, 1, 8, 8, 1, 8, 8, 2, false, false)
-    C3_CASE(6, 64, 64, 1, 8, 8, 1, 8, 8, 1, false, false)
-    C3_CASE(7, 64, 32, 3, 8, 8, 1, 8, 8, 1, true, false)
-    C3_CASE(8, 32, 16, 2, 8, 8, 2, 8, 8, 1, true, false)
-    C3_CASE(9, 16, 16, 4, 8, 8, 4, 8, 8, 1, true, false)
+    //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp   channel split of the waves (16-bit, split pairs)
+    C3_CASE(0, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
+    C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true, 1, 1)
+    C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false, 1, 1)
+    C3_CASE(2, 16, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
+    C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false, 2, 1)
+    C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false, 1, 1)
+    C3_CASE(5, 32, 64, 1, 8, 8, 1, 8, 8, 2, false, false, 4, 4)
+    C3_CASE(6, 64, 64, 1, 8, 8, 1, 8, 8, 1, false, false, 1, 1)
+    C3_CASE(7, 64, 32, 3, 8, 8, 1, 8, 8, 1, true, false, 1, 2)
+    C3_CASE(8, 32, 16, 2, 8, 8, 2, 8, 8, 1, true, false, 1, 1)
+    C3_CASE(9, 16, 16, 4, 8, 8, 4, 8, 8, 1, true, false, 1, 1)
     default: break;
   }
 #undef C3_CASE
