@@ -14,6 +14,7 @@
 // MFMA 16x16x32 bf16 (or 16x16x4 f32) accumulating in registers.  Transposed convs run their 8 sub-pixel
 // classes off one halo.  All loads of the staging phase are issued in batches so that many are in flight.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -94,6 +95,9 @@ __device__ __forceinline__ void warp_ixy(const float* __restrict__ hm, float x, 
 int g_debug_flags = 0;
 
 template <int N> struct IC { static constexpr int value = N; };
+// compile-time loop: f(IC<0>{}), ..., f(IC<N-1>{}) — register arrays indexed by the loop variable stay registers
+template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <typename T, int CIN, int COUTP, int TD, int TH, int TW, int STRIDE, bool TR, bool WARP, int WC = 1>
 __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDesc d) {
@@ -272,39 +276,71 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
     if constexpr (std::is_same<T, bx3_t>::value) {
       // split pairs: two consecutive steps (2 x 4 k values per lane, hi and lo) make the operands of the full-rate 16x16x32
       // instruction; an odd last step runs on the K=16 form
-      if (!(d.dbg & 2))
+      if (!(d.dbg & 2)) {
+        // same schedule as the 16-bit path below, in units of step PAIRS: the operands of pair p + 1 are read from LDS before the
+        // MFMAs of pair p (two register sets), the packed weights run two pairs ahead through a register ring
+        constexpr int NP = (NS + 1) / 2;
+        uint4 bq0[2][NF], bq1[2][NF], aq0[2][FM], aq1[2][FM];
+        auto read_pair = [&](auto PI, uint4 (&d0)[NF], uint4 (&d1)[NF]) {
+          constexpr int s = 2 * decltype(PI)::value;
+          constexpr bool two = s + 1 < NS;
+          int so0, so1 = 0;
+          bool pad0, pad1 = false;
+          step_off(s, so0, pad0);
+          if constexpr (two) step_off(s + 1, so1, pad1);
+          constexpr bool mp0 = (TPS > 1) && ((s + 1) * TPS > NT), mp1 = (TPS > 1) && ((s + 2) * TPS > NT);
 #pragma unroll
-      for (int s = 0; s < NS; s += 2) {
-        const bool two = s + 1 < NS;
-        int so0, so1 = 0;
-        bool pad0, pad1 = false;
-        step_off(s, so0, pad0);
-        if (two) step_off(s + 1, so1, pad1);
-        uint4 ah[FM], al[FM], a0[FM];
+          for (int f = 0; f < NF; ++f) {
+            d0[f] = *reinterpret_cast<const uint4*>(halo + ((mp0 && pad0) ? ZERO_OFF : base[f] + so0));
+            if constexpr (two) d1[f] = *reinterpret_cast<const uint4*>(halo + ((mp1 && pad1) ? ZERO_OFF : base[f] + so1));
+          }
+        };
+        auto load_pair = [&](auto PI, uint4 (&d0)[FM], uint4 (&d1)[FM]) {
+          constexpr int s = 2 * decltype(PI)::value;
 #pragma unroll
-        for (int a = 0; a < FM; ++a) {
-          a0[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
-          if (two) bx3_pair(a0[a], *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s + 1) * COUTP + a * 16) * 64), ah[a], al[a]);
-        }
+          for (int a = 0; a < FM; ++a) {
+            d0[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s) * COUTP + a * 16) * 64);
+            if constexpr (s + 1 < NS) d1[a] = *reinterpret_cast<const uint4*>(wg + ((long long)(S0 + s + 1) * COUTP + a * 16) * 64);
+          }
+        };
+        load_pair(IC<0>{}, aq0[0], aq1[0]);
+        if constexpr (NP > 1) load_pair(IC<1>{}, aq0[1], aq1[1]);
+        read_pair(IC<0>{}, bq0[0], bq1[0]);
+        static_for<NP>([&](auto PI) {
+          constexpr int pi = decltype(PI)::value;
+          constexpr bool two = 2 * pi + 1 < NS;
+          uint4 a0[FM], a1[FM];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const bool mp0 = (TPS > 1) && ((s + 1) * TPS > NT), mp1 = (TPS > 1) && ((s + 2) * TPS > NT);
-          const uint4 b0 = *reinterpret_cast<const uint4*>(halo + ((mp0 && pad0) ? ZERO_OFF : base[f] + so0));
-          if (two) {
-            const uint4 b1 = *reinterpret_cast<const uint4*>(halo + ((mp1 && pad1) ? ZERO_OFF : base[f] + so1));
-            uint4 bh, bl;
-            bx3_pair(b0, b1, bh, bl);
+          for (int a = 0; a < FM; ++a) {
+            a0[a] = aq0[pi & 1][a];
+            if constexpr (two) a1[a] = aq1[pi & 1][a];
+          }
+          if constexpr (pi + 2 < NP) load_pair(IC<pi + 2>{}, aq0[pi & 1], aq1[pi & 1]);
+          if constexpr (pi + 1 < NP) read_pair(IC<pi + 1>{}, bq0[(pi + 1) & 1], bq1[(pi + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (two) {
+            uint4 ah[FM], al[FM];
 #pragma unroll
-            for (int a = 0; a < FM; ++a) {
-              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
-              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bl), acc[a][f], 0, 0, 0);
-              acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
+            for (int a = 0; a < FM; ++a) bx3_pair(a0[a], a1[a], ah[a], al[a]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              uint4 bh, bl;
+              bx3_pair(bq0[pi & 1][f], bq1[pi & 1][f], bh, bl);
+#pragma unroll
+              for (int a = 0; a < FM; ++a) {
+                acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
+                acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bl), acc[a][f], 0, 0, 0);
+                acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[a]), __builtin_bit_cast(bf16x8, bh), acc[a][f], 0, 0, 0);
+              }
             }
           } else {
 #pragma unroll
-            for (int a = 0; a < FM; ++a) Mma3<T>::run(a0[a], b0, acc[a][f]);
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+              for (int a = 0; a < FM; ++a) Mma3<T>::run(a0[a], bq0[pi & 1][f], acc[a][f]);
           }
-        }
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
     } else {
     if (!(d.dbg & 2)) {
@@ -478,8 +514,8 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
     C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true, 1, 1)
     C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false, 1, 1)
     C3_CASE(2, 16, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
-    C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false, 2, 1)
-    C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false, 1, 1)
+    C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false, 2, 2)
+    C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false, 1, 2)
     C3_CASE(5, 32, 64, 1, 8, 8, 1, 8, 8, 2, false, false, 4, 4)
     C3_CASE(6, 64, 64, 1, 8, 8, 1, 8, 8, 1, false, false, 1, 1)
     C3_CASE(7, 64, 32, 3, 8, 8, 1, 8, 8, 1, true, false, 1, 2)
