@@ -55,7 +55,7 @@ struct C3Cfg {
   // LDS bytes per halo voxel: padded by 16 (conflict-free b128 rows), except 16-byte voxels (conv1): unpadded the halo is
   // 23 KB instead of 46 KB, 6 workgroups per CU instead of 3 — this layer is bound by bytes in flight (3.5 -> 2.9 ms),
   // the 2-way bank conflict on its few MFMA operand reads is not
-  static constexpr int VS = BPT == 16 ? 16 : BPT + 16;
+  static constexpr int VS = BPT <= 32 ? BPT : BPT + 16;
   static constexpr int CPV = BPT / 16;                 // 16-byte chunks per voxel
   static constexpr int KE = TR ? 2 : 3;                // taps per axis covered by the halo
   static constexpr int HD = (TD - 1) * STRIDE + KE, HH = (TH - 1) * STRIDE + KE, HW = (TW - 1) * STRIDE + KE;
