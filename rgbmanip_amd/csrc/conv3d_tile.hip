@@ -514,7 +514,7 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
     C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true, 1, 1)
     C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false, 1, 1)
     C3_CASE(2, 16, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
-    C3_CASE(3, 16, 32, 2, 8, 8, 2, 8, 8, 2, false, false, 2, 2)
+    C3_CASE(3, 16, 32, 2, 8, 8, 1, 8, 8, 2, false, false, 2, 2)
     C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false, 1, 2)
     C3_CASE(5, 32, 64, 1, 8, 8, 1, 8, 8, 2, false, false, 4, 4)
     C3_CASE(6, 64, 64, 1, 8, 8, 1, 8, 8, 1, false, false, 1, 1)
