@@ -36,7 +36,7 @@ struct AdaPose {
   ConvLayer psp[4], up1, up2, up3, fin;
   UpConvLayer up1c, up2c;       // up_1 / up_2 as a low-resolution 1x1 GEMM + tap combination (upconv.hip)
   UpConvFinal tail;             // up_3 + final in one kernel (upconv_final.hip; 16-bit and split-pair storage)
-  int upconv = 3;               // bit 0: up_1, bit 1: up_2 through UpConvLayer, bit 2: up_3 + final through UpConvFinal (opt-in: measured slower in the network than resize + fused ws64 conv); 0 = x2 resize + 3x3 conv on the up-sampled grid, for A/B and tests
+  int upconv = 7;               // bit 0: up_1, bit 1: up_2 through UpConvLayer, bit 2: up_3 + final through UpConvFinal (16-bit / split pairs); 0 = x2 resize + 3x3 conv on the up-sampled grid, for A/B and tests
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)
   // norm_mode 1 (per-sample BatchNorm3d: the as-shipped train-mode behaviour at batch 1): the same ten layers without
   // BN / activation, their gamma / beta, and the in-place normalisation of bn_kernels.hip behind each of them

@@ -1,0 +1,33 @@
+"""Same-box A/B of one rgbm_adapose_set_option key at batch 256: ms per forward for each value, interleaved.
+usage: ab_option.py <dtype> <key> <v0> <v1> [...]"""
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rgbmanip_amd import synth
+from rgbmanip_amd.adapose import AdaPoseNet
+
+dtype, key, vals = sys.argv[1], sys.argv[2], [int(v) for v in sys.argv[3:]]
+B = 256
+inp = synth.adapose_inputs(16, seed=0)
+inp = {k: torch.from_numpy(np.concatenate([v] * (B // 16), 0)).cuda() for k, v in inp.items()}
+sd = synth.adapose_state_dict(seed=0)
+nets = {v: AdaPoseNet(sd, dtype=dtype, options={key: v}) for v in vals}
+def run(net):
+    return net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"])
+for net in nets.values():
+    run(net)
+torch.cuda.synchronize()
+res = {v: [] for v in vals}
+for rep in range(4):
+    for v in vals:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run(nets[v])
+        e1.record()
+        torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1) / 3)
+for v in vals:
+    print(dtype, key, v, "ms per forward:", " ".join(f"{t:.2f}" for t in res[v]), " median", f"{np.median(res[v]):.2f}")
