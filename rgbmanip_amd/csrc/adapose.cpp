@@ -560,6 +560,8 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   if (pdt == F16) {
     if (int rc = launch_f32_to_f16(bf.PF96, bf.PF96h, (long long)VP * 96, s)) return rc;
     pf_in = bf.PF96h;
+  } else if (pdt == BF16X3) {
+    if (int rc = launch_f32_to_bx3(bf.PF96, bf.PF96, (long long)VP * 96, s)) return rc;      // in place: same 4-byte slots
   }
   if (int rc = pm1[0].run(pf_in, bf.Q128a, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;

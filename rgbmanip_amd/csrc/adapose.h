@@ -24,7 +24,10 @@ struct AdaPose {
   // activations are O(1); fp16 per-point features keep 11 mantissa bits, the means over points stay fp32, and the rotation
   // error stays at the 2e-3 the bf16 backbone sets), fp32 for fp32 nets and for the fp16 accuracy mode (where fp16 here would
   // raise the rotation error from 4e-5 to 3e-4)
-  int pose_dtype() const { return dtype == BF16 ? F16 : F32; }
+  // storage type of the four per-point layers of the pose MLP: fp16 for bf16 nets, split pairs for split-pair nets (the exact-fp32
+  // matrix path runs at a sixteenth of the bf16 rate: 1.5 ms per step for these layers), fp32 otherwise
+  int pose_dtype() const { return dtype == BF16 ? F16 : (dtype == BF16X3 && pose_x3) ? BF16X3 : F32; }
+  int pose_x3 = 1;
   int img = 224, n_pts = 1024, n_depth = 24;
   int img_cpad = 4;
   int max_chunk = 512;           // views per cost-volume chunk (bounds the workspace: ~80 MB per view in bf16; 512 = batch 256 in one chunk)

@@ -287,11 +287,13 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__
 }
 
 int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s) {
-  RGBM_REQUIRE(dtype == F32 || dtype == F16, "mean_points: fp32 or fp16 input");
+  RGBM_REQUIRE(dtype == F32 || dtype == F16 || dtype == BF16X3, "mean_points: fp32, fp16 or split-pair input");
   const int E = dtype == F16 ? 8 : 4;
   RGBM_REQUIRE(C % E == 0 && C / E <= 256 && 256 % (C / E) == 0, "mean_points: channel count");
   if (dtype == F16)
     hipLaunchKernelGGL(mean_points_kernel<f16_t>, dim3(V), dim3(256), 0, s, (const f16_t*)in, out, P, C);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(mean_points_kernel<bx3_t>, dim3(V), dim3(256), 0, s, (const bx3_t*)in, out, P, C);
   else
     hipLaunchKernelGGL(mean_points_kernel<float>, dim3(V), dim3(256), 0, s, (const float*)in, out, P, C);
   RGBM_CHECK_HIP(hipGetLastError());

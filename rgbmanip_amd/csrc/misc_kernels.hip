@@ -582,6 +582,21 @@ int launch_bx3_to_f32(const void* in, float* out, long long n, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------- fp32 -> split pairs (input of the split-pair pose MLP); in place is allowed
+__global__ __launch_bounds__(256) void f32_to_bx3_kernel(const float4* in, uint4* out, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = in[i];
+    out[i] = bx3_split4(a.x, a.y, a.z, a.w);
+  }
+}
+
+int launch_f32_to_bx3(const float* in, void* out, long long n, hipStream_t s) {
+  RGBM_REQUIRE(n % 4 == 0, "f32_to_bx3: element count must be a multiple of 4");
+  hipLaunchKernelGGL(f32_to_bx3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (const float4*)in, (uint4*)out, n / 4);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- fp32 -> fp16 copy (input of the fp16 pose MLP), 8 elements per thread
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ in, f16_t* __restrict__ out, long long n8) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
