@@ -270,6 +270,10 @@ int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, in
  * out_f32 (RGBM_BF16X3 only).  dtype RGBM_BF16 / RGBM_F16 / RGBM_BF16X3. */
 int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int w, const float* w3_host, const float* b3_host,
                                 float slope, const float* wf_host, const float* bf_host, void* out_dev, int out_f32, void* stream);
+/* The ResNet stem as the 16-bit / split-pair network runs it (stem.hip): Conv2d 7x7 stride 2 pad 3 (3 -> 64, no bias, pspnet.py:37)
+ * -> ReLU -> MaxPool2d 3x3 stride 2 pad 1 (pspnet.py:39) in one kernel.  img1_dev / img2_dev [B][3][S][S] fp32 NCHW (views
+ * 0..B-1 / B..2B-1), w_host [64][3][7][7]; out_dev [2B][S/4][S/4][64] in `dtype` (RGBM_BF16 / RGBM_F16 / RGBM_BF16X3); S % 32 == 0. */
+int rgbm_stem(int dtype, const float* img1_dev, const float* img2_dev, const float* w_host, void* out_dev, int B, int S, void* stream);
 int rgbm_maxpool3x3s2(int dtype, const void* in_dev, void* out_dev, int V, int H, int W, int C, void* stream);
 int rgbm_resize_bilinear_ac(int dtype, const void* in_dev, void* out_dev, int V, int Hs, int Ws, int C, int Ho, int Wo,
                             void* stream);

@@ -111,6 +111,7 @@ SIGNATURES = {
     "rgbm_conv3d_tile": (_i, [_i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_upsample_conv3x3": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
     "rgbm_upsample_conv3x3_final": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
+    "rgbm_stem": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "rgbm_maxpool3x3s2": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbm_resize_bilinear_ac": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rgbm_adaptive_avgpool": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

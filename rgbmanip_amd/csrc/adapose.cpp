@@ -78,6 +78,16 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
   img_cpad = E;                              // RGB padded to one 16-byte chunk
   const std::string fe = "img_extractor.feats.";
   if (int rc = init_conv2d(conv1, dtype, sd, fe + "conv1.weight", nullptr, 3, 64, 7, 2, 3, 1, ACT_RELU, 0.f, img_cpad)) return rc;
+  if (dtype != F32) {
+    GET(w1, fe + "conv1.weight");
+    RGBM_REQUIRE(w1->numel() == 64 * 3 * 7 * 7, "conv1 shape");
+    std::vector<float> pk;
+    stem_pack(w1->data, pk);
+    if (int rc = upload_packed(pk, dtype, &stem_w)) return rc;
+    // same-box A/B at batch 256: bf16 forward 56.58 -> 55.62 ms with the one-kernel stem, split pairs 122.63 -> 122.91 ms (three
+    // products per operand pair, 79 KB of staging: two workgroups per CU) — on by default for the 16-bit types only
+    stem = dtype_size(dtype) == 2 ? 1 : 0;
+  }
   int inpl = 64, nb = 0;
   for (int li = 0; li < 4; ++li) {
     for (int b = 0; b < kLayerBlocks[li]; ++b) {
@@ -220,6 +230,8 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
 
 void AdaPose::destroy() {
   conv1.destroy();
+  if (stem_w) (void)hipFree(stem_w);
+  stem_w = nullptr;
   for (int i = 0; i < n_blocks; ++i) { blocks[i].c1.destroy(); blocks[i].c2.destroy(); if (blocks[i].has_ds) blocks[i].ds.destroy(); }
   for (auto& l : psp) l.destroy();
   up1.destroy(); up2.destroy(); up3.destroy(); fin.destroy();
@@ -331,11 +343,20 @@ size_t AdaPose::workspace_bytes(int B) const {
   return A.peak + 256;
 }
 
-int AdaPose::pspnet(const Buffers& bf, int V, hipStream_t s) const {
+int AdaPose::pspnet(const Buffers& bf, int V, const float* img1, const float* img2, hipStream_t s) const {
   const int S = img;
   int H = S / 2, W = S / 2;
-  if (int rc = conv1.run(bf.imgpad, bf.c1, V, 1, S, S, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_maxpool3x3s2(dtype, bf.c1, bf.lb[0], V, H, W, 64, s)) return rc;
+  if (stem && stem_w) {
+    // NCHW fp32 images -> conv1 + ReLU + max-pool in one kernel (no padded copy, no 112 x 112 x 64 tensor)
+    if (int rc = launch_stem(dtype, img1, img2, stem_w, bf.lb[0], V / 2, V, S, s)) return rc;
+  } else {
+    const size_t es = dtype_size(dtype);
+    const int B = V / 2;
+    if (int rc = launch_nchw_to_nhwc_pad(dtype, img1, bf.imgpad, B, 3, S, S, img_cpad, s)) return rc;
+    if (int rc = launch_nchw_to_nhwc_pad(dtype, img2, (char*)bf.imgpad + (size_t)B * S * S * img_cpad * es, B, 3, S, S, img_cpad, s)) return rc;
+    if (int rc = conv1.run(bf.imgpad, bf.c1, V, 1, S, S, 64, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = launch_maxpool3x3s2(dtype, bf.c1, bf.lb[0], V, H, W, 64, s)) return rc;
+  }
   H = S / 4; W = S / 4;
   int xi = 0;                                   // index of the buffer holding x
   for (int i = 0; i < n_blocks; ++i) {
@@ -522,11 +543,7 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   RGBM_CHECK_HIP(hipMemcpyAsync(bf.Pviews + (size_t)B * 16, P2, (size_t)B * 64, hipMemcpyDeviceToDevice, s));
   RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose, choose1, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
   RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose + (size_t)B * P, choose2, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
-  const size_t es = dtype_size(dtype);
-  if (int rc = launch_nchw_to_nhwc_pad(dtype, img1, bf.imgpad, B, 3, S, S, img_cpad, s)) return rc;
-  if (int rc = launch_nchw_to_nhwc_pad(dtype, img2, (char*)bf.imgpad + (size_t)B * S * S * img_cpad * es, B, 3, S, S, img_cpad, s)) return rc;
-
-  if (int rc = pspnet(bf, V, s)) return rc;
+  if (int rc = pspnet(bf, V, img1, img2, s)) return rc;
   if (int rc = launch_homography(bf.Pviews, bf.homog, V, B, s)) return rc;
   // bf16x3 nets: everything that GATHERS from the feature map (plane sweep, point heads) reads a plain fp32 copy of it
   const void* featg = bf.feat;

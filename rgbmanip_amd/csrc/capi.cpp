@@ -65,6 +65,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "fuse_final") { RGBM_REQUIRE(value == 0 || value == 1, "fuse_final"); h->net.fuse_final = value; }
   else if (k == "sparse_tail") { RGBM_REQUIRE(value == 0 || value == 1, "sparse_tail"); h->net.sparse_tail = value; }
   else if (k == "upconv") { RGBM_REQUIRE(value >= 0 && value <= 7, "upconv"); h->net.upconv = value; }
+  else if (k == "stem") { RGBM_REQUIRE(value == 0 || value == 1, "stem"); h->net.stem = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   return 0;
@@ -195,6 +196,18 @@ int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int
   if (!rc) rc = L.run(in_dev, out_dev, out_f32 != 0, V, h, w, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   L.destroy();
+  return rc;
+}
+
+int rgbm_stem(int dtype, const float* img1_dev, const float* img2_dev, const float* w_host, void* out_dev, int B, int S, void* stream) {
+  RGBM_REQUIRE(img1_dev && img2_dev && w_host && out_dev && B > 0, "stem arguments");
+  std::vector<float> pk;
+  stem_pack(w_host, pk);
+  void* wd = nullptr;
+  int rc = upload_packed(pk, dtype, &wd);
+  if (!rc) rc = launch_stem(dtype, img1_dev, img2_dev, wd, out_dev, B, 2 * B, S, (hipStream_t)stream);
+  if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
+  if (wd) (void)hipFree(wd);
   return rc;
 }
 

@@ -44,6 +44,9 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
                        hipStream_t s);
 int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s);      // dtype of `in`: F32 or F16
 int launch_f32_to_f16(const float* in, void* out, long long n, hipStream_t s);
+// ResNet stem in one kernel (stem.hip): NCHW fp32 images -> maxpool3x3s2(relu(conv7x7s2)) [V][S/4][S/4][64]
+void stem_pack(const float* w, std::vector<float>& packed);
+int launch_stem(int dtype, const float* img1, const float* img2, const void* wpk, void* out, int B, int V, int S, hipStream_t s);
 int launch_f32_to_bx3(const float* in, void* out, long long n, hipStream_t s);     // plain fp32 -> split pairs (n % 4 == 0; in place allowed)
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s);

@@ -141,6 +141,20 @@ def test_upconv_path_equals_resize_then_conv_at_batch(inputs256, dtype, upconv):
         assert e < (tol if tol else 2 * GATE_BF16[k.split("_")[1]]), (k, e)
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "fp16"])
+def test_one_kernel_stem_equals_copy_conv_pool(inputs256, dtype):
+    """conv1 7x7 + ReLU + max-pool in one kernel from the NCHW images (option stem = 1, the 16-bit default) against the padded copy,
+    the implicit-GEMM conv and the pool kernel (stem = 0, the split-pair default) at B = 64: same function, another K order."""
+    args = _dev_inputs(inputs256, 64)
+    a = {k: v.cpu().numpy() for k, v in _forward(_net(dtype, options={"stem": 1}), args).items()}
+    b = {k: v.cpu().numpy() for k, v in _forward(_net(dtype, options={"stem": 0}), args).items()}
+    gate16 = GATE_BF16 if dtype == "bf16" else GATE_FP16
+    for k in OUT_KEYS:
+        e = _rel(a[k], b[k])
+        print(dtype, k, "fused stem vs unfused", e)
+        assert e < (RTOL_FP32 if dtype == "bf16x3" else 2 * gate16[k.split("_")[1]]), (k, e)
+
+
 @pytest.mark.parametrize("dtype,B,reps", [("bf16", B_FULL, 20), ("bf16x3", B_FULL, 20), ("fp16", B_FULL, 20), ("fp32", B_FULL, 4)])
 def test_forward_is_bit_stable_at_bench_shape(inputs256, dtype, B, reps):
     """`reps` forwards of the same batch must agree bit for bit in all ten outputs (what tools/check_determinism.py does by hand)."""

@@ -645,6 +645,35 @@ def test_upsample_conv3x3_commuted(case, dtype):
     assert err < tol, (name, dtype, err)
 
 
+@pytest.mark.parametrize("dtype", [d for d in DTYPES if d != _lib.F32])
+@pytest.mark.parametrize("S,B", [(32, 1), (64, 2), (224, 1)])
+def test_stem_conv_relu_pool_fused(S, B, dtype):
+    """rgbm_stem (stem.hip: conv1 7x7 s2 p3 -> ReLU -> max-pool 3x3 s2 p1 in one kernel, pspnet.py:37-39) against torch on the
+    CPU with operands rounded to the storage type (the conv output is rounded to it once more before the pool, like the tensor
+    the unfused path stores); a NaN pixel must poison exactly the pooled outputs whose windows see it."""
+    from gpu_util import from_channels_last, rel_err, empty_out, host_f32
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S * 10 + B)
+    img = torch.randn(2 * B, 3, S, S, generator=g)
+    img[0, 1, 5, 7] = float("nan")
+    w = _q(torch.randn(64, 3, 7, 7, generator=g) / 12.0, dtype)
+    conv = F.relu(F.conv2d(_q(img, dtype), w, None, 2, 3))
+    ref = F.max_pool2d(torch.nan_to_num(_q(conv, dtype), nan=float("inf")), 3, 2, 1)      # torch's CPU pool drops NaN; +inf marks its windows
+    i1, i2 = img[:B].contiguous().cuda(), img[B:].contiguous().cuda()
+    out = empty_out((2 * B, S // 4, S // 4, 64), dtype)
+    (_, wp), = keep = [host_f32(w)]
+    _lib.check(lib.rgbm_stem(dtype, _lib.ptr(i1), _lib.ptr(i2), wp, _lib.ptr(out), B, S, _lib.stream_ptr()), "rgbm_stem")
+    torch.cuda.synchronize()
+    got = from_channels_last(out, 64)
+    nanmask = torch.isinf(ref)
+    assert torch.equal(torch.isnan(got), nanmask), (int(torch.isnan(got).sum()), int(nanmask.sum()))
+    assert nanmask.any() and not nanmask[1:].any()
+    tol = {_lib.BF16: 2e-2, _lib.F16: 3e-3, _lib.BF16X3: 3e-5}[dtype]
+    err = rel_err(torch.where(nanmask, torch.zeros_like(got), got), torch.where(nanmask, torch.zeros_like(ref), ref))
+    print("stem", S, B, dtype, err)
+    assert err < tol, (S, B, dtype, err)
+
+
 TAIL_CASES = [("tail_one_tile", 1, 8, 8), ("tail_rect", 2, 8, 24), ("tail_multi", 3, 32, 16)]
 
 
