@@ -84,9 +84,9 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
     std::vector<float> pk;
     stem_pack(w1->data, pk);
     if (int rc = upload_packed(pk, dtype, &stem_w)) return rc;
-    // same-box A/B at batch 256: bf16 forward 56.58 -> 55.62 ms with the one-kernel stem, split pairs 122.63 -> 122.91 ms (three
-    // products per operand pair, 79 KB of staging: two workgroups per CU) — on by default for the 16-bit types only
-    stem = dtype_size(dtype) == 2 ? 1 : 0;
+    // same-box A/B at batch 256 (tools/ab_option.py <dtype> stem 0 1): bf16 forward 56.58 -> 55.62 ms; split pairs 125.06 -> 124.68 ms
+    // with 4-row tiles (8-row tiles: 79 KB of staging, 122.63 -> 122.91 ms)
+    stem = 1;
   }
   int inpl = 64, nb = 0;
   for (int li = 0; li < 4; ++li) {

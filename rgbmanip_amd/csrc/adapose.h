@@ -39,7 +39,7 @@ struct AdaPose {
   ConvLayer psp[4], up1, up2, up3, fin;
   UpConvLayer up1c, up2c;       // up_1 / up_2 as a low-resolution 1x1 GEMM + tap combination (upconv.hip)
   void* stem_w = nullptr;       // conv1 packed for the one-kernel stem (stem.hip; 16-bit and split-pair storage)
-  int stem = 0;                 // 1: NCHW images -> conv1 7x7 + ReLU + max-pool in one kernel (default for 16-bit storage, set in create()); 0: copy, implicit-GEMM conv, pool (materialises `conv1`)
+  int stem = 0;                 // 1: NCHW images -> conv1 7x7 + ReLU + max-pool in one kernel (default for 16-bit and split-pair storage, set in create()); 0: copy, implicit-GEMM conv, pool (materialises `conv1`)
   UpConvFinal tail;             // up_3 + final in one kernel (upconv_final.hip; 16-bit and split-pair storage)
   int upconv = 7;               // bit 0: up_1, bit 1: up_2 through UpConvLayer, bit 2: up_3 + final through UpConvFinal (16-bit / split pairs); 0 = x2 resize + 3x3 conv on the up-sampled grid, for A/B and tests
   ConvLayer c3d[7], dc[3];      // generic implicit-GEMM versions (kept for A/B: cost_impl = 0)

@@ -18,13 +18,18 @@ namespace rgbm {
 
 namespace {
 
-constexpr int kPT = 8;                      // pooled tile side
-constexpr int kCT = 2 * kPT + 1;            // conv tile side: 17
-constexpr int kPR = 2 * (kCT - 1) + 7;      // patch rows: 39
-constexpr int kPC = kPR + 1;                // patch columns: 40 (the zero-weight 8th column slot of the last pixel reads it)
-constexpr int kNPX = kCT * kCT;             // 289 conv outputs per tile
-constexpr int kNTL = (kNPX + 15) / 16;      // 19 pixel tiles
-constexpr int kNB = 5;                      // pixel tiles per read-ahead batch (4 batches: 5 + 5 + 5 + 4)
+constexpr int kPT = 8;                      // pooled tile width
+constexpr int kCT = 2 * kPT + 1;            // conv tile width: 17
+constexpr int kPC = 2 * (kCT - 1) + 7 + 1;  // patch columns: 40 (39 + one: the zero-weight 8th column slot of the last pixel reads it)
+constexpr int kNB = 5;                      // pixel tiles per read-ahead batch
+// PTY: pooled tile height — 8 for the 16-bit types (17 x 17 conv outputs, 19 pixel tiles), 4 for split pairs (9 x 17, 10 tiles: the
+// conv tile in 4-byte slots is 79 KB of LDS at height 8, two workgroups per CU and 186 registers)
+template <int PTY> struct StemGeo {
+  static constexpr int CTY = 2 * PTY + 1;             // conv tile height
+  static constexpr int PR = 2 * (CTY - 1) + 7;        // patch rows
+  static constexpr int NPX = CTY * kCT;               // conv outputs per tile
+  static constexpr int NTL = (NPX + 15) / 16;         // 16-pixel tiles
+};
 
 template <typename T> struct StemMma;
 template <> struct StemMma<unsigned short> {
@@ -38,10 +43,11 @@ template <> struct StemMma<f16_t> {
   }
 };
 
-template <typename T>
+template <typename T, int PTY>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                    const T* __restrict__ wpk, T* __restrict__ out, int B, int V, int S) {
   constexpr bool X3 = std::is_same<T, bx3_t>::value;
+  constexpr int kPR = StemGeo<PTY>::PR, kNPX = StemGeo<PTY>::NPX, kNTL = StemGeo<PTY>::NTL;
   constexpr int EB = (int)sizeof(T);
   constexpr int PXB = 4 * EB;                       // bytes per patch pixel (4 channels): 8 / 16
   constexpr int SROW = 64 * EB + 16;                // staging row (one conv output, 64 channels) + bank spread
@@ -50,14 +56,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   unsigned char* patch = lds;                       // [39][40] pixels
   unsigned char* stg = lds;                         // [289][SROW] conv outputs (after the products; aliases the patch)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int Sc = S / 2, Sp = S / 4, ntx = Sp / kPT;
+  const int Sc = S / 2, Sp = S / 4, ntx = Sp / kPT, nty = Sp / PTY;
   // every XCD (own L2) takes one contiguous eighth of the tiles: neighbours share their patch borders
-  const unsigned ntile = (unsigned)(V * ntx * ntx), per_xcd = (ntile + 7) / 8;
+  const unsigned ntile = (unsigned)(V * ntx * nty), per_xcd = (ntile + 7) / 8;
   const unsigned tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= ntile) return;
-  const int v = (int)(tile / (unsigned)(ntx * ntx));
-  const int rem = (int)(tile - (unsigned)v * (unsigned)(ntx * ntx));
-  const int py0 = (rem / ntx) * kPT, px0 = (rem % ntx) * kPT;
+  const int v = (int)(tile / (unsigned)(ntx * nty));
+  const int rem = (int)(tile - (unsigned)v * (unsigned)(ntx * nty));
+  const int py0 = (rem / ntx) * PTY, px0 = (rem % ntx) * kPT;
   const float* img = v < B ? img1 + (long long)v * 3 * S * S : img2 + (long long)(v - B) * 3 * S * S;
 
   // ---- input patch: rows 4 py0 - 5 .., columns 4 px0 - 5 .. (zero outside the image: the conv's padding) ----
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   constexpr int E = 16 / EB;                        // channels per 16-byte chunk
   constexpr int NCH = 16 / E;                       // chunks per thread
   const int pp = tid >> 2, cg = tid & 3;
+  if (pp >= PTY * kPT) return;                      // a 4-row tile has 32 pooled pixels: half of the threads are done
   const int py = pp >> 3, px = pp & 7;
   float m[16];
 #pragma unroll
@@ -181,15 +188,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   for (int k = 0; k < NCH; ++k) *reinterpret_cast<uint4*>(o + k * E) = pack_chunk(m + k * E, T());
 }
 
-template <typename T>
+template <typename T, int PTY>
 int launch_t(const float* img1, const float* img2, const void* wpk, void* out, int B, int V, int S, hipStream_t s) {
   constexpr int EB = (int)sizeof(T);
-  constexpr int lds_patch = kPR * kPC * 4 * EB, lds_stg = kNPX * (64 * EB + 16);
+  constexpr int lds_patch = StemGeo<PTY>::PR * kPC * 4 * EB, lds_stg = StemGeo<PTY>::NPX * (64 * EB + 16);
   constexpr int lds = lds_patch > lds_stg ? lds_patch : lds_stg;
-  auto kern = stem_kernel<T>;
+  auto kern = stem_kernel<T, PTY>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
-  const int ntx = S / 4 / kPT;
-  const long long ntile = (long long)V * ntx * ntx;
+  const int ntx = S / 4 / kPT, nty = S / 4 / PTY;
+  const long long ntile = (long long)V * ntx * nty;
   RGBM_REQUIRE(ntile > 0 && ntile < (1ll << 30), "stem grid out of range");
   hipLaunchKernelGGL(kern, dim3((unsigned)(((ntile + 7) / 8) * 8)), dim3(256), lds, s, img1, img2, (const T*)wpk, (T*)out, B, V, S);
   RGBM_CHECK_HIP(hipGetLastError());
@@ -211,9 +218,9 @@ void stem_pack(const float* w, std::vector<float>& packed) {
 int launch_stem(int dtype, const float* img1, const float* img2, const void* wpk, void* out, int B, int V, int S, hipStream_t s) {
   RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "stem kernel: 16-bit or split-pair storage");
   RGBM_REQUIRE(S % (4 * kPT) == 0 && V == 2 * B && img1 && img2 && wpk && out, "stem kernel geometry");
-  if (dtype == BF16) return launch_t<unsigned short>(img1, img2, wpk, out, B, V, S, s);
-  if (dtype == F16) return launch_t<f16_t>(img1, img2, wpk, out, B, V, S, s);
-  return launch_t<bx3_t>(img1, img2, wpk, out, B, V, S, s);
+  if (dtype == BF16) return launch_t<unsigned short, 8>(img1, img2, wpk, out, B, V, S, s);
+  if (dtype == F16) return launch_t<f16_t, 8>(img1, img2, wpk, out, B, V, S, s);
+  return launch_t<bx3_t, 4>(img1, img2, wpk, out, B, V, S, s);
 }
 
 }  // namespace rgbm
