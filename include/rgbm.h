@@ -67,7 +67,12 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
  * skip add, the prob conv, softmax and depth are evaluated only on the 3x3 neighbourhoods of the chosen pixels and u11
  * is never written; 0 = dense conv11 + gathering prob kernel), "cost_impl" (3 = 2 with the depth-sweeping conv0 kernel [default for bf16;
  * fp32 nets run 2]; 2 = halo-tiled 3-D convs with the plane-sweep volume fused into conv0's loader; 1 = halo-tiled convs on a materialised volume; 0 = generic implicit
- * GEMM on a materialised volume).  Set before querying the workspace size. */
+ * GEMM on a materialised volume), "igemm_conv6" (1 [default] = conv6 of the cost regularisation on the implicit-GEMM kernel), "upconv" (bit 0 / 1:
+ * PSPUpsample up_1 / up_2 as a 1x1 GEMM at the low resolution + tap combination, bit 2: up_3 + `final` in one kernel from the
+ * half-resolution tensor [16-bit and split-pair nets]; default 7; 0 = x2 resize followed by the 3x3 conv, the reference's operator
+ * order), "stem" (1 [default for 16-bit and split-pair nets] = conv1 7x7 + ReLU + max-pool in one kernel from the NCHW images; 0 = padded
+ * NHWC copy, implicit-GEMM conv, pool kernel — the only path that materialises the `conv1` tap of rgbm_adapose_fetch).
+ * Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
 /* img1/img2 [B,3,224,224] fp32 NCHW normalised; choose1/2 [B,1024] int32; P1/P2 [B,4,4] fp32; depths [B,24] fp32.
