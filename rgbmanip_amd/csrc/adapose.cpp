@@ -274,6 +274,8 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   bf.Pviews = (float*)A.alloc((size_t)V * 16 * 4);
   bf.homog = (float*)A.alloc((size_t)V * 12 * 4);
   bf.choose = (int*)A.alloc(VP * 4);
+  bf.mask9 = (unsigned char*)A.alloc((size_t)V * 64);      // ceil(S/32)^2 <= 64 and ceil(S/64)^2 <= 16 for S <= 256 (checked in cost_volume)
+  bf.mask7 = (unsigned char*)A.alloc((size_t)V * 16);
   bf.feat = A.alloc((size_t)V * S * S * 32 * es);
   bf.featf = dtype == BF16X3 ? (float*)A.alloc((size_t)V * S * S * 32 * 4) : nullptr;
   bf.X0 = (float*)A.alloc(VP * 32 * 4);
@@ -421,7 +423,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
   const bool b16 = dtype_size(dtype) == 2;      // 16-bit storage: the depth-sweeping conv0, implicit-GEMM conv6 and the sparse tail exist for these
   // halo-tiled path (cost_impl >= 1): one launch per layer; conv0 optionally builds its input on the fly
   auto tile = [&](int layer, const void* in, void* out, const void* res, int Vc, int Di, int Hi, int Wi, int Do, int Ho,
-                  int Wo, bool transposed, int v0) -> int {
+                  int Wo, bool transposed, int v0, const unsigned char* tmask = nullptr) -> int {
     const int li = layer == 10 ? 0 : layer;
     Conv3dTileDesc d;
     memset(&d, 0, sizeof(d));
@@ -431,6 +433,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.Cout = t3d[li].Cout; d.relu = 1;
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
     d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
+    d.tile_mask = tmask;
     // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
     d.prof_variant = dtype == BF16X3 ? (layer == 10 ? 28 : 27) : layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
@@ -470,9 +473,20 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     } else {
       if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
     }
-    if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0)) return rc;
-    if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0)) return rc;
-    if (cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail) {
+    // sparse decoder: with the sparse tail below nothing reads u9 outside the chosen pixels' neighbourhoods, nor u7 outside the conv9
+    // tiles that cover them — conv7 / conv9 skip the other tiles (exactly the same numbers wherever they are read)
+    const bool sparse_ok = cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail;
+    const unsigned char *m7 = nullptr, *m9 = nullptr;
+    if (sparse_ok && sparse_dec) {
+      int td, th, tw, ud, uh, uw;
+      RGBM_REQUIRE(!conv3d_tile_dims(7, dtype, &td, &th, &tw) && !conv3d_tile_dims(8, dtype, &ud, &uh, &uw) && th == 8 && tw == 8 &&
+                   uh == 8 && uw == 8 && S <= 256, "sparse decoder: 8 x 8 tiles expected");
+      if (int rc = launch_decoder_tile_masks(bf.choose, v0, Vc, P, S, S, bf.mask9, bf.mask7, s)) return rc;
+      m7 = bf.mask7; m9 = bf.mask9;
+    }
+    if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0, m7)) return rc;
+    if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0, m9)) return rc;
+    if (sparse_ok) {
       // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
       if (int rc = launch_prob_sparse(bf.u9, bf.c[0], dtype == BF16X3 ? w11_x3 : t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob,
                                       bf.depth, v0, Vc, B, P, D, S, S, dtype, s)) return rc;

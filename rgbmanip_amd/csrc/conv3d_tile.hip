@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   const int th = t % d.nth; t /= d.nth;
   const int td = t % d.ntd; t /= d.ntd;
   const int n = t;
+  if (d.tile_mask && !d.tile_mask[((long long)n * d.nth + th) * d.ntw + tw]) return;      // nothing downstream reads this output tile
   const int q0d = td * TD, q0h = th * TH, q0w = tw * TW;
   const int i0d = TR ? q0d : q0d * STRIDE - 1, i0h = TR ? q0h : q0h * STRIDE - 1, i0w = TR ? q0w : q0w * STRIDE - 1;
 
@@ -500,6 +501,18 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
   return 0;
 }
 
+int conv3d_tile_dims(int layer, int dtype, int* TD, int* TH, int* TW) {
+  const bool b16 = dtype == BF16 || dtype == F16;
+#define C3_CASE(L, CIN, COUTP, TDB, THB, TWB, TDF, THF, TWF, STRIDE, TR, WARP, WCB, WCF) \
+  case L: *TD = b16 ? TDB : TDF; *TH = b16 ? THB : THF; *TW = b16 ? TWB : TWF; return 0;
+  switch (layer) {
+#include "conv3d_tile_table.h"
+    default: break;
+  }
+#undef C3_CASE
+  return -1;
+}
+
 // layer ids: 0..6 = conv0..conv6, 7..9 = conv7/9/11 (transposed), 10 = conv0 with fused warp
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s) {
 #define C3_CASE(L, CIN, COUTP, TDB, THB, TWB, TDF, THF, TWF, STRIDE, TR, WARP, WCB, WCF)                           \
@@ -509,18 +522,7 @@ int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_
            : dtype == BF16X3 ? launch_c3<bx3_t, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP, WCF>(d, s)            \
                           : launch_c3<float, CIN, COUTP, TDF, THF, TWF, STRIDE, TR, WARP, 1>(d, s);
   switch (layer) {
-    //        layer cin coutp  bf16 tile   f32 tile   stride tr    warp   channel split of the waves (16-bit, split pairs)
-    C3_CASE(0, 32, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
-    C3_CASE(10, 32, 16, 4, 8, 8, 4, 8, 8, 1, false, true, 1, 1)
-    C3_CASE(1, 8, 16, 2, 8, 8, 2, 8, 8, 2, false, false, 1, 1)
-    C3_CASE(2, 16, 16, 6, 8, 8, 4, 8, 8, 1, false, false, 1, 1)
-    C3_CASE(3, 16, 32, 2, 8, 8, 1, 8, 8, 2, false, false, 2, 2)
-    C3_CASE(4, 32, 32, 3, 8, 8, 3, 8, 8, 1, false, false, 1, 2)
-    C3_CASE(5, 32, 64, 1, 8, 8, 1, 8, 8, 2, false, false, 4, 4)
-    C3_CASE(6, 64, 64, 1, 8, 8, 1, 8, 8, 1, false, false, 1, 1)
-    C3_CASE(7, 64, 32, 3, 8, 8, 1, 8, 8, 1, true, false, 1, 2)
-    C3_CASE(8, 32, 16, 2, 8, 8, 2, 8, 8, 1, true, false, 1, 1)
-    C3_CASE(9, 16, 16, 4, 8, 8, 4, 8, 8, 1, true, false, 1, 1)
+#include "conv3d_tile_table.h"
     default: break;
   }
 #undef C3_CASE

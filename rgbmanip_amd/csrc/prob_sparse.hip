@@ -200,6 +200,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sparse decoder: with the sparse tail, u9 (conv9's output) is read only under the 3 x 3 neighbourhoods of the chosen pixels and
+// u7 (conv7's) only under the conv9 tiles that cover those — the halo-tile kernels of both layers skip every (view, row tile,
+// column tile) whose byte is 0 (Conv3dTileDesc::tile_mask; all depth tiles share it).  8 x 8 tiles of the transposed convs' INPUT
+// grids: conv9 tile t covers half-resolution rows 16 t .. 16 t + 15, conv7 tile t quarter-resolution rows 16 t .. 16 t + 15.
+__global__ __launch_bounds__(256) void decoder_tile_mask_kernel(const int* __restrict__ choose, int v0, int Vc, int P, int H, int W,
+                                                                unsigned char* __restrict__ mask9, int nt9,
+                                                                unsigned char* __restrict__ mask7, int nt7) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)Vc * P) return;
+  const int vl = (int)(i / P);
+  const int pix = choose[(long long)(v0 + vl) * P + (i - (long long)vl * P)];
+  const int y = pix / W, x = pix - y * W;
+  const int Hh = H >> 1, Wh = W >> 1, Hq = H >> 2, Wq = W >> 2;
+  // half-resolution rows / columns of u9 that conv11 reads for full-resolution rows y - 1 .. y + 1 (prob_sparse_kernel: input voxel
+  // (row >> 1) of tap 0 and the one after it)
+  const int r0 = max(y - 1, 0) >> 1, r1 = min((min(y + 1, H - 1) >> 1) + 1, Hh - 1);
+  const int c0 = max(x - 1, 0) >> 1, c1 = min((min(x + 1, W - 1) >> 1) + 1, Wh - 1);
+  for (int a = r0 >> 4; a <= r1 >> 4; ++a)
+    for (int b = c0 >> 4; b <= c1 >> 4; ++b) {
+      mask9[((long long)vl * nt9 + a) * nt9 + b] = 1;
+      // conv9 tile (a, b) reads quarter-resolution rows 8 a .. 8 a + 8 of u7 (its 9-row halo) = conv7 tiles (8 a) >> 4 .. (8 a + 8) >> 4
+      const int q0 = 8 * a, q1 = min(8 * a + 8, Hq - 1), p0 = 8 * b, p1 = min(8 * b + 8, Wq - 1);
+      for (int e = q0 >> 4; e <= q1 >> 4; ++e)
+        for (int f = p0 >> 4; f <= p1 >> 4; ++f) mask7[((long long)vl * nt7 + e) * nt7 + f] = 1;
+    }
+}
+
+// mask9 [Vc][nt9][nt9], mask7 [Vc][nt7][nt7] bytes (nt9 = ceil(W / 4 / 8), nt7 = ceil(W / 8 / 8)); H == W
+int launch_decoder_tile_masks(const int* choose, int v0, int Vc, int P, int H, int W, unsigned char* mask9, unsigned char* mask7,
+                              hipStream_t s) {
+  RGBM_REQUIRE(choose && mask9 && mask7 && H == W && (H % 8) == 0, "decoder tile masks arguments");
+  const int nt9 = (W / 4 + 7) / 8, nt7 = (W / 8 + 7) / 8;
+  RGBM_CHECK_HIP(hipMemsetAsync(mask9, 0, (size_t)Vc * nt9 * nt9, s));
+  RGBM_CHECK_HIP(hipMemsetAsync(mask7, 0, (size_t)Vc * nt7 * nt7, s));
+  const long long n = (long long)Vc * P;
+  hipLaunchKernelGGL(decoder_tile_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, choose, v0, Vc, P, H, W, mask9, nt9, mask7, nt7);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
                        int D, int H, int W, int dtype, hipStream_t s) {

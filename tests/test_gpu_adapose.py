@@ -146,7 +146,8 @@ def test_per_sample_batchnorm_matches_reference_train_mode_golden(inputs, golden
 def test_bf16x3_intermediates_vs_oracle(inputs, oracle_taps):
     """Stage taps of the split-pair mode against the oracle: every stage inside the fp32 gate."""
     _, taps = oracle_taps
-    net = _net("bf16x3", options={"stem": 0})      # the `conv1` tap exists only on the unfused stem path (the fused one: test_stem_*)
+    # the `conv1` tap exists only on the unfused stem path (the fused one: test_stem_*), the whole `u9` volume only with the dense decoder
+    net = _net("bf16x3", options={"stem": 0, "sparse_dec": 0})
     B, V = 2, 4
     _run(net, inputs, stop_after=1)
 
