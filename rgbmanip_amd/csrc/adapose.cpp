@@ -274,8 +274,9 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   bf.Pviews = (float*)A.alloc((size_t)V * 16 * 4);
   bf.homog = (float*)A.alloc((size_t)V * 12 * 4);
   bf.choose = (int*)A.alloc(VP * 4);
-  bf.mask9 = (unsigned char*)A.alloc((size_t)V * 64);      // ceil(S/32)^2 <= 64 and ceil(S/64)^2 <= 16 for S <= 256 (checked in cost_volume)
-  bf.mask7 = (unsigned char*)A.alloc((size_t)V * 16);
+  bf.masks = (unsigned char*)A.alloc((size_t)V * sparse_mask_bytes_per_view(img));
+  bf.sweep_list = (int*)A.alloc((size_t)V * ((img + 11) / 12) * ((img + 15) / 16) * 4);
+  bf.sweep_count = (int*)A.alloc(256);
   bf.feat = A.alloc((size_t)V * S * S * 32 * es);
   bf.featf = dtype == BF16X3 ? (float*)A.alloc((size_t)V * S * S * 32 * 4) : nullptr;
   bf.X0 = (float*)A.alloc(VP * 32 * 4);
@@ -422,6 +423,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
   const int Vc0 = chunk_views(V);
   const bool b16 = dtype_size(dtype) == 2;      // 16-bit storage: the depth-sweeping conv0, implicit-GEMM conv6 and the sparse tail exist for these
   // halo-tiled path (cost_impl >= 1): one launch per layer; conv0 optionally builds its input on the fly
+  bool sweep_sparse = false;      // set per chunk below: the depth-sweeping conv0 walks the list of needed tiles
   auto tile = [&](int layer, const void* in, void* out, const void* res, int Vc, int Di, int Hi, int Wi, int Do, int Ho,
                   int Wo, bool transposed, int v0, const unsigned char* tmask = nullptr) -> int {
     const int li = layer == 10 ? 0 : layer;
@@ -434,6 +436,8 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     d.feat = bf.feat; d.homog = bf.homog; d.depths = depths; d.v0 = v0; d.V = V; d.B = B;
     d.out_classmajor = layer == 9 ? 1 : 0;      // u11 is only gathered sparsely by the prob kernel
     d.tile_mask = tmask;
+    d.tile_mask_stride = sparse_mask_bytes_per_view(S);
+    if (layer == 10 && sweep_sparse) { d.tile_list = bf.sweep_list; d.tile_count = bf.sweep_count; }
     // profiler rows (prof.h): conv0 + fused warp on its own; bf16 layers one row each, f32 layers aggregated
     d.prof_variant = dtype == BF16X3 ? (layer == 10 ? 28 : 27) : layer == 10 ? 10 + (dtype != F32 ? 1 : 0) : (dtype != F32 ? 16 + layer : 8);
     d.algo_flops = 2.0 * Vc * (double)(transposed ? Di * Hi * Wi : Do * Ho * Wo) * t3d[li].Cout * 27.0 * t3d[li].Cin;
@@ -454,39 +458,46 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     }
     return launch_conv3d_tile(layer, dtype, d, s);
   };
+  // Sparse cost regularisation (sparse_dec, with the sparse tail only): the tail reads the probability volume at the chosen pixels, so every
+  // layer is needed only inside their dependency cones (prob_sparse.hip: sparse_mask_kernel) — conv1 .. conv5, conv7 / conv9 skip the
+  // other tiles, the depth-sweeping conv0 walks the list of needed ones.  conv6 stays dense (a 0.3 ms GEMM): what it computes from
+  // unwritten input tiles is never read by anything that is read.
+  const bool sparse_ok = norm_mode == 0 && cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail && sweep_w != nullptr &&
+                         !(g_debug_flags & 4096);
   for (int v0 = 0; norm_mode == 0 && cost_impl >= 1 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+    const unsigned char* mk[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    sweep_sparse = false;
+    if (sparse_ok && sparse_dec) {
+      int td, th, tw;
+      for (int L : {1, 2, 3, 4, 5, 7, 8}) RGBM_REQUIRE(!conv3d_tile_dims(L, dtype, &td, &th, &tw) && th == 8 && tw == 8, "sparse cost regularisation: 8 x 8 tiles expected");
+      if (int rc = launch_sparse_masks(bf.choose, v0, Vc, P, S, bf.masks, bf.sweep_list, bf.sweep_count, s)) return rc;
+      for (int L : {7, 8}) mk[L] = bf.masks + sparse_mask_offset(S, L);
+      if (sparse_dec >= 2) {
+        for (int L : {1, 2, 3, 4, 5}) mk[L] = bf.masks + sparse_mask_offset(S, L);
+        sweep_sparse = true;
+      }
+    }
     if (cost_impl == 1) {
       if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
       if (int rc = tile(0, bf.vol, bf.c[0], nullptr, Vc, D, S, S, D, S, S, false, v0)) return rc;
     } else {
       if (int rc = tile(10, nullptr, bf.c[0], nullptr, Vc, D, S, S, D, S, S, false, v0)) return rc;
     }
-    if (int rc = tile(1, bf.c[0], bf.c[1], nullptr, Vc, D, S, S, D / 2, S / 2, S / 2, false, v0)) return rc;
-    if (int rc = tile(2, bf.c[1], bf.c[2], nullptr, Vc, D / 2, S / 2, S / 2, D / 2, S / 2, S / 2, false, v0)) return rc;
-    if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0)) return rc;
-    if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0)) return rc;
-    if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0)) return rc;
+    if (int rc = tile(1, bf.c[0], bf.c[1], nullptr, Vc, D, S, S, D / 2, S / 2, S / 2, false, v0, mk[1])) return rc;
+    if (int rc = tile(2, bf.c[1], bf.c[2], nullptr, Vc, D / 2, S / 2, S / 2, D / 2, S / 2, S / 2, false, v0, mk[2])) return rc;
+    if (int rc = tile(3, bf.c[2], bf.c[3], nullptr, Vc, D / 2, S / 2, S / 2, D / 4, S / 4, S / 4, false, v0, mk[3])) return rc;
+    if (int rc = tile(4, bf.c[3], bf.c[4], nullptr, Vc, D / 4, S / 4, S / 4, D / 4, S / 4, S / 4, false, v0, mk[4])) return rc;
+    if (int rc = tile(5, bf.c[4], bf.c[5], nullptr, Vc, D / 4, S / 4, S / 4, D / 8, S / 8, S / 8, false, v0, mk[5])) return rc;
     if (cost_impl == 3 && (b16 || dtype == BF16X3) && igemm_conv6) {
       // conv6 (64 -> 64, K = 27 x 64): a plain GEMM shape, 2.7x faster on the role-specialised implicit-GEMM kernel
       if (int rc = c3d[6].run(bf.c[5], bf.c[6], Vc, D / 8, S / 8, S / 8, 64, nullptr, RES_NONE, nullptr, 0, s)) return rc;
     } else {
       if (int rc = tile(6, bf.c[5], bf.c[6], nullptr, Vc, D / 8, S / 8, S / 8, D / 8, S / 8, S / 8, false, v0)) return rc;
     }
-    // sparse decoder: with the sparse tail below nothing reads u9 outside the chosen pixels' neighbourhoods, nor u7 outside the conv9
-    // tiles that cover them — conv7 / conv9 skip the other tiles (exactly the same numbers wherever they are read)
-    const bool sparse_ok = cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail;
-    const unsigned char *m7 = nullptr, *m9 = nullptr;
-    if (sparse_ok && sparse_dec) {
-      int td, th, tw, ud, uh, uw;
-      RGBM_REQUIRE(!conv3d_tile_dims(7, dtype, &td, &th, &tw) && !conv3d_tile_dims(8, dtype, &ud, &uh, &uw) && th == 8 && tw == 8 &&
-                   uh == 8 && uw == 8 && S <= 256, "sparse decoder: 8 x 8 tiles expected");
-      if (int rc = launch_decoder_tile_masks(bf.choose, v0, Vc, P, S, S, bf.mask9, bf.mask7, s)) return rc;
-      m7 = bf.mask7; m9 = bf.mask9;
-    }
-    if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0, m7)) return rc;
-    if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0, m9)) return rc;
-    if (sparse_ok) {
+    if (int rc = tile(7, bf.c[6], bf.u7, bf.c[4], Vc, D / 8, S / 8, S / 8, D / 4, S / 4, S / 4, true, v0, mk[7])) return rc;
+    if (int rc = tile(8, bf.u7, bf.u9, bf.c[2], Vc, D / 4, S / 4, S / 4, D / 2, S / 2, S / 2, true, v0, mk[8])) return rc;
+    if (cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail) {
       // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
       if (int rc = launch_prob_sparse(bf.u9, bf.c[0], dtype == BF16X3 ? w11_x3 : t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob,
                                       bf.depth, v0, Vc, B, P, D, S, S, dtype, s)) return rc;

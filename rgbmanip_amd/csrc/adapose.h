@@ -38,7 +38,7 @@ struct AdaPose {
   int n_blocks = 0;
   ConvLayer psp[4], up1, up2, up3, fin;
   UpConvLayer up1c, up2c;       // up_1 / up_2 as a low-resolution 1x1 GEMM + tap combination (upconv.hip)
-  int sparse_dec = 1;           // with the sparse tail: conv7 / conv9 only on the tiles the chosen pixels' neighbourhoods need (0 = dense, for A/B and the u7 / u9 taps)
+  int sparse_dec = 2;           // with the sparse tail: 2 = every 3-D layer (and the plane sweep) only on the tiles inside the chosen pixels' dependency cones, 1 = conv7 / conv9 only, 0 = dense (A/B, and the c0 .. u9 taps)
   void* stem_w = nullptr;       // conv1 packed for the one-kernel stem (stem.hip; 16-bit and split-pair storage)
   int stem = 0;                 // 1: NCHW images -> conv1 7x7 + ReLU + max-pool in one kernel (default for 16-bit and split-pair storage, set in create()); 0: copy, implicit-GEMM conv, pool (materialises `conv1`)
   UpConvFinal tail;             // up_3 + final in one kernel (upconv_final.hip; 16-bit and split-pair storage)
@@ -68,7 +68,8 @@ struct AdaPose {
 
   struct Buffers {
     float *Pviews, *homog; int* choose; void* feat;
-    unsigned char *mask9, *mask7;   // sparse decoder: needed tiles of conv9 / conv7 per view of a cost-volume chunk
+    unsigned char* masks;           // sparse cost regularisation: tile masks of the 3-D layers per view of a cost-volume chunk (prob_sparse.hip)
+    int *sweep_list, *sweep_count;  // ... and the needed tiles of the depth-sweeping conv0
     float* featf;                      // bf16x3 nets: plain fp32 copy of feat (what the plane sweep and the point heads gather from)
     float *X0, *X1, *H128, *H64, *nocs4, *N32, *PF96, *prob, *depth, *Q128a, *Q128b, *G256a, *G256b;
     void* PF96h;                       // fp16 copy of PF96 (pose MLP input of 16-bit nets)

@@ -84,6 +84,7 @@ struct SweepDesc {
   const float* depths;            // [B][D]
   unsigned short* out;            // [N][D][H][W][8] bf16
   int N, D, H, W, v0, V, B, nth, ntw, relu, dbg;
+  const int* tile_list; const int* tile_count;      // sparse cost regularisation: only these tiles (ascending), else null
 };
 
 struct Corner {                     // everything the blend of one plane needs besides the gathered data
@@ -177,8 +178,13 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
 
   // XCD-aware tile order: every XCD walks a contiguous run of tiles (whole views) so the partner feature maps its CUs
   // gather from stay in that XCD's L2
-  const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  // (with a tile list the launch still covers every tile: workgroups past the list's end leave at once)
+  const int nblk = d.tile_list ? d.tile_count[0] : (int)gridDim.x;
+  if ((int)blockIdx.x >= nblk) return;
+  const int bq = nblk >> 3, br = nblk & 7, xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  // blocks xcd, xcd + 8, ... < nblk: XCD xcd owns (nblk - xcd + 7) / 8 = bq + (xcd < br) of them
   int t = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+  if (d.tile_list) t = d.tile_list[t];
   const int tw = t % d.ntw; t /= d.ntw;
   const int th = t % d.nth; t /= d.nth;
   const int n = t;
@@ -497,7 +503,9 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   d.N = t.N; d.D = t.Di; d.H = t.Hi; d.W = t.Wi; d.v0 = t.v0; d.V = t.V; d.B = t.B; d.relu = t.relu;
   d.nth = (d.H + SW_TH - 1) / SW_TH; d.ntw = (d.W + SW_TW - 1) / SW_TW;
   d.dbg = g_debug_flags;
+  d.tile_list = t.tile_list; d.tile_count = t.tile_count;
   RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep arguments");
+  RGBM_REQUIRE((d.tile_list == nullptr) == (d.tile_count == nullptr), "conv0 sweep: tile list and count go together");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short>), SW_LDS)) return rc;

@@ -60,6 +60,7 @@ struct Sweep3Desc {
   const float* depths;      // [B][D]
   bx3_t* out;               // [N][D][H][W][8]
   int N, D, H, W, v0, V, B, nth, ntw, relu, n_tiles;
+  const int* tile_list; const int* tile_count;      // sparse cost regularisation: only these tiles (ascending), else null
 };
 
 struct Corner3 {
@@ -104,13 +105,15 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = d.D, H = d.H, W = d.W;
-  const int n_my = (d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int n_tiles = d.tile_list ? d.tile_count[0] : d.n_tiles;      // wave-uniform: every role walks the same tiles
+  const int n_my = n_tiles > (int)blockIdx.x ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   // XCD-aware tile order (the grid is a multiple of 8): every XCD walks a contiguous run of tiles, i.e. whole views, so the
   // partner feature maps its CUs gather from stay in that XCD's L2
   auto tile_of = [&](int k, int& n, int& h0, int& w0) {
     const int v = (int)blockIdx.x + k * (int)gridDim.x;
-    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
+    const int nblk = n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
     int t = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+    if (d.tile_list) t = d.tile_list[t];
     const int tw = t % d.ntw; t /= d.ntw;
     const int th = t % d.nth; t /= d.nth;
     n = t; h0 = th * X3_TH; w0 = tw * X3_TW;
@@ -624,6 +627,8 @@ int launch_conv0_sweep_x3(const Conv3dTileDesc& t, hipStream_t s) {
   const long long ntiles = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31), "conv0 sweep grid out of range");
   d.n_tiles = (int)ntiles;
+  d.tile_list = t.tile_list; d.tile_count = t.tile_count;
+  RGBM_REQUIRE((d.tile_list == nullptr) == (d.tile_count == nullptr), "conv0 sweep: tile list and count go together");
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_x3_kernel), X3_LDS)) return rc;
   int n_cu = 0;
   if (int rc = persistent_grid_cus(&n_cu)) return rc;

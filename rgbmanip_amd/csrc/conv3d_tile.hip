@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   const int th = t % d.nth; t /= d.nth;
   const int td = t % d.ntd; t /= d.ntd;
   const int n = t;
-  if (d.tile_mask && !d.tile_mask[((long long)n * d.nth + th) * d.ntw + tw]) return;      // nothing downstream reads this output tile
+  if (d.tile_mask && !d.tile_mask[(long long)n * (d.tile_mask_stride ? d.tile_mask_stride : d.nth * d.ntw) + th * d.ntw + tw]) return;      // nothing downstream reads this output tile
   const int q0d = td * TD, q0h = th * TH, q0w = tw * TW;
   const int i0d = TR ? q0d : q0d * STRIDE - 1, i0h = TR ? q0h : q0h * STRIDE - 1, i0w = TR ? q0w : q0w * STRIDE - 1;
 

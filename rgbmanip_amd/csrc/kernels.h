@@ -65,6 +65,8 @@ struct Conv3dTileDesc {
   int prof_variant; double algo_flops, algo_bytes;
   int out_classmajor;           // transposed only: write each sub-pixel class as its own dense [N][Dq][Hq][Wq][C] volume
   int dbg;                      // ablation bits (benchmark only): 1 = skip halo staging work, 2 = skip the MFMA phase
+  const int* tile_list; const int* tile_count;      // depth-sweeping conv0 only: walk tile_list[0 .. tile_count[0]) instead of all tiles
+  int tile_mask_stride;             // bytes between consecutive views' masks (0: nth * ntw)
   const unsigned char* tile_mask;   // optional [N][nth][ntw]: a workgroup whose (view, row tile, column tile) byte is 0 returns at once (its
                                     // output tile is never read: sparse decoder, see launch_decoder_tile_masks); all depth tiles share a byte
 };
@@ -72,9 +74,12 @@ extern int g_debug_flags;
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed);
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);
-// prob_sparse.hip: which conv9 / conv7 tiles the sparse tail needs (bytes [Vc][nt][nt], nt9 = ceil(W/32), nt7 = ceil(W/64))
-int launch_decoder_tile_masks(const int* choose, int v0, int Vc, int P, int H, int W, unsigned char* mask9, unsigned char* mask7,
-                              hipStream_t s);
+// prob_sparse.hip: sparse cost regularisation — tile masks of every 3-D layer from the chosen pixels' dependency cones, and the
+// compacted tile list of the depth-sweeping conv0 (layer ids as launch_conv3d_tile's; 0 = the sweep)
+int sparse_mask_bytes_per_view(int S);
+int sparse_mask_offset(int S, int layer);
+int launch_sparse_masks(const int* choose, int v0, int Vc, int P, int S, unsigned char* masks, int* sweep_list, int* sweep_count,
+                        hipStream_t s);
 // tile grid of a layer's halo-tile kernel in the given storage type (for sizing Conv3dTileDesc::tile_mask)
 int conv3d_tile_dims(int layer, int dtype, int* TD, int* TH, int* TW);
 

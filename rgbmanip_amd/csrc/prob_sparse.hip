@@ -201,42 +201,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Sparse decoder: with the sparse tail, u9 (conv9's output) is read only under the 3 x 3 neighbourhoods of the chosen pixels and
-// u7 (conv7's) only under the conv9 tiles that cover those — the halo-tile kernels of both layers skip every (view, row tile,
-// column tile) whose byte is 0 (Conv3dTileDesc::tile_mask; all depth tiles share it).  8 x 8 tiles of the transposed convs' INPUT
-// grids: conv9 tile t covers half-resolution rows 16 t .. 16 t + 15, conv7 tile t quarter-resolution rows 16 t .. 16 t + 15.
-__global__ __launch_bounds__(256) void decoder_tile_mask_kernel(const int* __restrict__ choose, int v0, int Vc, int P, int H, int W,
-                                                                unsigned char* __restrict__ mask9, int nt9,
-                                                                unsigned char* __restrict__ mask7, int nt7) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)Vc * P) return;
-  const int vl = (int)(i / P);
-  const int pix = choose[(long long)(v0 + vl) * P + (i - (long long)vl * P)];
-  const int y = pix / W, x = pix - y * W;
-  const int Hh = H >> 1, Wh = W >> 1, Hq = H >> 2, Wq = W >> 2;
-  // half-resolution rows / columns of u9 that conv11 reads for full-resolution rows y - 1 .. y + 1 (prob_sparse_kernel: input voxel
-  // (row >> 1) of tap 0 and the one after it)
-  const int r0 = max(y - 1, 0) >> 1, r1 = min((min(y + 1, H - 1) >> 1) + 1, Hh - 1);
-  const int c0 = max(x - 1, 0) >> 1, c1 = min((min(x + 1, W - 1) >> 1) + 1, Wh - 1);
-  for (int a = r0 >> 4; a <= r1 >> 4; ++a)
-    for (int b = c0 >> 4; b <= c1 >> 4; ++b) {
-      mask9[((long long)vl * nt9 + a) * nt9 + b] = 1;
-      // conv9 tile (a, b) reads quarter-resolution rows 8 a .. 8 a + 8 of u7 (its 9-row halo) = conv7 tiles (8 a) >> 4 .. (8 a + 8) >> 4
-      const int q0 = 8 * a, q1 = min(8 * a + 8, Hq - 1), p0 = 8 * b, p1 = min(8 * b + 8, Wq - 1);
-      for (int e = q0 >> 4; e <= q1 >> 4; ++e)
-        for (int f = p0 >> 4; f <= p1 >> 4; ++f) mask7[((long long)vl * nt7 + e) * nt7 + f] = 1;
-    }
+// Sparse cost regularisation.  With the sparse tail the network reads the probability volume only at the chosen pixels, so every
+// tensor of the 3-D U-Net is needed only inside the dependency cone of those pixels: per axis and per chosen coordinate y the
+// needed index interval of each tensor follows from the layers' geometry (network_v5.py:260-291; Conv3d k3 p1 stride 1: i-1..i+1,
+// stride 2: 2i-1..2i+1; ConvTranspose3d k3 s2 p1 op1: output o reads inputs floor(o/2)..ceil(o/2); skips read their own index):
+//     u11 [y-1, y+1] -> u9 -> u7 -> c6 -> c5 -> c4 (input of conv5, and skip of u7) -> c3 -> c2 (input of conv3, skip of u9) -> c1
+//     -> c0 (input of conv1, skip of u11): +-29 pixels around a chosen pixel at full resolution.
+// A point's needed set is the product of its row and column intervals; a tile of a layer is needed if it intersects the box of
+// any point of its view (all depths are needed).  Unneeded tiles are never computed: what is read later never depends on them
+// (convolutions are local), so the numbers that reach the outputs are unchanged bit for bit.  One workgroup per view builds the
+// eight tile masks in LDS; a second kernel compacts the depth-sweeping conv0's needed tiles into a list (its kernels walk it).
+namespace {
+struct Ival { int a, b; };
+__device__ __forceinline__ Ival iv_clamp(int a, int b, int n) { return Ival{a < 0 ? 0 : a, b > n - 1 ? n - 1 : b}; }
+__device__ __forceinline__ Ival iv_tr(Ival o, int n_in) { return iv_clamp(o.a >> 1, (o.b + 1) >> 1, n_in); }      // transposed conv: inputs of outputs [a, b]
+__device__ __forceinline__ Ival iv_s1(Ival o, int n_in) { return iv_clamp(o.a - 1, o.b + 1, n_in); }
+__device__ __forceinline__ Ival iv_s2(Ival o, int n_in) { return iv_clamp(2 * o.a - 1, 2 * o.b + 1, n_in); }
+__device__ __forceinline__ Ival iv_or(Ival p, Ival q) { return Ival{p.a < q.a ? p.a : q.a, p.b > q.b ? p.b : q.b}; }
+struct Cone { Ival c0, c1, c2, c3, c4, c5, u7, u9; };
+__device__ __forceinline__ Cone cone_of(int y, int S) {
+  Cone k;
+  const Ival u11 = iv_clamp(y - 1, y + 1, S);
+  k.u9 = iv_tr(u11, S / 2);
+  k.u7 = iv_tr(k.u9, S / 4);
+  const Ival c6 = iv_tr(k.u7, S / 8);
+  k.c5 = iv_s1(c6, S / 8);
+  k.c4 = iv_or(iv_s2(k.c5, S / 4), k.u7);
+  k.c3 = iv_s1(k.c4, S / 4);
+  k.c2 = iv_or(iv_s2(k.c3, S / 2), k.u9);
+  k.c1 = iv_s1(k.c2, S / 2);
+  k.c0 = iv_or(iv_s2(k.c1, S), u11);
+  return k;
+}
+__device__ __forceinline__ void mark(unsigned char* m, int nw, Ival r, Ival c, int shr_r, int div_r, int shr_c, int div_c) {
+  // tiles = index / div (div > 0) or index >> shr
+  const int ra = div_r ? r.a / div_r : r.a >> shr_r, rb = div_r ? r.b / div_r : r.b >> shr_r;
+  const int ca = div_c ? c.a / div_c : c.a >> shr_c, cb = div_c ? c.b / div_c : c.b >> shr_c;
+  for (int i = ra; i <= rb; ++i)
+    for (int j = ca; j <= cb; ++j) m[i * nw + j] = 1;
+}
+}  // namespace
+
+// mask layout per view (bytes, row-major [rows][cols] of each layer's tile grid; S = crop size, 8 x 8-cell tiles for the halo-tile
+// kernels, 12 x 16 pixels for the depth-sweeping conv0): offsets in SparseMaskLayout
+struct SparseMaskLayout {
+  int n0h, n0w, n1, n3, n5;      // tile grids: sweep n0h x n0w; conv1 / conv2 n1 x n1 (half resolution); conv3 / conv4 / conv9 n3 x n3; conv5 / conv7 n5 x n5
+  int o0, o1, o2, o3, o4, o5, o7, o9, total;
+};
+static SparseMaskLayout sparse_mask_layout(int S) {
+  SparseMaskLayout L;
+  L.n0h = (S + 11) / 12; L.n0w = (S + 15) / 16; L.n1 = (S / 2 + 7) / 8; L.n3 = (S / 4 + 7) / 8; L.n5 = (S / 8 + 7) / 8;
+  int o = 0;
+  L.o0 = o; o += L.n0h * L.n0w;
+  L.o1 = o; o += L.n1 * L.n1;
+  L.o2 = o; o += L.n1 * L.n1;
+  L.o3 = o; o += L.n3 * L.n3;
+  L.o4 = o; o += L.n3 * L.n3;
+  L.o5 = o; o += L.n5 * L.n5;
+  L.o7 = o; o += L.n5 * L.n5;
+  L.o9 = o; o += L.n3 * L.n3;
+  L.total = (o + 15) & ~15;
+  return L;
+}
+int sparse_mask_bytes_per_view(int S) { return sparse_mask_layout(S).total; }
+int sparse_mask_offset(int S, int layer) {      // layer: 0 = sweep, 1..5 = conv1..conv5, 7 = conv7, 8 = conv9 (launch_conv3d_tile's ids)
+  const SparseMaskLayout L = sparse_mask_layout(S);
+  switch (layer) { case 0: return L.o0; case 1: return L.o1; case 2: return L.o2; case 3: return L.o3; case 4: return L.o4;
+                   case 5: return L.o5; case 7: return L.o7; case 8: return L.o9; default: return -1; }
 }
 
-// mask9 [Vc][nt9][nt9], mask7 [Vc][nt7][nt7] bytes (nt9 = ceil(W / 4 / 8), nt7 = ceil(W / 8 / 8)); H == W
-int launch_decoder_tile_masks(const int* choose, int v0, int Vc, int P, int H, int W, unsigned char* mask9, unsigned char* mask7,
-                              hipStream_t s) {
-  RGBM_REQUIRE(choose && mask9 && mask7 && H == W && (H % 8) == 0, "decoder tile masks arguments");
-  const int nt9 = (W / 4 + 7) / 8, nt7 = (W / 8 + 7) / 8;
-  RGBM_CHECK_HIP(hipMemsetAsync(mask9, 0, (size_t)Vc * nt9 * nt9, s));
-  RGBM_CHECK_HIP(hipMemsetAsync(mask7, 0, (size_t)Vc * nt7 * nt7, s));
-  const long long n = (long long)Vc * P;
-  hipLaunchKernelGGL(decoder_tile_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, choose, v0, Vc, P, H, W, mask9, nt9, mask7, nt7);
+__global__ __launch_bounds__(256) void sparse_mask_kernel(const int* __restrict__ choose, int v0, int P, int S, SparseMaskLayout L,
+                                                          unsigned char* __restrict__ masks) {
+  __shared__ unsigned char m[2048];
+  const int vl = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < L.total; i += 256) m[i] = 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    const int pix = choose[(long long)(v0 + vl) * P + p];
+    const int y = pix / S, x = pix - y * S;
+    const Cone r = cone_of(y, S), c = cone_of(x, S);
+    mark(m + L.o0, L.n0w, r.c0, c.c0, 0, 12, 0, 16);
+    mark(m + L.o1, L.n1, r.c1, c.c1, 3, 0, 3, 0);
+    mark(m + L.o2, L.n1, r.c2, c.c2, 3, 0, 3, 0);
+    mark(m + L.o3, L.n3, r.c3, c.c3, 3, 0, 3, 0);
+    mark(m + L.o4, L.n3, r.c4, c.c4, 3, 0, 3, 0);
+    mark(m + L.o5, L.n5, r.c5, c.c5, 3, 0, 3, 0);
+    mark(m + L.o7, L.n5, r.u7, c.u7, 4, 0, 4, 0);      // transposed: the tile grid is the INPUT grid, two output cells per input cell
+    mark(m + L.o9, L.n3, r.u9, c.u9, 4, 0, 4, 0);
+  }
+  __syncthreads();
+  for (int i = tid; i < L.total; i += 256) masks[(long long)vl * L.total + i] = m[i];
+}
+
+// needed tiles of the depth-sweeping conv0 in ascending order: list[i] = (view * n0h + row tile) * n0w + column tile, count[0] = how many
+__global__ __launch_bounds__(1024) void sparse_sweep_list_kernel(const unsigned char* __restrict__ masks, int Vc, SparseMaskLayout L,
+                                                                 int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int part[1024];
+  const int per_view = L.n0h * L.n0w, total = Vc * per_view, tid = threadIdx.x;
+  const int chunk = (total + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += masks[(long long)(i / per_view) * L.total + L.o0 + i % per_view] ? 1 : 0;
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {      // inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int o = part[tid] - c;
+  for (int i = lo; i < hi; ++i)
+    if (masks[(long long)(i / per_view) * L.total + L.o0 + i % per_view]) list[o++] = i;
+  if (tid == 1023) count[0] = part[1023];
+}
+
+// masks: Vc * sparse_mask_bytes_per_view(S) bytes; sweep_list: Vc * ceil(S/12) * ceil(S/16) ints; sweep_count: 1 int
+int launch_sparse_masks(const int* choose, int v0, int Vc, int P, int S, unsigned char* masks, int* sweep_list, int* sweep_count,
+                        hipStream_t s) {
+  RGBM_REQUIRE(choose && masks && sweep_list && sweep_count && S % 8 == 0 && S >= 16 && Vc > 0, "sparse masks arguments");
+  const SparseMaskLayout L = sparse_mask_layout(S);
+  RGBM_REQUIRE(L.total <= 2048, "sparse masks: crop too large for the mask kernel's LDS table");
+  hipLaunchKernelGGL(sparse_mask_kernel, dim3((unsigned)Vc), dim3(256), 0, s, choose, v0, P, S, L, masks);
+  hipLaunchKernelGGL(sparse_sweep_list_kernel, dim3(1), dim3(1024), 0, s, masks, Vc, L, sweep_list, sweep_count);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

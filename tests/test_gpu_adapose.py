@@ -221,7 +221,7 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps):
     _, taps = oracle_taps
     c0 = {}
     for ci in (2, 3):
-        net = _net("bf16", cost_impl=ci)
+        net = _net("bf16", cost_impl=ci, options={"sparse_dec": 0})      # the whole c0 volume is compared: no tile skipping
         _run(net, inputs, stop_after=2)
         c0[ci] = net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).view(4, 24, 224, 224, 8).cpu().numpy()
     scale = np.abs(c0[2]).max()
@@ -554,7 +554,7 @@ def test_fp16_sweep_conv0_stable_and_matches_tile_conv0(inputs):
     def c0(flag):
         _lib.check(lib.rgbm_debug_flags(flag))
         try:
-            net = _net("fp16", cost_impl=3)
+            net = _net("fp16", cost_impl=3, options={"sparse_dec": 0})      # whole c0 volume
             _run(net, inputs, stop_after=2)
             return net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).view(4, 24, 224, 224, 8).float().cpu().numpy()
         finally:

@@ -141,6 +141,33 @@ def test_upconv_path_equals_resize_then_conv_at_batch(inputs256, dtype, upconv):
         assert e < (tol if tol else 2 * GATE_BF16[k.split("_")[1]]), (k, e)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "fp16"])
+def test_sparse_cost_regularisation_is_bit_identical_to_dense(inputs256, dtype):
+    """Option sparse_dec = 2 (default: plane sweep, conv1 .. conv5, conv7, conv9 only on the tiles inside the chosen pixels'
+    dependency cones) and 1 (conv7 / conv9 only) against 0 (every layer dense) at B = 32: all ten outputs must agree BIT FOR BIT —
+    nothing that is read may depend on a skipped tile.  Four poses get adversarial pixel sets: a 32 x 32 block in the top-left
+    corner, the last rows of the crop, one pixel repeated 1024 times, and pixels scattered over the whole crop (nothing to skip)."""
+    args = _dev_inputs(inputs256, 32)
+    g = torch.Generator().manual_seed(11)
+    for ch in (args[1], args[3]):                      # choose1, choose2: [B, 1024] pixel indices of the 224 x 224 crop
+        yy, xx = torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij")
+        ch[0] = (yy * 224 + xx).reshape(-1).to(ch)
+        ch[1] = torch.arange(224 * 224 - 1024, 224 * 224).to(ch)
+        ch[2] = torch.full((1024,), 100 * 224 + 7).to(ch)
+        ch[3] = torch.sort(torch.randperm(224 * 224, generator=g)[:1024])[0].to(ch)
+    outs = {}
+    for sd in (0, 1, 2):
+        net = _net(dtype, options={"sparse_dec": sd})
+        _forward(net, args)                                                # twice: the second run sees the first one's values in the skipped tiles
+        outs[sd] = {k: v.clone() for k, v in _forward(net, args).items()}
+    for sd in (1, 2):
+        for k in OUT_KEYS:
+            assert torch.equal(outs[sd][k].view(torch.int32), outs[0][k].view(torch.int32)), (dtype, sd, k,
+                                                                                                float((outs[sd][k] - outs[0][k]).abs().max()))
+    for k in OUT_KEYS:
+        assert torch.isfinite(outs[2][k]).all(), k
+
+
 @pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "fp16"])
 def test_one_kernel_stem_equals_copy_conv_pool(inputs256, dtype):
     """conv1 7x7 + ReLU + max-pool in one kernel from the NCHW images (option stem = 1, the 16-bit default) against the padded copy,
