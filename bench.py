@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32", "bf16x3"], help="storage type of the mixed-object leg (configs[4] names fp16)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense-cost-regularisation leg (option sparse_dec = 0) of the headline dtype")
     ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
     ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel A/B switches (rgbm_debug_flags); a non-zero value is echoed in config")
@@ -327,6 +328,36 @@ def main():
             modes_res[md] = {"poses_per_sec": round(B / mdt, 1), "ms_per_step": round(mdt * 1e3, 2), "batch": B, "steps": args.mode_steps,
                              "accuracy": macc}
             del mnet2
+            torch.cuda.empty_cache()
+
+    # ---- how much of the cost regularisation the benched inputs need (option sparse_dec: the 3-D layers and the plane sweep run only inside
+    # the chosen pixels' dependency cones), and the same step with every layer dense ----
+    sparse_res = None
+    if rank == 0 and world == 1 and args.dtype != "fp32":
+        from rgbmanip_amd.adapose import sweep_tiles_needed_fraction
+        frac = sweep_tiles_needed_fraction(torch.cat([d["choose1"][:16], d["choose2"][:16]]).cpu().numpy())      # the batch tiles 16 unique poses
+        sparse_res = {"enabled": True, "sweep_tiles_needed_frac": round(frac, 4),
+                      "note": "exact: outputs are bit-identical to the dense computation (tests/test_gpu_at_batch.py); data dependent: the synthetic "
+                              "masks are ellipses covering 5-50 % of the crop, pixels scattered over the whole crop need every tile"}
+        if not args.no_dense_leg:
+            dnet = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank, max_chunk_views=args.chunk or None,
+                              options={"sparse_dec": 0})
+
+            def dstep():
+                o = dnet(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
+                return postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"])
+            for _ in range(args.warmup):
+                dstep()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                dstep()
+            torch.cuda.synchronize()
+            ddt = (time.perf_counter() - t1) / args.steps
+            sparse_res["dense"] = {"poses_per_sec": round(B / ddt, 1), "ms_per_step": round(ddt * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
+                                   "whole_net_tflops": round(B / ddt * GFLOP_PER_POSE / 1e3, 2),
+                                   "whole_net_frac_of_mfma_peak": round(B / ddt * GFLOP_PER_POSE / 1e3 / PEAK_TFLOPS[args.dtype], 4)}
+            del dnet
             torch.cuda.empty_cache()
 
     _mark("accuracy / modes legs done")
@@ -471,13 +502,17 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"adapose_cabinet forward + post-processing, batch={B} poses ({2 * B} views of 224x224) per GPU, "
-                                   "synthetic RGB, random-init weights of the reference architecture",
+                                   "synthetic RGB, random-init weights of the reference architecture, 1024 chosen pixels per view inside an elliptical "
+                                   "mask of 5-50 % of the crop",
                        "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
                        **({"debug_flags": args.debug_flags} if args.debug_flags else {})},
             "world_size": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
             "tree": tree_hash(),
+            # ALGORITHMIC flops of the reference's dense forward per second; with sparse cost regularisation part of them is not executed,
+            # so the executed-flop MFMA fraction is the dense leg's (sparse_cost_regularisation.dense.whole_net_frac_of_mfma_peak)
             "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
             "whole_net_frac_of_mfma_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
+            "whole_net_flops_are": "algorithmic (dense reference forward); see sparse_cost_regularisation.dense for the all-flops-executed figures",
             "valid_poses_last_step": n_valid, "outputs_finite": finite,
             "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
@@ -490,6 +525,8 @@ def main():
         res["accuracy"] = acc_res
         if modes_res is not None:
             res["modes"] = modes_res
+        if sparse_res is not None:
+            res["sparse_cost_regularisation"] = sparse_res
         res["timed_region_note"] = ("rgbm_prof_start brackets every conv launch with two HIP events inside the timed region: the headline includes "
                                     "that overhead; inputs are 16 unique poses tiled to the batch (no dedupe exists in the library)")
         if ppo_res is not None:

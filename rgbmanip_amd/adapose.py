@@ -236,3 +236,39 @@ def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: i
     if want_pts2d:
         out["pts2d"] = pts2d
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Host mirror of the device's dependency cone (csrc/prob_sparse.hip::cone_of), for reporting and capacity planning: which part of
+# the plane-sweep volume the network needs for a given set of chosen pixels (option "sparse_dec"; network_v5.py:260-291, 449-455).
+def needed_c0_interval(y: int, S: int = 224):
+    """Index interval [lo, hi] of c0 (full resolution, one axis) that the probabilities of a pixel at coordinate y depend on."""
+    def clamp(a, b, n):
+        return max(a, 0), min(b, n - 1)
+    tr = lambda o, n: clamp(o[0] >> 1, (o[1] + 1) >> 1, n)      # noqa: E731  ConvTranspose3d k3 s2 p1 op1
+    s1 = lambda o, n: clamp(o[0] - 1, o[1] + 1, n)              # noqa: E731  Conv3d k3 p1
+    s2 = lambda o, n: clamp(2 * o[0] - 1, 2 * o[1] + 1, n)      # noqa: E731  Conv3d k3 p1 stride 2
+    u = lambda p, q: (min(p[0], q[0]), max(p[1], q[1]))         # noqa: E731
+    u11 = clamp(y - 1, y + 1, S)
+    u9 = tr(u11, S // 2)
+    u7 = tr(u9, S // 4)
+    c5 = s1(tr(u7, S // 8), S // 8)
+    c4 = u(s2(c5, S // 4), u7)
+    c2 = u(s2(s1(c4, S // 4), S // 2), u9)
+    return u(s2(s1(c2, S // 2), S), u11)
+
+
+def sweep_tiles_needed_fraction(choose, S: int = 224, th: int = 12, tw: int = 16) -> float:
+    """Fraction of the depth-sweeping conv0's th x tw-pixel tiles inside the dependency cones of the chosen pixels; choose [V, P]."""
+    ch = np.asarray(choose.cpu() if isinstance(choose, torch.Tensor) else choose).reshape(-1, np.asarray(choose.shape)[-1])
+    lo = np.array([needed_c0_interval(v, S)[0] for v in range(S)])
+    hi = np.array([needed_c0_interval(v, S)[1] for v in range(S)])
+    nth, ntw = -(-S // th), -(-S // tw)
+    total = 0
+    for row in ch:
+        y, x = row // S, row % S
+        m = np.zeros((nth, ntw), bool)
+        for ra, rb, ca, cb in set(zip(lo[y] // th, hi[y] // th, lo[x] // tw, hi[x] // tw)):
+            m[ra:rb + 1, ca:cb + 1] = True
+        total += int(m.sum())
+    return total / (len(ch) * nth * ntw)
