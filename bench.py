@@ -39,6 +39,10 @@ def make_inputs(B, device, unique=16):
     for k, v in base.items():
         t = np.concatenate([v] * reps, axis=0)[:B]
         out[k] = t
+    if os.environ.get("RGBM_BENCH_CHOOSE") == "uniform":     # worst case of the sparse cost regularisation: pixels all over the crop need every tile
+        g = np.random.default_rng(7)
+        for k in ("choose1", "choose2"):
+            out[k] = np.sort(np.stack([g.permutation(224 * 224)[:out[k].shape[1]] for _ in range(B)]), axis=1).astype(np.int64)
     dev = {
         "img1": torch.from_numpy(out["img1"]).to(device), "img2": torch.from_numpy(out["img2"]).to(device),
         "choose1": torch.from_numpy(out["choose1"]).to(device=device, dtype=torch.int32),
@@ -335,7 +339,7 @@ def main():
     sparse_res = None
     if rank == 0 and world == 1 and args.dtype != "fp32":
         from rgbmanip_amd.adapose import sweep_tiles_needed_fraction
-        frac = sweep_tiles_needed_fraction(torch.cat([d["choose1"][:16], d["choose2"][:16]]).cpu().numpy())      # the batch tiles 16 unique poses
+        frac = sweep_tiles_needed_fraction(torch.cat([d["choose1"][:16], d["choose2"][:16]]).cpu().numpy())      # first 16 poses (the batch tiles 16 unique ones)
         sparse_res = {"enabled": True, "sweep_tiles_needed_frac": round(frac, 4),
                       "note": "exact: outputs are bit-identical to the dense computation (tests/test_gpu_at_batch.py); data dependent: the synthetic "
                               "masks are ellipses covering 5-50 % of the crop, pixels scattered over the whole crop need every tile"}
@@ -505,7 +509,8 @@ def main():
                                    "synthetic RGB, random-init weights of the reference architecture, 1024 chosen pixels per view inside an elliptical "
                                    "mask of 5-50 % of the crop",
                        "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
-                       **({"debug_flags": args.debug_flags} if args.debug_flags else {})},
+                       **({"debug_flags": args.debug_flags} if args.debug_flags else {}),
+                       **({"choose": "uniform over the crop (RGBM_BENCH_CHOOSE)"} if os.environ.get("RGBM_BENCH_CHOOSE") == "uniform" else {})},
             "world_size": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
             "tree": tree_hash(),
             # ALGORITHMIC flops of the reference's dense forward per second; with sparse cost regularisation part of them is not executed,

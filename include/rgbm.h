@@ -72,8 +72,10 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
  * half-resolution tensor [16-bit and split-pair nets]; default 7; 0 = x2 resize followed by the 3x3 conv, the reference's operator
  * order), "stem" (1 [default for 16-bit and split-pair nets] = conv1 7x7 + ReLU + max-pool in one kernel from the NCHW images; 0 = padded
  * NHWC copy, implicit-GEMM conv, pool kernel — the only path that materialises the `conv1` tap of rgbm_adapose_fetch).
- * "sparse_dec" (1 [default] = with the sparse tail, conv7 / conv9 of the cost regularisation run only on the 8x8 tiles that the chosen
- * pixels' neighbourhoods need — u7 / u9 are undefined elsewhere; 0 = dense).  Set before querying the workspace size. */
+ * "sparse_dec" (sparse cost regularisation with the sparse tail: the probability volume is read only at the chosen pixels, so every 3-D
+ * layer has a dependency cone per axis; 2 [default] = the plane sweep, conv1..conv5, conv7 and conv9 run only on the tiles inside those
+ * cones — c0..c5 / u7 / u9 are undefined elsewhere, every network output is bit-identical; 1 = conv7 / conv9 only; 0 = dense).
+ * Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
 /* img1/img2 [B,3,224,224] fp32 NCHW normalised; choose1/2 [B,1024] int32; P1/P2 [B,4,4] fp32; depths [B,24] fp32.

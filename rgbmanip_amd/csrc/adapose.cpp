@@ -276,7 +276,7 @@ int AdaPose::plan(int B, Arena& A, Buffers& bf) const {
   bf.choose = (int*)A.alloc(VP * 4);
   bf.masks = (unsigned char*)A.alloc((size_t)V * sparse_mask_bytes_per_view(img));
   bf.sweep_list = (int*)A.alloc((size_t)V * ((img + 11) / 12) * ((img + 15) / 16) * 4);
-  bf.sweep_count = (int*)A.alloc(256);
+  bf.sweep_count = (int*)A.alloc((size_t)(V + 64) * 4);      // total, then one count per view
   bf.feat = A.alloc((size_t)V * S * S * 32 * es);
   bf.featf = dtype == BF16X3 ? (float*)A.alloc((size_t)V * S * S * 32 * 4) : nullptr;
   bf.X0 = (float*)A.alloc(VP * 32 * 4);

@@ -237,6 +237,7 @@ struct ConvDesc {
   int n_pix_tiles, n_ch_tiles;
   // persistent kernel only (filled by its launcher): tiles in total, and exact-division magics for Wq, Hq, Dq
   int n_tiles; unsigned fd_m[3]; int fd_s[3];
+  int korder;                             // K-tile walk of the request waves: 1 = channel block outer, taps inner; 0 = taps outer
   // optional 1x1 conv fused behind the activation (conv_igemm_ws64_kernel only): y2 = act2(W2 . act(y) + bias2); when set,
   // `out` is not written.  w2: [cout2_pad][kpad2] K-major bf16 rows of 64 input channels.
   const void* w2; const float* bias2; void* out2; int ldo2, cout2, kpad2, act2; float slope2;

@@ -789,6 +789,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     const char* wrow[WL];
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
+    long long wko = 0;                       // byte offset of the walker's K index in a weight row
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));      // this wave's first piece, stage 0
 
     // The eight lanes (r0, j = 0..7) of a row group need the same XR row descriptors (GEMM rows r0 + 32*i): lane j decodes
@@ -838,12 +839,13 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(my_ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
       }
       tkd = tkh = tkw = tc = 0;
+      wko = 0;
     };
 
     int ikt = 0, itile = 0;                  // K tile / tile index of the next request
     auto issue = [&](int stage) {
       if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile();
-      if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
+      if ((IG_ABL & 256) && ikt == 0) { tkd = tkh = tkw = tc = 0; wko = 0; }
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
       const long long soff =
@@ -855,13 +857,21 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         const char* src = ok ? rowp[i] + soff : zero;
         glds16(src, sbase + (BCH * 8 + i * 256) * 16);               // X rows 32*i + 8*pw .. +7
       }
-      const long long wk = (long long)ikt * BK * (long long)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wk, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7
-      tc += BK;
-      if (d.lcin >= 0 && tc >= d.Cin) {
-        tc = 0;
-        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
+      if (d.korder && d.lcin >= 0) {
+        // channel block outer, taps inner: the taps of one channel block read the same pixel rows shifted by a few rows / columns,
+        // so between two uses of a cache line the XCD touches one channel block of its 32 tiles (~0.6 MB) instead of every channel
+        // of them (2-4 MB, as much as its L2 holds): the pixels cross the fabric into L2 once per tile instead of once per kernel row
+        wko += (long long)d.Cin * (long long)sizeof(T);
+        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; if (++tkd == d.KD) { tkd = 0; tc += BK; wko = (long long)tc * (long long)sizeof(T); } } }
+      } else {
+        wko += BK * (long long)sizeof(T);
+        tc += BK;
+        if (d.lcin >= 0 && tc >= d.Cin) {
+          tc = 0;
+          if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
+        }
       }
       if (++ikt == KT) { ikt = 0; ++itile; if (itile < n_my) prepare_tile(itile); }
     };
@@ -1205,6 +1215,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
+  d.korder = (g_debug_flags & (1 << 20)) ? 0 : 1;          // debug flag 1048576: taps outer, channels inner (the order before round 3) for A/B
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), (int)LDS)) return rc;
   int n_cu = 0;
   if (int rc = persistent_grid_cus(&n_cu)) return rc;

@@ -271,7 +271,7 @@ int sparse_mask_offset(int S, int layer) {      // layer: 0 = sweep, 1..5 = conv
 }
 
 __global__ __launch_bounds__(256) void sparse_mask_kernel(const int* __restrict__ choose, int v0, int P, int S, SparseMaskLayout L,
-                                                          unsigned char* __restrict__ masks) {
+                                                          unsigned char* __restrict__ masks, int* __restrict__ view_count) {
   __shared__ unsigned char m[2048];
   const int vl = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < L.total; i += 256) m[i] = 0;
@@ -291,38 +291,59 @@ __global__ __launch_bounds__(256) void sparse_mask_kernel(const int* __restrict_
   }
   __syncthreads();
   for (int i = tid; i < L.total; i += 256) masks[(long long)vl * L.total + i] = m[i];
+  // this view's number of sweep tiles (the list kernel's offsets)
+  int c = 0;
+  for (int i = tid; i < L.n0h * L.n0w; i += 256) c += m[L.o0 + i];
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  __shared__ int wsum[4];
+  if ((tid & 63) == 0) wsum[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) view_count[1 + vl] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// needed tiles of the depth-sweeping conv0 in ascending order: list[i] = (view * n0h + row tile) * n0w + column tile, count[0] = how many
-__global__ __launch_bounds__(1024) void sparse_sweep_list_kernel(const unsigned char* __restrict__ masks, int Vc, SparseMaskLayout L,
-                                                                 int* __restrict__ list, int* __restrict__ count) {
-  __shared__ int part[1024];
-  const int per_view = L.n0h * L.n0w, total = Vc * per_view, tid = threadIdx.x;
-  const int chunk = (total + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < total ? lo + chunk : total;
+// needed tiles of the depth-sweeping conv0 in ascending order: list[i] = (view * n0h + row tile) * n0w + column tile, count[0] = how many.
+// One workgroup per view: its offset is the sum of the per-view counts (count[1 + u], written by sparse_mask_kernel) of the views before it.
+__global__ __launch_bounds__(256) void sparse_sweep_list_kernel(const unsigned char* __restrict__ masks, int Vc, SparseMaskLayout L,
+                                                                int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int part[256];
+  const int per_view = L.n0h * L.n0w, v = blockIdx.x, tid = threadIdx.x;
   int c = 0;
-  for (int i = lo; i < hi; ++i) c += masks[(long long)(i / per_view) * L.total + L.o0 + i % per_view] ? 1 : 0;
+  for (int u = tid; u < v; u += 256) c += count[1 + u];
   part[tid] = c;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {      // inclusive scan
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) part[tid] += part[tid + off];
     __syncthreads();
   }
-  int o = part[tid] - c;
-  for (int i = lo; i < hi; ++i)
-    if (masks[(long long)(i / per_view) * L.total + L.o0 + i % per_view]) list[o++] = i;
-  if (tid == 1023) count[0] = part[1023];
+  int base = part[0];
+  __syncthreads();
+  const unsigned char* m = masks + (long long)v * L.total + L.o0;
+  for (int seg = 0; seg < per_view; seg += 256) {
+    const int i = seg + tid;
+    const int f = i < per_view && m[i] ? 1 : 0;
+    part[tid] = f;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {      // inclusive scan
+      const int t = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (f) list[base + part[tid] - 1] = v * per_view + i;
+    base += part[255];
+    __syncthreads();
+  }
+  if (v == Vc - 1 && tid == 0) count[0] = base;
 }
 
-// masks: Vc * sparse_mask_bytes_per_view(S) bytes; sweep_list: Vc * ceil(S/12) * ceil(S/16) ints; sweep_count: 1 int
+// masks: Vc * sparse_mask_bytes_per_view(S) bytes; sweep_list: Vc * ceil(S/12) * ceil(S/16) ints; sweep_count: 1 + Vc ints (total, then per view)
 int launch_sparse_masks(const int* choose, int v0, int Vc, int P, int S, unsigned char* masks, int* sweep_list, int* sweep_count,
                         hipStream_t s) {
   RGBM_REQUIRE(choose && masks && sweep_list && sweep_count && S % 8 == 0 && S >= 16 && Vc > 0, "sparse masks arguments");
   const SparseMaskLayout L = sparse_mask_layout(S);
   RGBM_REQUIRE(L.total <= 2048, "sparse masks: crop too large for the mask kernel's LDS table");
-  hipLaunchKernelGGL(sparse_mask_kernel, dim3((unsigned)Vc), dim3(256), 0, s, choose, v0, P, S, L, masks);
-  hipLaunchKernelGGL(sparse_sweep_list_kernel, dim3(1), dim3(1024), 0, s, masks, Vc, L, sweep_list, sweep_count);
+  hipLaunchKernelGGL(sparse_mask_kernel, dim3((unsigned)Vc), dim3(256), 0, s, choose, v0, P, S, L, masks, sweep_count);
+  hipLaunchKernelGGL(sparse_sweep_list_kernel, dim3((unsigned)Vc), dim3(256), 0, s, masks, Vc, L, sweep_list, sweep_count);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,5 +1,5 @@
 """Same-box A/B of one rgbm_adapose_set_option key at batch 256: ms per forward for each value, interleaved.
-usage: ab_option.py <dtype> <key> <v0> <v1> [...]"""
+usage: ab_option.py <dtype> <key> <v0> <v1> [...]      key "debug": the values are rgbm_debug_flags words (read at launch time) on one net"""
 import os
 import sys
 import numpy as np
@@ -13,8 +13,16 @@ B = 256
 inp = synth.adapose_inputs(16, seed=0)
 inp = {k: torch.from_numpy(np.concatenate([v] * (B // 16), 0)).cuda() for k, v in inp.items()}
 sd = synth.adapose_state_dict(seed=0)
-nets = {v: AdaPoseNet(sd, dtype=dtype, options={key: v}) for v in vals}
+if key == "debug":
+    from rgbmanip_amd import _lib
+    one = AdaPoseNet(sd, dtype=dtype)
+    nets = {v: (one, v) for v in vals}
+else:
+    nets = {v: AdaPoseNet(sd, dtype=dtype, options={key: v}) for v in vals}
 def run(net):
+    if isinstance(net, tuple):
+        _lib.load().rgbm_debug_flags(net[1])
+        net = net[0]
     return net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"])
 for net in nets.values():
     run(net)
