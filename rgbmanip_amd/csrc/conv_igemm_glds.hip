@@ -107,6 +107,30 @@ __device__ __forceinline__ void mma_bx3_tile(const uint4 (&a0)[FM], const uint4 
     for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
 }
 
+// 8-byte LDS read the compiler cannot merge with its neighbours (and does not count: the caller waits by hand)
+template <int OFF>
+__device__ __forceinline__ void lds_rd8(uint2& dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// the three products of a split-pair tile from operands that are already separated into hi and lo parts
+template <int FM, int FN>
+__device__ __forceinline__ void mma_bx3_ops(const uint4 (&ah)[FM], const uint4 (&al)[FM], const uint4 (&bh)[FN], const uint4 (&bl)[FN],
+                                            f32x4 (&acc)[FM][FN]) {
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al[a], bh[b], acc[a][b]);
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
+}
+
 template <int N> struct IC { static constexpr int value = N; };
 
 __device__ __forceinline__ float apply_act_g(float v, int act, float slope) {
@@ -949,6 +973,15 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
   };
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
+  // split pairs: byte offsets (inside a stage) of this lane's two chunks of its first A / B fragment row
+  unsigned x3a0 = 0, x3a1 = 0, x3b0 = 0, x3b1 = 0;
+  if constexpr (std::is_same<T, bx3_t>::value) {
+    const int ra = wch + (lr >> 2) * 16 + (lr & 3), rb = wpix + lr;
+    x3a0 = (unsigned)(ra * 8 + (lg ^ swz_w(ra))) * 16u;
+    x3a1 = (unsigned)(ra * 8 + ((4 + lg) ^ swz_w(ra))) * 16u;
+    x3b0 = (unsigned)(BCH * 8 + rb * 8 + (lg ^ ((rb >> 1) & 7))) * 16u;
+    x3b1 = (unsigned)(BCH * 8 + rb * 8 + ((4 + lg) ^ ((rb >> 1) & 7))) * 16u;
+  }
   int st = 0;
   int xs = 0, kw = 0;                        // RH: X slot and kernel column of the current step
   auto tile_interior = [&](int pix_tile, int ch_tile) {
@@ -1009,6 +1042,14 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
       // split pairs: the two half-tile chunks of a lane (channels 4*lg.. and 16 + 4*lg..) together are the 8 k values of
       // one 16x16x32 operand — hi parts and lo parts separately — so a K tile (32 channels) is 16 x 3 full-rate MFMAs
       // (lo*hi, hi*lo, hi*hi; 16 independent accumulators between two uses of the same one)
+      // The hi parts of a lane's two chunks are the first 8 bytes of each, the lo parts the last 8: read as 8-byte halves they land
+      // in the operand registers directly.  (Read as two 16-byte chunks, every operand pair cost ~6 v_mov to regroup — 52 per wave
+      // and K tile on the MFMA issue port, all behind the full read latency.  The 8-byte reads of a half wave hit each bank pair
+      // twice, which costs the LDS array what the 16-byte reads cost.)  The reads are inline asm — hipcc merges plain 8-byte loads
+      // back into 16-byte or paired ones and regroups with v_mov again — issued in the order the products need them and waited for
+      // with counted waits (LDS reads return in order; at most 16 are outstanding).
+      static_assert(!std::is_same<T, bx3_t>::value || (FM == 4 && FN == 4), "counted waits below: 4 x 4 fragments");
+#ifdef X3_PAIR_B128      // timing builds (tools/abl_build.sh): the 16-byte reads + regrouping this loop replaced
       for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RGBM_BARRIER();
@@ -1017,6 +1058,72 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         mma_bx3_tile<FM, FN>(af0, af1, bf0, bf1, acc);
         st = st == 2 ? 0 : st + 1;
       }
+#else
+      for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RGBM_BARRIER();
+        const unsigned sb = lds_addr(lds3 + st * STAGE);
+        const unsigned pa0 = sb + x3a0, pa1 = sb + x3a1, pb0 = sb + x3b0, pb1 = sb + x3b1;
+        uint2 ahp[FM][2], alp[FM][2], bhp[FN][2], blp[FN][2];
+#define X3_RD_A(dst, a, half) { lds_rd8<(a) * 512 + (half) * 8>(dst[a][0], pa0); lds_rd8<(a) * 512 + (half) * 8>(dst[a][1], pa1); }
+#define X3_RD_B(dst, b, half) { lds_rd8<(b) * 2048 + (half) * 8>(dst[b][0], pb0); lds_rd8<(b) * 2048 + (half) * 8>(dst[b][1], pb1); }
+#define X3_T(p) "+v"(p[0]), "+v"(p[1])
+#define X3_OP(p) make_uint4(p[0].x, p[0].y, p[1].x, p[1].y)
+        X3_RD_A(alp, 0, 1) X3_RD_B(bhp, 0, 0) X3_RD_B(bhp, 1, 0) X3_RD_B(bhp, 2, 0) X3_RD_B(bhp, 3, 0)
+        X3_RD_A(alp, 1, 1) X3_RD_A(alp, 2, 1) X3_RD_A(alp, 3, 1)
+        asm volatile("s_waitcnt lgkmcnt(6)" : X3_T(alp[0]), X3_T(bhp[0]), X3_T(bhp[1]), X3_T(bhp[2]), X3_T(bhp[3]) :: "memory");
+        const uint4 bh[FN] = {X3_OP(bhp[0]), X3_OP(bhp[1]), X3_OP(bhp[2]), X3_OP(bhp[3])};
+        {
+          const uint4 al = X3_OP(alp[0]);
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al, bh[b], acc[0][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RD_A(ahp, 0, 0) X3_RD_A(ahp, 1, 0)
+        asm volatile("s_waitcnt lgkmcnt(8)" : X3_T(alp[1]) :: "memory");
+        {
+          const uint4 al = X3_OP(alp[1]);
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al, bh[b], acc[1][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RD_A(ahp, 2, 0) X3_RD_A(ahp, 3, 0)
+        asm volatile("s_waitcnt lgkmcnt(10)" : X3_T(alp[2]) :: "memory");
+        {
+          const uint4 al = X3_OP(alp[2]);
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al, bh[b], acc[2][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RD_B(blp, 0, 1) X3_RD_B(blp, 1, 1)
+        asm volatile("s_waitcnt lgkmcnt(12)" : X3_T(alp[3]) :: "memory");
+        {
+          const uint4 al = X3_OP(alp[3]);
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(al, bh[b], acc[3][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RD_B(blp, 2, 1) X3_RD_B(blp, 3, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : X3_T(ahp[0]), X3_T(ahp[1]), X3_T(ahp[2]), X3_T(ahp[3]), X3_T(blp[0]), X3_T(blp[1]), X3_T(blp[2]), X3_T(blp[3])
+                     :: "memory");
+        const uint4 ah[FM] = {X3_OP(ahp[0]), X3_OP(ahp[1]), X3_OP(ahp[2]), X3_OP(ahp[3])};
+        const uint4 bl[FN] = {X3_OP(blp[0]), X3_OP(blp[1]), X3_OP(blp[2]), X3_OP(blp[3])};
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) MmaG<unsigned short>::run(ah[a], bh[b], acc[a][b]);
+#undef X3_RD_A
+#undef X3_RD_B
+#undef X3_T
+#undef X3_OP
+        st = st == 2 ? 0 : st + 1;
+      }
+#endif
     } else {
     for (int kt = 0; kt < KT; ++kt) {
       // every fragment read of the previous step has returned before the request waves may refill its stage
