@@ -878,11 +878,11 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = ok ? rowp[i] + soff : zero;
+        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : zero;
         glds16(src, sbase + (BCH * 8 + i * 256) * 16);               // X rows 32*i + 8*pw .. +7
       }
 #pragma unroll
-      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
+      for (int i = 0; i < WL; ++i) glds16((IG_ABL & 4) ? zero : wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
       if (d.korder && d.lcin >= 0) {
         // channel block outer, taps inner: the taps of one channel block read the same pixel rows shifted by a few rows / columns,
         // so between two uses of a cache line the XCD touches one channel block of its 32 tiles (~0.6 MB) instead of every channel
@@ -1068,10 +1068,15 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 #define X3_RD_A(dst, a, half) { lds_rd8<(a) * 512 + (half) * 8>(dst[a][0], pa0); lds_rd8<(a) * 512 + (half) * 8>(dst[a][1], pa1); }
 #define X3_RD_B(dst, b, half) { lds_rd8<(b) * 2048 + (half) * 8>(dst[b][0], pb0); lds_rd8<(b) * 2048 + (half) * 8>(dst[b][1], pb1); }
 #define X3_T(p) "+v"(p[0]), "+v"(p[1])
+#ifdef X3_NOWAIT      // timing builds only (wrong results): the products do not wait for their operands = a perfect prefetch
+#define X3_WAIT(w) ""
+#else
+#define X3_WAIT(w) w
+#endif
 #define X3_OP(p) make_uint4(p[0].x, p[0].y, p[1].x, p[1].y)
         X3_RD_A(alp, 0, 1) X3_RD_B(bhp, 0, 0) X3_RD_B(bhp, 1, 0) X3_RD_B(bhp, 2, 0) X3_RD_B(bhp, 3, 0)
         X3_RD_A(alp, 1, 1) X3_RD_A(alp, 2, 1) X3_RD_A(alp, 3, 1)
-        asm volatile("s_waitcnt lgkmcnt(6)" : X3_T(alp[0]), X3_T(bhp[0]), X3_T(bhp[1]), X3_T(bhp[2]), X3_T(bhp[3]) :: "memory");
+        asm volatile(X3_WAIT("s_waitcnt lgkmcnt(6)") : X3_T(alp[0]), X3_T(bhp[0]), X3_T(bhp[1]), X3_T(bhp[2]), X3_T(bhp[3]) :: "memory");
         const uint4 bh[FN] = {X3_OP(bhp[0]), X3_OP(bhp[1]), X3_OP(bhp[2]), X3_OP(bhp[3])};
         {
           const uint4 al = X3_OP(alp[0]);
@@ -1080,7 +1085,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         }
         __builtin_amdgcn_sched_barrier(0);
         X3_RD_A(ahp, 0, 0) X3_RD_A(ahp, 1, 0)
-        asm volatile("s_waitcnt lgkmcnt(8)" : X3_T(alp[1]) :: "memory");
+        asm volatile(X3_WAIT("s_waitcnt lgkmcnt(8)") : X3_T(alp[1]) :: "memory");
         {
           const uint4 al = X3_OP(alp[1]);
 #pragma unroll
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         }
         __builtin_amdgcn_sched_barrier(0);
         X3_RD_A(ahp, 2, 0) X3_RD_A(ahp, 3, 0)
-        asm volatile("s_waitcnt lgkmcnt(10)" : X3_T(alp[2]) :: "memory");
+        asm volatile(X3_WAIT("s_waitcnt lgkmcnt(10)") : X3_T(alp[2]) :: "memory");
         {
           const uint4 al = X3_OP(alp[2]);
 #pragma unroll
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         }
         __builtin_amdgcn_sched_barrier(0);
         X3_RD_B(blp, 0, 1) X3_RD_B(blp, 1, 1)
-        asm volatile("s_waitcnt lgkmcnt(12)" : X3_T(alp[3]) :: "memory");
+        asm volatile(X3_WAIT("s_waitcnt lgkmcnt(12)") : X3_T(alp[3]) :: "memory");
         {
           const uint4 al = X3_OP(alp[3]);
 #pragma unroll
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         }
         __builtin_amdgcn_sched_barrier(0);
         X3_RD_B(blp, 2, 1) X3_RD_B(blp, 3, 1)
-        asm volatile("s_waitcnt lgkmcnt(0)"
+        asm volatile(X3_WAIT("s_waitcnt lgkmcnt(0)")
                      : X3_T(ahp[0]), X3_T(ahp[1]), X3_T(ahp[2]), X3_T(ahp[3]), X3_T(blp[0]), X3_T(blp[1]), X3_T(blp[2]), X3_T(blp[3])
                      :: "memory");
         const uint4 ah[FM] = {X3_OP(ahp[0]), X3_OP(ahp[1]), X3_OP(ahp[2]), X3_OP(ahp[3])};
@@ -1121,6 +1126,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 #undef X3_RD_B
 #undef X3_T
 #undef X3_OP
+#undef X3_WAIT
         st = st == 2 ? 0 : st + 1;
       }
 #endif

@@ -103,6 +103,66 @@ void run3(int waves, int barrier, const char* name) {
   hipFree(out);
 }
 
+
+// mode 4: register tile FM x FN per wave (FM + FN fragment reads per FM * FN MFMAs and half K tile), plain loads, compiler-scheduled with the
+// ws kernel's half-tile software pipeline (reads of the next half issued before the MFMAs of the current one), barrier per K tile.
+// 8 waves of 4 x 4 = the ws kernel's multiply loop; 4 waves of 8 x 4 = one multiply wave per SIMD with a 128 x 64 tile.
+template <int FM, int FN>
+__global__ __launch_bounds__(512) void k4(float* out, int iters, int barrier) {
+  __shared__ uint4 lds[6144];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 6144; i += blockDim.x) lds[i] = fill_value(i);
+  __syncthreads();
+  f32x4 acc[FM][FN];
+  for (int i = 0; i < FM; ++i) for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 a0[FM], b0[FN], a1[FM], b1[FN];
+  const uint4* base = lds + (tid >> 6) * 256 + lane;
+  auto load = [&](int s, uint4 (&a)[FM], uint4 (&b)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = base[((s * (FM + FN) + i) * 64) % 4096];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = base[((s * (FM + FN) + FM + j) * 64) % 4096];
+  };
+  auto mma = [&](const uint4 (&a)[FM], const uint4 (&b)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+  };
+  load(1, a1, b1);
+  for (int it = 0; it < iters; ++it) {
+    if (barrier) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    load(0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < FM; ++i) for (int j = 0; j < FN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[blockIdx.x * blockDim.x + tid] = s;
+}
+template <int FM, int FN>
+void run4(int waves, int barrier, const char* name) {
+  float* out; hipMalloc(&out, 256 * 1024 * 4);
+  const int iters = g_iters;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k4<FM, FN>), dim3(256), dim3(64 * waves), 0, 0, out, 100, barrier);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k4<FM, FN>), dim3(256), dim3(64 * waves), 0, 0, out, iters, barrier);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double nm = 2.0 * FM * FN;
+  const double flops = 256.0 * waves * iters * nm * 16 * 16 * 32 * 2;
+  printf("%-34s waves/CU %2d: %.3f ms  %.0f TFLOP/s  (%.1f clk per MFMA per SIMD at 2.4 GHz)\n", name, waves, ms, flops / ms / 1e9,
+         ms * 1e-3 * 2.4e9 / (iters * nm * waves / 4.0));
+  hipFree(out);
+}
+
 template <int MODE>
 void run(int waves, const char* name) {
   float* out; hipMalloc(&out, 256 * 1024 * 4);
@@ -129,6 +189,12 @@ int main(int argc, char** argv) {
   for (int w : {4, 8, 12}) run<2>(w, "+ barrier per 32 MFMAs");
   for (int w : {4, 8, 12}) run3(w, 0, "asm reads, 1 wait per 16 MFMAs");
   for (int w : {4, 8, 12}) run3(w, 1, "asm reads, 1 wait, + barrier");
+  run4<4, 4>(8, 1, "4x4 tile, pipelined, + barrier");
+  run4<4, 4>(8, 0, "4x4 tile, pipelined, no barrier");
+  run4<8, 4>(4, 1, "8x4 tile, pipelined, + barrier");
+  run4<8, 4>(4, 0, "8x4 tile, pipelined, no barrier");
+  run4<8, 4>(8, 1, "8x4 tile, 8 waves, + barrier");
+  run4<8, 8>(4, 1, "8x8 tile, pipelined, + barrier");
   }
   return 0;
 }
