@@ -332,7 +332,8 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
  *   4096  halo-tile conv0 instead of the plane-sweep kernels             8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
- * 262144  generic tile instead of the 64 x 256 four-wave ws tile */
+ * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
+ *                                                                                  (default since round 3: channel block outer, taps inner) */
 int rgbm_debug_flags(int flags);
 /* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
  * flags are then ignored */
