@@ -168,6 +168,20 @@ def test_sparse_cost_regularisation_is_bit_identical_to_dense(inputs256, dtype):
         assert torch.isfinite(outs[2][k]).all(), k
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_sparse_cost_regularisation_with_a_chunked_cost_volume(inputs256, dtype):
+    """The tile masks and the sweep's tile list are built per cost-volume chunk: 40 views in chunks of 24 + 16 (max_chunk_views = 24,
+    ragged last chunk) with sparse_dec = 2 must give the dense result of the same chunking bit for bit (another chunk size may pick
+    other kernels for some layers, i.e. another summation order)."""
+    args = _dev_inputs(inputs256, 20)
+    ref = {k: v.clone() for k, v in _forward(_net(dtype, max_chunk_views=24, options={"sparse_dec": 0}), args).items()}
+    net = _net(dtype, max_chunk_views=24)
+    _forward(net, args)
+    cur = _forward(net, args)
+    for k in OUT_KEYS:
+        assert torch.equal(cur[k].view(torch.int32), ref[k].view(torch.int32)), (dtype, k, float((cur[k] - ref[k]).abs().max()))
+
+
 @pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "fp16"])
 def test_one_kernel_stem_equals_copy_conv_pool(inputs256, dtype):
     """conv1 7x7 + ReLU + max-pool in one kernel from the NCHW images (option stem = 1, the 16-bit default) against the padded copy,
