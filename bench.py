@@ -509,6 +509,9 @@ def main():
                                    "synthetic RGB, random-init weights of the reference architecture, 1024 chosen pixels per view inside an elliptical "
                                    "mask of 5-50 % of the crop",
                        "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
+                       "cost_regularisation": ("library default (sparse_dec = 2): computed only where the chosen pixels' outputs depend on it, all ten "
+                                               "outputs bit-identical to the dense computation; the dense timing of the same run is in "
+                                               "sparse_cost_regularisation.dense" if args.dtype != "fp32" else "dense"),
                        **({"debug_flags": args.debug_flags} if args.debug_flags else {}),
                        **({"choose": "uniform over the crop (RGBM_BENCH_CHOOSE)"} if os.environ.get("RGBM_BENCH_CHOOSE") == "uniform" else {})},
             "world_size": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
