@@ -3,7 +3,10 @@
 
 One "step" = one pass of the estimator hot path over one batch of 256 synthetic poses per GPU:
   HIP network forward (2 x 256 views of 224x224, all 10 outputs)  +  device post-processing to world boxes,
-with every input already resident in HBM.  N > 1: one process per GPU (torch.distributed, RCCL); poses are
+with every input already resident in HBM.  The headline inputs come through the reference's own crop logic (480x640 frames with an
+elliptical object mask -> crop window of lib/utils.py:10-38 -> 224x224 crop + 1024 chosen pixels, rgbm_prepare_inputs), so the
+masks span their crops as the reference's do; `value_dense` (every layer computed densely), `value_worst_case` (chosen pixels all
+over the crop) and `value_survey_masks` (SURVEY 8d's ellipses inside the crop, the headline of rounds 1-3) are timed in the same run.  N > 1: one process per GPU (torch.distributed, RCCL); poses are
 independent, so ranks shard the batch with no data-path collective (weak scaling, 256 poses per GPU).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
@@ -52,6 +55,64 @@ def make_inputs(B, device, unique=16):
         "K1": torch.from_numpy(out["K1"]).to(device), "E1": torch.from_numpy(out["E1"]).to(device),
     }
     return out, dev
+
+
+def make_inputs_crop(B, device, seed=0, keep_frames=False):
+    """The headline workload: B stereo pairs as the reference's pipeline produces them.  Two look-at cameras per pose (the geometry of
+    synth.adapose_inputs), a 480x640 frame per view with an elliptical object mask around the projected target (semi-axes 40-120 px
+    vertically, 40-150 px horizontally), then `prepare_model_input` on the device (rgbm_prepare_inputs: crop window per
+    lib/utils.py:10-38 = the mask's longer side rounded up to a multiple of 40, INTER_LINEAR crop-resize to 224, normalisation,
+    1024-pixel subset, cropped intrinsics; interface_v5.py:58-170).  Returns (host dict of numpy arrays for the oracle, device dict,
+    frames dict or None)."""
+    from rgbmanip_amd import synth
+    from rgbmanip_amd.adapose import prepare_inputs
+    g = np.random.default_rng(424242 + seed)
+    E = np.empty((B, 2, 4, 4))
+    ell = np.empty((B, 2, 4), dtype=np.float32)
+    for b in range(B):
+        target = g.uniform(-0.05, 0.05, size=3) + np.array([0.0, 0.0, 0.5])
+        d0 = g.normal(size=3)
+        d0[2] = abs(d0[2]) * 0.3
+        d0 /= np.linalg.norm(d0)
+        eye1 = target + d0 * g.uniform(0.55, 0.9)
+        side = np.cross(d0, np.array([0.0, 0.0, 1.0]))
+        side /= np.linalg.norm(side)
+        eye2 = eye1 + side * g.uniform(0.15, 0.35) + np.array([0, 0, g.uniform(-0.05, 0.05)])
+        for v, eye in enumerate((eye1, eye2)):
+            E[b, v] = synth._lookat_extrinsic(eye, target)
+            ell[b, v] = (240 + g.uniform(-50, 50), 320 + g.uniform(-80, 80), g.uniform(40, 120), g.uniform(40, 150))     # cy, cx, ry, rx
+    fx = 240.0 / np.tan(0.5)
+    K0 = torch.tensor([[fx, 0, 320.0], [0, fx, 240.0], [0, 0, 1.0]], dtype=torch.float64, device=device).repeat(B, 1, 1)
+    gen = torch.Generator(device=device).manual_seed(1000 + seed)
+    yy, xx = torch.meshgrid(torch.arange(480, device=device, dtype=torch.float32), torch.arange(640, device=device, dtype=torch.float32), indexing="ij")
+    prep, frames = [], {}
+    for v in range(2):
+        noise = torch.rand(B, 480, 640, 3, generator=gen, device=device)
+        ph = torch.rand(B, 3, generator=gen, device=device) * 6.2832
+        smooth = 0.5 + 0.125 * (torch.cos(0.02 * xx[None] + ph[:, 0, None, None]) + torch.cos(0.03 * yy[None] + ph[:, 1, None, None]) +
+                                torch.cos(0.011 * (xx + yy)[None] + ph[:, 2, None, None]))
+        rgb = (0.5 * noise + 0.5 * smooth[..., None]).clamp_(0.0, 1.0)
+        e = torch.from_numpy(ell[:, v]).to(device)
+        mask = ((((yy[None] - e[:, 0, None, None]) / e[:, 2, None, None]) ** 2 + ((xx[None] - e[:, 1, None, None]) / e[:, 3, None, None]) ** 2) <= 1).to(torch.uint8)
+        prep.append(prepare_inputs(rgb, mask, K0, 224, 1024, seed + v))
+        if keep_frames:
+            frames[f"rgb{v + 1}"], frames[f"mask{v + 1}"] = rgb, mask
+        del noise, smooth
+    assert int(prep[0]["valid"].sum()) == B and int(prep[1]["valid"].sum()) == B
+    Ed = torch.from_numpy(E).to(device)
+    P = []
+    for v in range(2):
+        Pm = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1)
+        Pm[:, :3, :] = prep[v]["Kcrop"] @ Ed[:, v, :3, :]
+        P.append(Pm.float())
+    depths = torch.from_numpy(np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (B, 1))).to(device)
+    dev = {"img1": prep[0]["img"], "img2": prep[1]["img"], "choose1": prep[0]["choose"], "choose2": prep[1]["choose"],
+           "P1": P[0], "P2": P[1], "depths": depths, "K1": prep[0]["Kcrop"], "E1": Ed[:, 0].contiguous()}
+    host = {k: v.cpu().numpy() for k, v in dev.items()}
+    host["choose1"], host["choose2"] = host["choose1"].astype(np.int64), host["choose2"].astype(np.int64)
+    if keep_frames:
+        frames.update(K=K0, E1=Ed[:, 0].contiguous(), E2=Ed[:, 1].contiguous())
+    return host, dev, (frames if keep_frames else None)
 
 
 def _mark(msg):
@@ -169,7 +230,7 @@ def cpu_baseline_ppo(n_envs=4):
 OUT_KEYS = ["view1_nocs", "view2_nocs", "view1_depth", "view2_depth", "view1_r", "view2_r", "view1_t", "view2_t", "view1_s", "view2_s"]
 
 
-def cpu_baseline(host, n_chunks=6, chunk=2):
+def cpu_baseline(host, n_chunks=6, chunk=2, n_unique=16):
     """Oracle (kind "port") on the host cores: network forward + numpy post-processing, bounded sample of the benched workload's
     own poses (chunks of `chunk` of the batch's unique poses, last ones first).  Returns (result dict, {pose index: oracle
     outputs}) — the second is the checker for `accuracy.at_batch`: what the device produced for those poses inside the timed
@@ -179,7 +240,7 @@ def cpu_baseline(host, n_chunks=6, chunk=2):
     cores = min(os.cpu_count() or 1, 32)       # oneDNN convs at batch 2 stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     sd = adapose_ref.to_torch_sd(synth.adapose_state_dict(seed=0))
-    n_unique = min(16, host["img1"].shape[0])
+    n_unique = min(n_unique, host["img1"].shape[0])
     chunks = [[(n_unique - 1 - (c * chunk + j)) % n_unique for j in range(chunk)] for c in range(n_chunks + 1)]
     ref = {}
 
@@ -220,6 +281,32 @@ def at_batch_accuracy(dev_out, ref, B, n_unique=16):
             "checker": "oracle/adapose_ref outputs of the cpu_baseline leg (same poses, same run)"}
 
 
+def time_steps(fn, warmup, steps):
+    """seconds per call of fn() (device-synchronised on both sides)"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def prof_table(stats, steps):
+    from rgbmanip_amd import _lib
+    st = np.array(list(stats)).reshape(_lib.PROF_ROWS, 4)
+    kernels = []
+    for v in range(_lib.PROF_ROWS):
+        n, ms, fl, by = st[v]
+        if n > 0:
+            kernels.append({"kernel": _lib.PROF_KERNELS[v][0], "dtype": _lib.PROF_KERNELS[v][1], "row": v, "launches_per_step": n / steps,
+                            "avg_launch_ms": ms / n, "total_ms_per_step": ms / steps,
+                            "tflops": fl / (ms * 1e-3) / 1e12, "algo_GBps": by / (ms * 1e-3) / 1e9, "flops_per_step": fl / steps})
+    kernels.sort(key=lambda k: -k["total_ms_per_step"])
+    return kernels
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +314,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16", "bf16x3"])
+    ap.add_argument("--inputs", default="crop", choices=["crop", "survey", "uniform"],
+                    help="headline inputs: crop = 480x640 frames through the reference's crop window (masks span their crops); survey = "
+                         "SURVEY 8d's ellipses inside the 224 crop (rounds 1-3); uniform = chosen pixels all over the crop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="views per cost-volume chunk (0 = library default)")
     ap.add_argument("--ppo-envs", type=int, default=512, help="envs per GPU for the PPO leg (0 = skip it)")
@@ -237,12 +327,16 @@ def main():
     ap.add_argument("--mixed-dtype", default="fp16", choices=["bf16", "fp16", "fp32", "bf16x3"], help="storage type of the mixed-object leg (configs[4] names fp16)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="PPO learning iterations (the last one is reported)")
     ap.add_argument("--cost-impl", type=int, default=-1, help="A/B switch of the cost-volume path (see rgbm.h); -1 = default")
-    ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense-cost-regularisation leg (option sparse_dec = 0) of the headline dtype")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense / worst-case / survey-mask legs of the headline dtype")
     ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the estimate() plugin-boundary leg (host numpy frames in, H2D included)")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / B = 8 latency leg (eager launches and hipGraph replay)")
     ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel A/B switches (rgbm_debug_flags); a non-zero value is echoed in config")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the golden-vector accuracy leg (profiling runs: keeps the trace to the timed steps)")
     args = ap.parse_args()
+    if os.environ.get("RGBM_BENCH_CHOOSE") == "uniform":      # rounds 1-3 spelling of --inputs uniform
+        args.inputs = "uniform"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -266,19 +360,32 @@ def main():
             dist.init_process_group(backend)
 
     from rgbmanip_amd import _lib, synth
-    from rgbmanip_amd.adapose import AdaPoseNet, postprocess
+    from rgbmanip_amd.adapose import AdaPoseNet, postprocess, sweep_tiles_needed_fraction
     lib = _lib.load()
     if args.debug_flags:
         lib.rgbm_debug_flags(args.debug_flags)
-    net = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank,
+    sd0 = synth.adapose_state_dict(seed=0)
+    net = AdaPoseNet(sd0, dtype=args.dtype, device=local_rank,
                      max_chunk_views=args.chunk or None, cost_impl=None if args.cost_impl < 0 else args.cost_impl)
     B = args.batch
-    host, d = make_inputs(B, device)
+    want_boundary = rank == 0 and world == 1 and not args.no_boundary
+    frames = None
+    if args.inputs == "crop":
+        host, d, frames = make_inputs_crop(B, device, seed=rank, keep_frames=want_boundary)
+        n_unique = B
+    else:
+        if args.inputs == "uniform":
+            os.environ["RGBM_BENCH_CHOOSE"] = "uniform"
+        host, d = make_inputs(B, device)
+        n_unique = min(16, B)
 
-    def step():
-        out = net(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
-        bbox, ts, valid = postprocess(out["view1_nocs"], out["view1_depth"], out["view1_r"], d["choose1"], d["K1"], d["E1"])
-        return out, bbox, valid
+    def mkstep(n, dd):
+        def f():
+            out = n(dd["img1"], dd["choose1"], dd["img2"], dd["choose2"], dd["P1"], dd["P2"], dd["depths"])
+            bbox, ts, valid = postprocess(out["view1_nocs"], out["view1_depth"], out["view1_r"], dd["choose1"], dd["K1"], dd["E1"])
+            return out, bbox, valid
+        return f
+    step = mkstep(net, d)
 
     def barrier():
         if dist is not None:
@@ -293,16 +400,36 @@ def main():
     for _ in range(args.steps):
         out, bbox, valid = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     stats = (C.c_double * (4 * _lib.PROF_ROWS))()
     _lib.check(lib.rgbm_prof_stop(stats), "rgbm_prof_stop")
+    # how much of the plane sweep this rank's chosen pixels need (sparse cost regularisation is data dependent: a straggler shows here)
+    ch_all = torch.cat([d["choose1"], d["choose2"]]).cpu().numpy()
+    my_frac = sweep_tiles_needed_fraction(ch_all[:: max(1, len(ch_all) // 64)]) if args.dtype != "fp32" else 1.0
+    per_rank = None
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # every rank's own numbers through one SUM all-reduce of a [world, 2] table (all-reduce is what RCCL and gloo both offer for device tensors)
+        allr = torch.zeros(world, 2, dtype=torch.float64, device=device)
+        allr[rank] = torch.tensor([elapsed_local / args.steps * 1e3, my_frac], dtype=torch.float64, device=device)
+        dist.all_reduce(allr)
+        per_rank = {"ms_per_step": [round(float(a[0]), 3) for a in allr], "sweep_tiles_needed_frac": [round(float(a[1]), 4) for a in allr]}
+        per_rank["ms_per_step_min"], per_rank["ms_per_step_max"] = min(per_rank["ms_per_step"]), max(per_rank["ms_per_step"])
     n_valid = int(valid.sum().item())
     finite = bool(torch.isfinite(bbox).all().item())
-    batch_outs = {args.dtype: {k: v.clone() for k, v in out.items()}} if rank == 0 else {}      # last timed step (10 small tensors)
+    batch_outs = {}
+    if rank == 0:
+        # the at-batch accuracy check uses one more forward of the same batch on a POISONED workspace (every byte 0xFF in front of the
+        # forward): it must reproduce the timed step bit for bit — nothing read may come from a previous run — and is what the oracle sees
+        net.poison_workspace = True
+        pout, _, _ = step()
+        torch.cuda.synchronize()
+        net.poison_workspace = False
+        poison_same = all(torch.equal(pout[k].view(torch.int32), out[k].view(torch.int32)) for k in OUT_KEYS)
+        batch_outs[args.dtype] = {k: v.clone() for k, v in pout.items()}
 
     _mark("timed region done")
     # ---- accuracy of the benched mode and throughput + accuracy of the modes that meet north_star's 1e-4 gate (not part of `value`) ----
@@ -314,57 +441,162 @@ def main():
         for md in ("bf16x3", "fp32"):
             if md == args.dtype:
                 continue
-            mnet2 = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=md, device=local_rank, max_chunk_views=args.chunk or None)
+            mnet2 = AdaPoseNet(sd0, dtype=md, device=local_rank, max_chunk_views=args.chunk or None)
             macc = accuracy_vs_golden(mnet2, device)
-
-            def mstep2():
-                o = mnet2(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
-                return postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"])
-            mstep2()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.mode_steps):
-                mstep2()
-            torch.cuda.synchronize()
-            mdt = (time.perf_counter() - t1) / args.mode_steps
-            batch_outs[md] = {k: v.clone() for k, v in mnet2(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"]).items()}
+            mstep2 = mkstep(mnet2, d)
+            mdt = time_steps(mstep2, 1, args.mode_steps)
+            mnet2.poison_workspace = True
+            batch_outs[md] = {k: v.clone() for k, v in mstep2()[0].items()}
             torch.cuda.synchronize()
             modes_res[md] = {"poses_per_sec": round(B / mdt, 1), "ms_per_step": round(mdt * 1e3, 2), "batch": B, "steps": args.mode_steps,
                              "accuracy": macc}
+            if md == "bf16x3" and not args.no_dense_leg:
+                dn = AdaPoseNet(sd0, dtype=md, device=local_rank, max_chunk_views=args.chunk or None, options={"sparse_dec": 0})
+                ddt = time_steps(mkstep(dn, d), 1, args.mode_steps)
+                modes_res[md]["dense"] = {"poses_per_sec": round(B / ddt, 1), "ms_per_step": round(ddt * 1e3, 2)}
+                del dn
             del mnet2
             torch.cuda.empty_cache()
 
-    # ---- how much of the cost regularisation the benched inputs need (option sparse_dec: the 3-D layers and the plane sweep run only inside
-    # the chosen pixels' dependency cones), and the same step with every layer dense ----
-    sparse_res = None
-    if rank == 0 and world == 1 and args.dtype != "fp32":
-        from rgbmanip_amd.adapose import sweep_tiles_needed_fraction
-        frac = sweep_tiles_needed_fraction(torch.cat([d["choose1"][:16], d["choose2"][:16]]).cpu().numpy())      # first 16 poses (the batch tiles 16 unique ones)
-        sparse_res = {"enabled": True, "sweep_tiles_needed_frac": round(frac, 4),
-                      "note": "exact: outputs are bit-identical to the dense computation (tests/test_gpu_at_batch.py); data dependent: the synthetic "
-                              "masks are ellipses covering 5-50 % of the crop, pixels scattered over the whole crop need every tile"}
-        if not args.no_dense_leg:
-            dnet = AdaPoseNet(synth.adapose_state_dict(seed=0), dtype=args.dtype, device=local_rank, max_chunk_views=args.chunk or None,
-                              options={"sparse_dec": 0})
+    # ---- the same step with every layer dense, on the worst-case pixel sets, and on SURVEY 8d's in-crop ellipses (N = 1 information) ----
+    legs = None
+    if rank == 0 and world == 1 and args.dtype != "fp32" and not args.no_dense_leg:
+        legs = {}
+        dnet = AdaPoseNet(sd0, dtype=args.dtype, device=local_rank, max_chunk_views=args.chunk or None, options={"sparse_dec": 0})
+        dstep = mkstep(dnet, d)
+        for _ in range(args.warmup):
+            dstep()
+        torch.cuda.synchronize()
+        _lib.check(lib.rgbm_prof_start(), "rgbm_prof_start")
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dstep()
+        torch.cuda.synchronize()
+        ddt = (time.perf_counter() - t1) / args.steps
+        dstats = (C.c_double * (4 * _lib.PROF_ROWS))()
+        _lib.check(lib.rgbm_prof_stop(dstats), "rgbm_prof_stop")
+        dk = prof_table(dstats, args.steps)
+        # flops the conv launches of one dense step EXECUTE (each launch's own shape: the commuted PSPUpsample GEMMs count a quarter of
+        # the reference's multiply-adds; the tap-combination rows 37 / 38 are vector work and left out)
+        exec_flops = sum(k["flops_per_step"] for k in dk if k["row"] not in (37, 38))
+        legs["dense"] = {"poses_per_sec": round(B / ddt, 1), "ms_per_step": round(ddt * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
+                         "executed_conv_tflop_per_step": round(exec_flops / 1e12, 3),
+                         "mfma_frac_executed_flops": round(exec_flops / ddt / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                         "algorithmic_tflops_over_peak": round(B / ddt * GFLOP_PER_POSE / 1e3 / PEAK_TFLOPS[args.dtype], 4)}
+        del dnet
+        torch.cuda.empty_cache()
+        # worst case of the sparse path: pixels all over the crop need every tile (mask + list kernels and the indirection on top of dense)
+        gq = np.random.default_rng(7)
+        du = dict(d)
+        for k in ("choose1", "choose2"):
+            du[k] = torch.from_numpy(np.sort(np.stack([gq.permutation(224 * 224)[:1024] for _ in range(B)]), axis=1).astype(np.int32)).to(device)
+        wdt = time_steps(mkstep(net, du), args.warmup, args.steps)
+        legs["worst_case"] = {"poses_per_sec": round(B / wdt, 1), "ms_per_step": round(wdt * 1e3, 2), "sweep_tiles_needed_frac": 1.0,
+                              "inputs": "the headline's crops with 1024 chosen pixels drawn uniformly over the whole 224 x 224 crop"}
+        if args.inputs == "crop":
+            _, ds = make_inputs(B, device)
+            sdt = time_steps(mkstep(net, ds), args.warmup, args.steps)
+            sfrac = sweep_tiles_needed_fraction(torch.cat([ds["choose1"][:16], ds["choose2"][:16]]).cpu().numpy())
+            legs["survey_masks"] = {"poses_per_sec": round(B / sdt, 1), "ms_per_step": round(sdt * 1e3, 2), "sweep_tiles_needed_frac": round(sfrac, 4),
+                                    "inputs": "SURVEY 8d: ellipses with semi-axes 30-90 px anywhere inside the 224 crop, 16 unique poses tiled (the "
+                                              "headline workload of rounds 1-3)"}
+            del ds
+        del du
+        torch.cuda.empty_cache()
 
-            def dstep():
-                o = dnet(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
-                return postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"])
-            for _ in range(args.warmup):
-                dstep()
+    _mark("accuracy / modes / dense legs done")
+    # ---- plugin boundary (the full estimate()-equivalent incl. H2D): AdaPoseEstimator_v5.estimate with numpy frames ----
+    boundary_res = None
+    if want_boundary and frames is not None:
+        from rgbmanip_amd.config import ADAPOSE_CFGS
+        from rgbmanip_amd.estimator import AdaPoseEstimator_v5
+        ecfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False)
+        est_d = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device"), None, dtype=args.dtype, net=net)
+        Kh, E1h, E2h = frames["K"].cpu().numpy(), frames["E1"].cpu().numpy(), frames["E2"].cpu().numpy()
+        # what rl_pose.py:210-218 hands over: [N,480,640,3] float64 frames and [N,480,640] masks, host numpy
+        r1, r2 = frames["rgb1"].cpu().numpy().astype(np.float64), frames["rgb2"].cpu().numpy().astype(np.float64)
+        m1, m2 = frames["mask1"].cpu().numpy().astype(np.float64), frames["mask2"].cpu().numpy().astype(np.float64)
+        est_d.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            bb = est_d.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
+        e_s = (time.perf_counter() - t1) / 2
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ups = [est_d._upload_frames(r1), est_d._upload_masks(m1), est_d._upload_frames(r2), est_d._upload_masks(m2)]
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                dstep()
-            torch.cuda.synchronize()
-            ddt = (time.perf_counter() - t1) / args.steps
-            sparse_res["dense"] = {"poses_per_sec": round(B / ddt, 1), "ms_per_step": round(ddt * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
-                                   "whole_net_tflops": round(B / ddt * GFLOP_PER_POSE / 1e3, 2),
-                                   "whole_net_frac_of_mfma_peak": round(B / ddt * GFLOP_PER_POSE / 1e3 / PEAK_TFLOPS[args.dtype], 4)}
-            del dnet
+        up_s = (time.perf_counter() - t1) / 2
+        del ups
+        dev_s = time_steps(lambda: est_d.estimate_device(frames["K"], frames["rgb1"], frames["mask1"], frames["E1"], frames["rgb2"], frames["mask2"],
+                                                         frames["E2"]), 1, 3)
+        r1f, r2f = r1.astype(np.float32), r2.astype(np.float32)
+        m1b, m2b = m1 != 0, m2 != 0
+        est_d.estimate(Kh, r1f, m1b, E1h, r2f, m2b, E2h)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            est_d.estimate(Kh, r1f, m1b, E1h, r2f, m2b, E2h)
+        e32_s = (time.perf_counter() - t1) / 2
+        # the reference's own structure (per-frame numpy crop / resize on the host, then one batched forward): bounded sample of 16 poses
+        est_h = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="host"), None, dtype=args.dtype, net=net)
+        nh = min(16, B)
+        est_h.estimate(Kh[:2], r1[:2], m1[:2], E1h[:2], r2[:2], m2[:2], E2h[:2])
+        t1 = time.perf_counter()
+        est_h.estimate(Kh[:nh], r1[:nh], m1[:nh], E1h[:nh], r2[:nh], m2[:nh], E2h[:nh])
+        h_s = time.perf_counter() - t1
+        gb = (r1.nbytes + r2.nbytes + m1.nbytes + m2.nbytes) / 1e9
+        boundary_res = {
+            "call": "AdaPoseEstimator_v5.estimate(K, rgb1, mask1, E1, rgb2, mask2, E2) -> [N,8,3] world boxes, numpy in, numpy out "
+                    "(interface_v5.py:213-227 as rl_pose.py:210-218 calls it)", "poses": B, "dtype": args.dtype,
+            "frames": f"[{B},480,640,3] float64 + [{B},480,640] float64 masks per view, {gb:.2f} GB of host arrays per call",
+            "device_prepare": {"poses_per_sec": round(B / e_s, 1), "ms_per_call": round(e_s * 1e3, 1),
+                               "upload_ms": round(up_s * 1e3, 1), "upload_share": round(up_s / e_s, 3),
+                               "upload_host_GBps": round(gb / up_s, 1),
+                               "device_resident_ms": round(dev_s * 1e3, 1), "device_resident_poses_per_sec": round(B / dev_s, 1),
+                               "float32_frames_bool_masks": {"poses_per_sec": round(B / e32_s, 1), "ms_per_call": round(e32_s * 1e3, 1)},
+                               "note": "hip_prepare: device — frames converted to float32 on the host cores into pinned double-buffered chunks "
+                                       "and copied while the next chunk converts; crop / resize / subset / network / post-processing on the GPU"},
+            "host_prepare": {"poses_per_sec": round(nh / h_s, 2), "ms_per_pose": round(h_s / nh * 1e3, 1), "sample_poses": nh,
+                             "note": "hip_prepare: host — the reference's per-frame numpy crop / resize on one host core, then one batched forward"},
+            "finite": bool(np.isfinite(bb).all())}
+        del r1, r2, m1, m2, r1f, r2f, est_d, est_h
+    frames = None
+    torch.cuda.empty_cache()
+
+    _mark("boundary leg done")
+    # ---- small batches (the deployment path: the reference calls the network per env, num_envs: 8 ships): B = 1 and 8, latency of
+    # forward + post-processing, launched one by one and replayed from a hipGraph ----
+    small_res = None
+    if rank == 0 and world == 1 and not args.no_small_batch:
+        small_res = {"what": "median wall-clock latency of one forward + post-processing call incl. the final device synchronisation, "
+                             "50 calls per entry; eager = ~150 launches from the host, graph = one hipGraphLaunch of the captured sequence "
+                             "(AdaPoseNet(graph=True), rgbm_adapose_forward_graph)", "entries": []}
+        for md in dict.fromkeys((args.dtype, "bf16x3")):
+            nets = {"eager": AdaPoseNet(sd0, dtype=md, device=local_rank), "graph": AdaPoseNet(sd0, dtype=md, device=local_rank, graph=True)}
+            for sb in (1, 8):
+                dd = {k: v[:sb].contiguous() for k, v in d.items()}
+                ent = {"dtype": md, "batch": sb}
+                for how, nn in nets.items():
+                    f = mkstep(nn, dd)
+                    for _ in range(3):
+                        f()
+                    torch.cuda.synchronize()
+                    lat = []
+                    for _ in range(50):
+                        t1 = time.perf_counter()
+                        f()
+                        torch.cuda.synchronize()
+                        lat.append(time.perf_counter() - t1)
+                    ent[how + "_ms"] = round(float(np.median(lat)) * 1e3, 3)
+                    ent[how + "_ms_p90"] = round(float(np.percentile(lat, 90)) * 1e3, 3)
+                    # device-side duration of the same call: back-to-back calls, one synchronisation (launch overhead hidden when the GPU is the limit)
+                    ent[how + "_pipelined_ms"] = round(time_steps(f, 2, 20) * 1e3, 3)
+                ent["graph_nodes"] = nets["graph"].last_graph_nodes
+                ent["poses_per_sec_graph"] = round(sb / (ent["graph_pipelined_ms"] * 1e-3), 1)
+                small_res["entries"].append(ent)
+            del nets
             torch.cuda.empty_cache()
 
-    _mark("accuracy / modes legs done")
     # ---- SURVEY 8f-1 leg (not part of `value`): device-side prepare_model_input on 480x640 frames, vs the host numpy path ----
     prep_res = None
     if rank == 0 and not args.no_prepare:
@@ -372,7 +604,7 @@ def main():
         from rgbmanip_amd.estimator import AdaPoseEstimator_v5
         nf = 256
         gen = torch.Generator(device=device).manual_seed(0)
-        frames = torch.rand(nf, 480, 640, 3, generator=gen, device=device)
+        pframes = torch.rand(nf, 480, 640, 3, generator=gen, device=device)
         yy, xx = torch.meshgrid(torch.arange(480, device=device), torch.arange(640, device=device), indexing="ij")
         cy = 140 + 200 * torch.rand(nf, generator=gen, device=device)
         cx = 160 + 320 * torch.rand(nf, generator=gen, device=device)
@@ -380,17 +612,17 @@ def main():
         rx = 40 + 110 * torch.rand(nf, generator=gen, device=device)
         masks = ((((yy[None] - cy[:, None, None]) / ry[:, None, None]) ** 2 + ((xx[None] - cx[:, None, None]) / rx[:, None, None]) ** 2) < 1).to(torch.uint8)
         Kf = torch.tensor([[439.31, 0, 320.0], [0, 439.31, 240.0], [0, 0, 1.0]], dtype=torch.float64, device=device).repeat(nf, 1, 1)
-        prepare_inputs(frames, masks, Kf, 224, 1024, 0)
+        prepare_inputs(pframes, masks, Kf, 224, 1024, 0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for it in range(3):
-            po = prepare_inputs(frames, masks, Kf, 224, 1024, it)
+            po = prepare_inputs(pframes, masks, Kf, 224, 1024, it)
         torch.cuda.synchronize()
         dev_ms = (time.perf_counter() - t1) / 3 * 1e3
         est = AdaPoseEstimator_v5.__new__(AdaPoseEstimator_v5)          # host arithmetic only: no network needed
         est.rng = np.random.default_rng(0)
         est._frame = 0
-        fh, mh = frames[:4].cpu().numpy(), masks[:4].cpu().numpy()
+        fh, mh = pframes[:4].cpu().numpy(), masks[:4].cpu().numpy()
         t1 = time.perf_counter()
         for i in range(4):
             est.prepare_model_input(fh[i], mh[i], Kf[0].cpu().numpy(), 224)
@@ -398,7 +630,7 @@ def main():
         prep_res = {"frames": nf, "device_ms_per_frame": round(dev_ms / nf, 4), "device_frames_per_sec": round(nf / dev_ms * 1e3, 1),
                     "host_numpy_ms_per_frame": round(host_ms, 2), "valid_frames": int(po["valid"].sum().item()),
                     "note": "480x640x3 f32 frame + mask -> 224x224 normalised crop, 1024 choose indices, cropped intrinsics (interface_v5.py:58-170)"}
-        del frames, masks
+        del pframes, masks
 
     _mark("prepare leg done")
     # ---- configs[4] leg (not part of `value`): mixed-object batch, 4 heads, sorted by head and sharded over the ranks ----
@@ -463,20 +695,18 @@ def main():
                    "collection_s": round(ppo.last_collection_time, 3), "learn_s": round(ppo.last_learn_time, 4),
                    "optimizer_steps": 32, "env": env_name,
                    "lr_after": ppo.step_size}
+        if dist is not None:      # per-rank collection / learn times: a straggler of the PPO loop is visible the day SCALE runs
+            allr = torch.zeros(world, 3, dtype=torch.float64, device=device)
+            allr[rank] = torch.tensor([ppo.last_collection_time, ppo.last_learn_time, ppo.last_fps], dtype=torch.float64, device=device)
+            dist.all_reduce(allr)
+            ppo_res["per_rank"] = {"collection_s": [round(float(a[0]), 3) for a in allr], "learn_s": [round(float(a[1]), 4) for a in allr]}
+            ppo_res["env_steps_per_sec_all_ranks"] = round(world * args.ppo_envs * 16 / max(float(a[0] + a[1]) for a in allr), 1)
 
     _mark("ppo leg done")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B / (elapsed / args.steps)
-        st = np.array(list(stats)).reshape(_lib.PROF_ROWS, 4)
-        kernels = []
-        for v in range(_lib.PROF_ROWS):
-            n, ms, fl, by = st[v]
-            if n > 0:
-                kernels.append({"kernel": _lib.PROF_KERNELS[v][0], "dtype": _lib.PROF_KERNELS[v][1], "launches_per_step": n / args.steps,
-                                "avg_launch_ms": ms / n, "total_ms_per_step": ms / args.steps,
-                                "tflops": fl / (ms * 1e-3) / 1e12, "algo_GBps": by / (ms * 1e-3) / 1e9})
-        kernels.sort(key=lambda k: -k["total_ms_per_step"])
+        kernels = prof_table(stats, args.steps)
         dom = kernels[0]
         peak = PEAK_TFLOPS[dom["dtype"]]
         # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure is read
@@ -492,7 +722,8 @@ def main():
                 for kname, nbytes in tj["bytes_per_launch"].items():
                     if key in kname:
                         traffic = float(nbytes)
-                        traffic_src = f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this tree, 2*FETCH+WRITE)"
+                        traffic_src = (f"profiles/{os.path.basename(tpath)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this tree (2*FETCH+WRITE), "
+                                       f"taken by the builder on another box of the pool ({meta.get('box', 'box not recorded')}), not in this run")
                         break
                 hbm_step = meta.get("hbm_bytes_per_step")
             else:
@@ -501,29 +732,48 @@ def main():
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom["avg_launch_ms"], 4), "launches_per_step": dom["launches_per_step"],
                     "flops_per_launch": dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3}
+        inputs_desc = {
+            "crop": "480x640 synthetic frames with an elliptical object mask (semi-axes 40-120 x 40-150 px) -> the reference's crop window "
+                    "(lib/utils.py:10-38) -> 224x224 crop + 1024 chosen pixels on the device (interface_v5.py:58-170): masks span their crops",
+            "survey": "SURVEY 8d: 1024 chosen pixels inside an elliptical mask of 5-50 % of the 224 crop, 16 unique poses tiled",
+            "uniform": "1024 chosen pixels uniform over the whole crop (worst case of the sparse cost regularisation)"}[args.inputs]
         res = {
             "metric": "adapose_poses_per_sec_batch256", "value": round(value, 3), "unit": "poses/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"adapose_cabinet forward + post-processing, batch={B} poses ({2 * B} views of 224x224) per GPU, "
-                                   "synthetic RGB, random-init weights of the reference architecture, 1024 chosen pixels per view inside an elliptical "
-                                   "mask of 5-50 % of the crop",
-                       "poses_per_gpu": B, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
+                                   "synthetic RGB, random-init weights of the reference architecture; inputs: " + inputs_desc,
+                       "poses_per_gpu": B, "unique_poses": n_unique, "outputs": "all 10 network outputs + world bbox", "parallelism": f"dp{world}",
+                       "inputs": args.inputs,
                        "cost_regularisation": ("library default (sparse_dec = 2): computed only where the chosen pixels' outputs depend on it, all ten "
-                                               "outputs bit-identical to the dense computation; the dense timing of the same run is in "
-                                               "sparse_cost_regularisation.dense" if args.dtype != "fp32" else "dense"),
-                       **({"debug_flags": args.debug_flags} if args.debug_flags else {}),
-                       **({"choose": "uniform over the crop (RGBM_BENCH_CHOOSE)"} if os.environ.get("RGBM_BENCH_CHOOSE") == "uniform" else {})},
+                                               "outputs bit-identical to the dense computation; value_dense / value_worst_case of the same run are "
+                                               "top-level keys" if args.dtype != "fp32" else "dense"),
+                       **({"debug_flags": args.debug_flags} if args.debug_flags else {})},
             "world_size": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
             "tree": tree_hash(),
-            # ALGORITHMIC flops of the reference's dense forward per second; with sparse cost regularisation part of them is not executed,
-            # so the executed-flop MFMA fraction is the dense leg's (sparse_cost_regularisation.dense.whole_net_frac_of_mfma_peak)
-            "whole_net_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
-            "whole_net_frac_of_mfma_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
-            "whole_net_flops_are": "algorithmic (dense reference forward); see sparse_cost_regularisation.dense for the all-flops-executed figures",
+            "sweep_tiles_needed_frac": round(my_frac, 4),
+            # ALGORITHMIC flops of the reference's dense forward per second over the MFMA peak: a SPEED figure, not a utilisation (the
+            # commuted PSPUpsample and the sparse cost regularisation do not execute all of them); the executed-flop fraction is
+            # mfma_frac_executed_flops_dense
+            "algorithmic_tflops": round(value * GFLOP_PER_POSE / 1e3, 2),
+            "algorithmic_tflops_over_peak": round(value * GFLOP_PER_POSE / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
             "valid_poses_last_step": n_valid, "outputs_finite": finite,
-            "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
+            "roofline": roofline, "conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items() if k != "flops_per_step"} for kk in kernels],
         }
+        if legs is not None:
+            res["value_dense"] = legs["dense"]["poses_per_sec"]
+            res["ms_per_step_dense"] = legs["dense"]["ms_per_step"]
+            res["mfma_frac_executed_flops_dense"] = legs["dense"]["mfma_frac_executed_flops"]
+            res["value_worst_case"] = legs["worst_case"]["poses_per_sec"]
+            if "survey_masks" in legs:
+                res["value_survey_masks"] = legs["survey_masks"]["poses_per_sec"]
+            res["sparse_cost_regularisation"] = {
+                "enabled": True, **legs,
+                "note": "exact: outputs are bit-identical to the dense computation (tests/test_gpu_at_batch.py, poisoned workspace); data "
+                        "dependent: `value` is on masks that span their crops like the reference's, value_worst_case needs every tile, "
+                        "value_survey_masks is SURVEY 8d's ellipses of 5-50 % of the crop"}
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         # whole-net HBM rate: measured bytes per step (PMC, every kernel of one forward) against the algorithmic minimum of
         # SURVEY 8(d) (0.54 GB per pose at 2 bytes per element: every conv reads its input once and writes its output once)
         algo_gb_pose = 0.54 * (2.0 if args.dtype in ("fp32", "bf16x3") else 1.0)
@@ -533,10 +783,13 @@ def main():
         res["accuracy"] = acc_res
         if modes_res is not None:
             res["modes"] = modes_res
-        if sparse_res is not None:
-            res["sparse_cost_regularisation"] = sparse_res
         res["timed_region_note"] = ("rgbm_prof_start brackets every conv launch with two HIP events inside the timed region: the headline includes "
-                                    "that overhead; inputs are 16 unique poses tiled to the batch (no dedupe exists in the library)")
+                                    "that overhead" + ("" if n_unique == B else f"; inputs are {n_unique} unique poses tiled to the batch (no dedupe exists in the library)"))
+        if boundary_res is not None:
+            res["plugin_boundary"] = boundary_res
+            res["value_plugin_boundary"] = boundary_res["device_prepare"]["poses_per_sec"]
+        if small_res is not None:
+            res["small_batch"] = small_res
         if ppo_res is not None:
             res["ppo"] = ppo_res
         if prep_res is not None:
@@ -544,14 +797,17 @@ def main():
         if mixed_res is not None:
             res["mixed_object"] = mixed_res
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], oref = cpu_baseline(host)
+            res["cpu_baseline"], oref = cpu_baseline(host, n_unique=n_unique)
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
             # the timed batch itself against the oracle (the CPU baseline's outputs are the checker): B = 2 goldens never reach the
             # kernels the dispatcher picks at batch 256
             if acc_res is not None:
-                acc_res["at_batch"] = at_batch_accuracy(batch_outs[args.dtype], oref, B)
+                acc_res["at_batch"] = at_batch_accuracy(batch_outs[args.dtype], oref, B, n_unique)
+                acc_res["at_batch"]["workspace_poisoned"] = True
+                acc_res["at_batch"]["poisoned_run_bit_identical_to_timed_step"] = bool(poison_same)
             for md, mr in (modes_res or {}).items():
-                mr["accuracy"]["at_batch"] = at_batch_accuracy(batch_outs[md], oref, B)
+                mr["accuracy"]["at_batch"] = at_batch_accuracy(batch_outs[md], oref, B, n_unique)
+                mr["accuracy"]["at_batch"]["workspace_poisoned"] = True
             if ppo_res is not None:
                 res["ppo"]["cpu_baseline"] = cpu_baseline_ppo()
         # the fastest mode of this run whose outputs meet north_star's 1e-4 (on the reference's golden vectors AND, when the

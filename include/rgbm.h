@@ -304,10 +304,24 @@ int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_de
                         int V, int B, int D, int H, int W, void* stream);
 /* debugging access to a named intermediate of the last rgbm_adapose_forward on (h, B, workspace):
  * converts it to fp32 into out_dev (elems = capacity in floats); *n_elems returns its size.  Intermediates of the
- * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first. */
+ * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first.
+ * The 3-D taps "c0" "c2" "c4" "c6" "u7" "u9" exist as whole tensors only with option sparse_dec = 0: with the default (sparse cost
+ * regularisation) the call fails with an error instead of returning tensors that are stale outside the dependency cones.
+ * "pf96" of a split-pair net is converted back from the hi / lo pairs the pose MLP consumed. */
 int rgbm_adapose_forward_ex(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
                             const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
                             size_t workspace_bytes, const rgbm_adapose_out* out, int stop_after, void* stream);
+/* rgbm_adapose_forward replayed from a hipGraph (small batches — the reference calls the network at batch 1 per env,
+ * interface_v5.py:213-227,259-280, and ships num_envs: 8 — are launch-bound: ~150 launches per forward).  The first call with a
+ * given (B, every device pointer, workspace, outputs) runs the forward once eagerly, captures its launch sequence on `stream` and
+ * keeps the instantiated graph (up to 8 per handle, least recently used evicted; dropped when an option changes); later calls with the
+ * same arguments replay it with one hipGraphLaunch.  The caller keeps every buffer alive and at the same address.  `stream` must be
+ * a created (non-null) stream.  *n_nodes (optional) = graph nodes (kernel launches + copies) of this batch size; *captured
+ * (optional) = 1 when this call did the capture, 0 on a replay, -1 when it ran eagerly because rgbm_prof_start is active. */
+int rgbm_adapose_forward_graph(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                               const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                               size_t workspace_bytes, const rgbm_adapose_out* out, void* stream, int32_t* n_nodes, int32_t* captured);
+int rgbm_adapose_graph_clear(rgbm_adapose_t* h);
 int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* name, float* out_dev, size_t capacity,
                        size_t* n_elems, void* stream);
 

@@ -49,7 +49,7 @@ PROF_KERNELS = [
      ("conv_igemm_ws_kernel<unsigned short, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16"),
      ("conv_igemm_ws_kernel<float, false, false, true> (64 channels x 256 pixels, four multiply waves)", "fp32"),
      ("upconv_combine_kernel<16-bit> (PSPUpsample tap combination)", "bf16"), ("upconv_combine_kernel<4-byte> (PSPUpsample tap combination)", "bf16x3"),
-     ("unused", "bf16")]
+     ("upconv_final_kernel (up_3 + final in one kernel; either storage width)", "bf16")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 
@@ -96,6 +96,9 @@ SIGNATURES = {
     "rgbm_adapose_workspace_bytes": (_i, [_vp, _i, C.POINTER(_sz)]),
     "rgbm_adapose_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _vp]),
     "rgbm_adapose_forward_ex": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _i, _vp]),
+    "rgbm_adapose_forward_graph": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(AdaposeOut), _vp, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
+    "rgbm_adapose_graph_clear": (_i, [_vp]),
     "rgbm_adapose_fetch": (_i, [_vp, _i, _vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "rgbm_adapose_postprocess": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_adapose_postprocess_ransac": (_i, [_i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -23,8 +23,21 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.
 class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
                  cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None,
-                 norm_mode: int | str = 0):
+                 norm_mode: int | str = 0, poison_workspace: bool = False, graph: bool = False, graph_max_batch: int = 32):
         self.lib = _lib.load()
+        # graph: forwards of at most `graph_max_batch` poses are replayed from a hipGraph captured per batch size
+        # (rgbm_adapose_forward_graph): static input / output / workspace buffers per batch size, one hipGraphLaunch instead of ~150
+        # launches — the small-batch deployment path (interface_v5.py:213-227 calls the network per env; cfg/task/open_cabinet.yaml
+        # ships num_envs: 8).  Larger batches run eagerly: they are bound by the kernels, not by their launches.
+        self.graph = bool(graph)
+        self.graph_max_batch = int(graph_max_batch)
+        self._static = {}
+        self._gstream = None
+        self.last_graph_nodes = 0
+        # debug: fill the whole workspace with 0xFF bytes (NaN in every storage type, -1 in index lists) in front of EVERY forward, so
+        # that a kernel reading a tile the sparse cost regularisation skipped — or anything else a forward did not write itself —
+        # cannot find a previous run's (correct) values there (tests/test_gpu_at_batch.py, bench.py's at-batch check)
+        self.poison_workspace = bool(poison_workspace)
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -90,8 +103,53 @@ class AdaPoseNet:
             t = torch.as_tensor(np.asarray(t))
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def _forward_graph(self, args):
+        """Replay (first call per batch size: capture) the forward on static buffers; returns fresh output tensors."""
+        def as_t(x):
+            return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        args = [as_t(a) for a in args]
+        B = int(args[0].shape[0])
+        st = self._static.get(B)
+        if st is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            i32 = dict(dtype=torch.int32, device=self.device)
+            ins = [torch.empty(B, 3, 224, 224, **f32), torch.empty(B, 1024, **i32), torch.empty(B, 3, 224, 224, **f32), torch.empty(B, 1024, **i32),
+                   torch.empty(B, 4, 4, **f32), torch.empty(B, 4, 4, **f32), torch.empty(B, 24, **f32)]
+            out = {"view1_nocs": torch.empty(B, 1024, 3, **f32), "view2_nocs": torch.empty(B, 1024, 3, **f32),
+                   "view1_depth": torch.empty(B, 1024, **f32), "view2_depth": torch.empty(B, 1024, **f32),
+                   "view1_r": torch.empty(B, 3, 3, **f32), "view2_r": torch.empty(B, 3, 3, **f32),
+                   "view1_t": torch.empty(B, 3, **f32), "view2_t": torch.empty(B, 3, **f32),
+                   "view1_s": torch.empty(B, 3, **f32), "view2_s": torch.empty(B, 3, **f32)}
+            ws = torch.empty(self.workspace_bytes(B) + 256, dtype=torch.uint8, device=self.device)
+            st = self._static[B] = (ins, out, ws)
+        ins, out, ws = st
+        for dst, src in zip(ins, args):
+            assert tuple(src.shape) == tuple(dst.shape), (tuple(src.shape), tuple(dst.shape))
+            dst.copy_(src, non_blocking=True)              # converts dtype / uploads as needed, on the caller's stream
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.device)      # capture is not allowed on the default stream
+        cur = torch.cuda.current_stream(self.device)
+        gs = self._gstream
+        gs.wait_stream(cur)
+        off = (-ws.data_ptr()) % 256
+        o = _lib.AdaposeOut(*[out[n].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
+        nodes, cap = C.c_int32(), C.c_int32()
+        if self.poison_workspace:
+            with torch.cuda.stream(gs):
+                ws.fill_(0xFF)
+        # (img1, choose1, img2, choose2, P1, P2, depths) -> the C ABI's (img1, img2, choose1, choose2, P1, P2, depths)
+        _lib.check(self.lib.rgbm_adapose_forward_graph(self._h, B, _lib.ptr(ins[0]), _lib.ptr(ins[2]), _lib.ptr(ins[1]), _lib.ptr(ins[3]),
+                                                       _lib.ptr(ins[4]), _lib.ptr(ins[5]), _lib.ptr(ins[6]), C.c_void_p(ws.data_ptr() + off),
+                                                       ws.numel() - off, C.byref(o), C.c_void_p(gs.cuda_stream), C.byref(nodes), C.byref(cap)),
+                   "rgbm_adapose_forward_graph")
+        self.last_graph_nodes = nodes.value
+        cur.wait_stream(gs)
+        return {k: v.clone() for k, v in out.items()}      # the static outputs are overwritten by the next replay
+
     def forward(self, view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values,
                 stop_after: int = 0, stream=None):
+        if self.graph and stop_after == 0 and stream is None and len(view1_img) <= self.graph_max_batch:
+            return self._forward_graph((view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values))
         img1 = self._prep(view1_img, torch.float32)
         img2 = self._prep(view2_img, torch.float32)
         ch1 = self._prep(view1_choose, torch.int32)
@@ -113,6 +171,9 @@ class AdaPoseNet:
         }
         o = _lib.AdaposeOut(*[out[n].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
         ws_ptr, ws_bytes = self._workspace(B)
+        if self.poison_workspace:
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+                self._ws.fill_(0xFF)
         _lib.check(self.lib.rgbm_adapose_forward_ex(self._h, B, _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(ch1), _lib.ptr(ch2),
                                                     _lib.ptr(P1), _lib.ptr(P2), _lib.ptr(dep), C.c_void_p(ws_ptr), ws_bytes,
                                                     C.byref(o), stop_after, _lib.stream_ptr(stream)), "rgbm_adapose_forward")

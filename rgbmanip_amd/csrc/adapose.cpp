@@ -261,6 +261,12 @@ bool AdaPose::feat_f32_only() const {
   return dtype == BF16X3 && cost_impl == 3 && sweep_w != nullptr && norm_mode == 0 && !(g_debug_flags & 4096);
 }
 
+bool AdaPose::sparse_active() const {
+  const bool b16 = dtype_size(dtype) == 2;
+  return sparse_dec != 0 && norm_mode == 0 && cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail && sweep_w != nullptr &&
+         !(g_debug_flags & 4096);
+}
+
 int AdaPose::chunk_views(int V) const {
   const int cap = norm_mode == 1 && max_chunk > 32 ? 32 : max_chunk;      // per-sample BN materialises the 32-channel volume (154 MB per view in fp32)
   return V < cap ? V : cap;
@@ -462,13 +468,12 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
   // layer is needed only inside their dependency cones (prob_sparse.hip: sparse_mask_kernel) — conv1 .. conv5, conv7 / conv9 skip the
   // other tiles, the depth-sweeping conv0 walks the list of needed ones.  conv6 stays dense (a 0.3 ms GEMM): what it computes from
   // unwritten input tiles is never read by anything that is read.
-  const bool sparse_ok = norm_mode == 0 && cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail && sweep_w != nullptr &&
-                         !(g_debug_flags & 4096);
+  const bool sparse_ok = sparse_active();
   for (int v0 = 0; norm_mode == 0 && cost_impl >= 1 && v0 < V; v0 += Vc0) {
     const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
     const unsigned char* mk[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     sweep_sparse = false;
-    if (sparse_ok && sparse_dec) {
+    if (sparse_ok) {
       int td, th, tw;
       for (int L : {1, 2, 3, 4, 5, 7, 8}) RGBM_REQUIRE(!conv3d_tile_dims(L, dtype, &td, &th, &tw) && th == 8 && tw == 8, "sparse cost regularisation: 8 x 8 tiles expected");
       if (int rc = launch_sparse_masks(bf.choose, v0, Vc, P, S, bf.masks, bf.sweep_list, bf.sweep_count, s)) return rc;

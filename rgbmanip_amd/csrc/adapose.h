@@ -101,6 +101,8 @@ struct AdaPose {
   // bf16x3 on the default path: nothing reads the split-pair feature map (the sweep and the point heads gather from plain fp32), so
   // `final` writes fp32 directly; the A/B paths (materialised volume, halo-tile conv0, per-sample BN) still want split pairs
   bool feat_f32_only() const;
+  // the conditions under which cost_volume() skips tiles outside the chosen pixels' dependency cones (option sparse_dec)
+  bool sparse_active() const;
 };
 
 const char* last_error_cstr();

@@ -5,16 +5,44 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "adapose.h"
 #include "control.h"
+#include "prof.h"
 
 using namespace rgbm;
+
+// One captured forward: the launch sequence of AdaPose::forward for a fixed batch size and fixed device pointers, replayed with a
+// single hipGraphLaunch (small batches are launch-bound: ~150 launches of a few microseconds each per forward).
+struct ForwardGraph {
+  int B = 0;
+  const void* in[7] = {nullptr};
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  rgbm_adapose_out out;
+  int opt_version = 0;
+  int debug_flags = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  size_t nodes = 0;
+  unsigned long long last_use = 0;
+};
 
 struct rgbm_adapose {
   AdaPose net;
   int device;
+  int opt_version = 0;                 // bumped by set_option / set_chunk: captured graphs of older settings are dropped
+  unsigned long long tick = 0;
+  std::vector<ForwardGraph> graphs;    // at most kMaxGraphs, least recently used evicted
 };
+static const size_t kMaxGraphs = 8;
+
+static void drop_graph(ForwardGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr; g.graph = nullptr;
+}
 
 
 extern "C" {
@@ -46,6 +74,7 @@ int rgbm_adapose_create(rgbm_adapose_t** h, int device, const rgbm_weight_desc* 
 
 int rgbm_adapose_destroy(rgbm_adapose_t* h) {
   if (!h) return 0;
+  for (auto& g : h->graphs) drop_graph(g);
   h->net.destroy();
   delete h;
   return 0;
@@ -54,6 +83,7 @@ int rgbm_adapose_destroy(rgbm_adapose_t* h) {
 int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views) {
   RGBM_REQUIRE(h && max_chunk_views > 0, "set_chunk arguments");
   h->net.max_chunk = max_chunk_views;
+  ++h->opt_version;
   return 0;
 }
 
@@ -69,6 +99,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "stem") { RGBM_REQUIRE(value == 0 || value == 1, "stem"); h->net.stem = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
+  ++h->opt_version;
   return 0;
 }
 
@@ -97,6 +128,70 @@ int rgbm_adapose_forward(rgbm_adapose_t* h, int B, const float* img1, const floa
                          const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
                          size_t workspace_bytes, const rgbm_adapose_out* out, void* stream) {
   return rgbm_adapose_forward_ex(h, B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, out, 0, stream);
+}
+
+int rgbm_adapose_graph_clear(rgbm_adapose_t* h) {
+  RGBM_REQUIRE(h, "graph_clear arguments");
+  for (auto& g : h->graphs) drop_graph(g);
+  h->graphs.clear();
+  return 0;
+}
+
+int rgbm_adapose_forward_graph(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
+                               const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
+                               size_t workspace_bytes, const rgbm_adapose_out* out, void* stream, int32_t* n_nodes, int32_t* captured) {
+  RGBM_REQUIRE(h && img1 && img2 && choose1 && choose2 && P1 && P2 && depths && workspace && out, "forward_graph arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_nodes) *n_nodes = 0;
+  if (captured) *captured = 0;
+  // the in-library profiler records events around launches: not capturable, and a timing run wants the launches themselves
+  if (prof_enabled()) {
+    if (captured) *captured = -1;
+    return h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out), s, 0);
+  }
+  RGBM_REQUIRE(s != nullptr, "forward_graph: stream capture is not allowed on the default (null) stream; pass a created stream");
+  const void* in[7] = {img1, img2, choose1, choose2, P1, P2, depths};
+  ForwardGraph* hit = nullptr;
+  for (size_t i = 0; i < h->graphs.size();) {
+    ForwardGraph& g = h->graphs[i];
+    if (g.opt_version != h->opt_version || g.debug_flags != g_debug_flags) {      // settings changed since the capture
+      drop_graph(g);
+      h->graphs.erase(h->graphs.begin() + i);
+      continue;
+    }
+    if (g.B == B && !memcmp(g.in, in, sizeof(in)) && g.ws == workspace && g.ws_bytes == workspace_bytes &&
+        !memcmp(&g.out, out, sizeof(*out))) hit = &g;
+    ++i;
+  }
+  if (!hit) {
+    // an eager forward first: it sets the dynamic-LDS attributes of the kernels this shape uses and loads their code objects (neither
+    // may happen inside a capture), and reports argument errors with their own messages
+    if (int rc = h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out), s, 0)) return rc;
+    ForwardGraph g;
+    g.B = B; memcpy(g.in, in, sizeof(in)); g.ws = workspace; g.ws_bytes = workspace_bytes; g.out = *out;
+    g.opt_version = h->opt_version; g.debug_flags = g_debug_flags;
+    RGBM_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out), s, 0);
+    const hipError_t ee = hipStreamEndCapture(s, &g.graph);
+    if (rc) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+    if (ee != hipSuccess || !g.graph) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee)); return -2; }
+    if (hipGraphGetNodes(g.graph, nullptr, &g.nodes) != hipSuccess) g.nodes = 0;
+    const hipError_t ei = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { (void)hipGraphDestroy(g.graph); set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); return -2; }
+    if (h->graphs.size() >= kMaxGraphs) {
+      size_t lru = 0;
+      for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+      drop_graph(h->graphs[lru]);
+      h->graphs.erase(h->graphs.begin() + lru);
+    }
+    h->graphs.push_back(g);
+    hit = &h->graphs.back();
+    if (captured) *captured = 1;
+  }
+  hit->last_use = ++h->tick;
+  if (n_nodes) *n_nodes = (int32_t)hit->nodes;
+  RGBM_CHECK_HIP(hipGraphLaunch(hit->exec, s));
+  return 0;
 }
 
 int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* name, float* out_dev, size_t capacity,
@@ -128,10 +223,16 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
   else if (nm == "u11") { src = bf.u11; cnt = Vc * D * S * S * 8; }
   else if (nm == "homog") { src = bf.homog; cnt = V * 12; dt = F32; }
   else if (nm == "prob") { src = bf.prob; cnt = V * P * D; dt = F32; }
-  else if (nm == "pf96") { src = bf.PF96; cnt = V * P * 96; dt = F32; }
+  // pf96: after a forward of a split-pair net the buffer holds hi / lo pairs (adapose.cpp converts it in place for the pose MLP)
+  else if (nm == "pf96") { src = bf.PF96; cnt = V * P * 96; dt = n.pose_dtype() == BF16X3 ? BF16X3 : F32; }
   else if (nm == "pf2") { src = bf.pf2; cnt = V * 256; dt = F32; }
   else if (nm == "r6") { src = bf.r6; cnt = V * 6; dt = F32; }
   RGBM_REQUIRE(src != nullptr, "unknown intermediate name: " + nm);
+  // with sparse cost regularisation c0..c5 / u7 / u9 are written only inside the chosen pixels' dependency cones (and c6 is computed
+  // from them): the rest of these tensors is whatever the workspace held, so a tap of them is refused instead of returned partly stale
+  const bool tap3d = nm == "c0" || nm == "c2" || nm == "c4" || nm == "c6" || nm == "u7" || nm == "u9";
+  RGBM_REQUIRE(!(tap3d && n.sparse_active()), "tap '" + nm + "' needs a dense cost regularisation: set option sparse_dec = 0 before the forward "
+               "(the default computes it only inside the chosen pixels' dependency cones)");
   *n_elems = cnt;
   RGBM_REQUIRE(cnt <= capacity, "fetch capacity too small");
   return launch_to_f32(dt, src, out_dev, (long long)cnt, (hipStream_t)stream);

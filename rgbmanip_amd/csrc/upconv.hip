@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                                          // hipcc sink each block position's accumulation chain into its store's branch)
         float r[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) r[e] = acc[a][b][e] >= 0.f ? acc[a][b][e] : acc[a][b][e] * nslope;      // NaN stays NaN
+        for (int e = 0; e < E; ++e) r[e] = acc[a][b][e] < 0.f ? __builtin_fmaxf(acc[a][b][e], -3.402823466e38f) * nslope : acc[a][b][e];      // NaN stays NaN
         store4(ob + ((long long)oy * Wo + ox) * ldo, r);
       }
     }
@@ -223,7 +223,8 @@ int launch_upconv_combine(int dtype, const void* z, const float* bias, void* out
   const double nout = (double)V * 4.0 * h * w * Co;
   // profiler rows 37 (16-bit storage) / 38 (4-byte slots); algorithmic flops: 36 multiply-adds per output element; bytes: z in + y out
   prof_begin_launch(s, dtype_size(dtype) == 2 ? 37 : 38, 72.0 * nout, ((double)V * h * w * 9.0 * Co + nout) * (double)dtype_size(dtype));
-  // one branch-free activation: y = v >= 0 ? v : v * nslope (none: 1, ReLU: 0, PReLU: its slope); per-element branches on `act`
+  // one branch-free activation: y = v < 0 ? max(v, -FLT_MAX) * nslope : v (none: 1, ReLU: 0, PReLU: its slope; NaN stays NaN, -inf
+  // under ReLU gives -0 instead of NaN, the form conv_igemm_glds.hip uses); per-element branches on `act`
   // made hipcc sink every accumulation chain into the epilogue (all interpolated values live at once)
   const float nslope = act == ACT_NONE ? 1.f : act == ACT_RELU ? 0.f : slope;
   int rc;

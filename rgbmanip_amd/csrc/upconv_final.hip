@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int b = 0; b < 4; ++b) {
       float r[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = acc[a][b][e] >= 0.f ? acc[a][b][e] : acc[a][b][e] * nslope;
+      for (int e = 0; e < 4; ++e) r[e] = acc[a][b][e] < 0.f ? __builtin_fmaxf(acc[a][b][e], -3.402823466e38f) * nslope : acc[a][b][e];
       const int p = (4 * bi + a) * 16 + 4 * bj + b;
       store4(reinterpret_cast<T*>(Ys + p * XROW) + 4 * g, r);
     }

@@ -14,6 +14,8 @@ is then a seeded hash, cfg["hip_prepare_seed"]); `estimate_device` takes device-
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -112,8 +114,11 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 if logger is not None:
                     logger.warning("AdaPoseEstimator_v5: cfg.load is False -> synthetic (seeded) weights")
         self.dtype = dtype or cfg.get("hip_dtype", "bf16x3")      # the fastest mode inside north_star's 1e-4 (fp32: 4x slower, bf16: 2.4x faster at 1e-2)
+        # hip_graph: batches of at most hip_graph_max_batch poses replay a captured hipGraph (the per-env / num_envs: 8 deployment path)
         self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device,
-                                                                norm_mode=cfg.get("hip_norm_mode", "eval"))
+                                                                norm_mode=cfg.get("hip_norm_mode", "eval"),
+                                                                graph=bool(cfg.get("hip_graph", True)),
+                                                                graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)))
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
         self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))
@@ -162,10 +167,11 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         S = self.cfg["img_size"]
         n = len(rgb1_batch)
         if self.prepare_mode == "device":
-            return self.estimate_device(np.asarray(camera_intrinsic_batch), np.asarray(rgb1_batch, dtype=np.float32),
-                                        np.asarray(view1_mask_batch), np.asarray(view1_extrinsic_batch),
-                                        np.asarray(rgb2_batch, dtype=np.float32), np.asarray(view2_mask_batch),
-                                        np.asarray(view2_extrinsic_batch)).cpu().numpy()
+            # host frames -> device through pinned, double-buffered chunks (conversion to float32 on all host cores, copy overlapped);
+            # the controller hands [N,480,640,3] float64 arrays over (rl_pose.py:210-218): 3.8 GB per call at N = 256
+            return self.estimate_device(np.asarray(camera_intrinsic_batch), self._upload_frames(rgb1_batch), self._upload_masks(view1_mask_batch),
+                                        np.asarray(view1_extrinsic_batch), self._upload_frames(rgb2_batch),
+                                        self._upload_masks(view2_mask_batch), np.asarray(view2_extrinsic_batch)).cpu().numpy()
         out = np.repeat(DEFAULT_BBOX[None], n, axis=0)
         rows, img1, img2, ch1, ch2, P1, P2, K1, E1 = [], [], [], [], [], [], [], [], []
         pt1, pt2, E2, K0 = [], [], [], []                    # the PnP branch also needs the pixels, the second extrinsic and the original K
@@ -198,6 +204,53 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         bbox = self._bbox_tail(pred, ch1, np.stack(K1), np.stack(E1), pts2d=(np.stack(pt1), np.stack(pt2)), E2=np.stack(E2), K=np.stack(K0))
         out[np.asarray(rows)] = bbox.cpu().numpy()
         return out
+
+    # ------------------------------------------------------------------ host frames -> HBM
+    _CHUNK_BYTES = 64 << 20
+
+    def _upload_frames(self, frames):
+        """[N,H,W,3] host frames (float64 / float32 in [0,1], or uint8) -> CUDA float32 [N,H,W,3] in [0,1].  Frames that already are
+        CUDA tensors pass through.  The conversion to float32 runs multi-threaded (torch CPU copy) straight into one of two pinned
+        staging buffers while the previous chunk's copy is in flight; uint8 frames travel as bytes and are scaled on the device."""
+        if isinstance(frames, torch.Tensor) and frames.is_cuda:
+            return frames.to(torch.float32) if frames.dtype != torch.uint8 else frames.to(torch.float32) / 255.0
+        src = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(frames)))
+        dev = self.estimator.device
+        as_bytes = src.dtype == torch.uint8
+        if not as_bytes and not src.dtype.is_floating_point:
+            raise TypeError(f"estimate: rgb frames must be float images in [0, 1] or uint8, got {src.dtype}")
+        stage_dt = torch.uint8 if as_bytes else torch.float32
+        n = src.shape[0]
+        per = max(1, int(np.prod(src.shape[1:])))
+        rows = max(1, min(n, self._CHUNK_BYTES // (per * (1 if as_bytes else 4))))
+        key = (rows, tuple(src.shape[1:]), stage_dt)
+        if getattr(self, "_stage_key", None) != key:
+            self._stage = [torch.empty((rows,) + tuple(src.shape[1:]), dtype=stage_dt, pin_memory=True) for _ in range(2)]
+            self._stage_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._stage_key = key
+            self._stage_used = [False, False]
+        out = torch.empty(tuple(src.shape), dtype=stage_dt, device=dev)
+        for i, a in enumerate(range(0, n, rows)):
+            b = min(a + rows, n)
+            k = i & 1
+            if self._stage_used[k]:
+                self._stage_ev[k].synchronize()                    # the copy that last read this staging buffer has finished
+            self._stage[k][: b - a].copy_(src[a:b])                # dtype conversion + gather into pinned memory, on the host cores
+            out[a:b].copy_(self._stage[k][: b - a], non_blocking=True)
+            self._stage_ev[k].record()
+            self._stage_used[k] = True
+        return out.to(torch.float32) / 255.0 if as_bytes else out
+
+    def _upload_masks(self, masks):
+        """[N,H,W] host masks (bool / uint8 / any number type, non-zero = object) -> CUDA uint8."""
+        if isinstance(masks, torch.Tensor) and masks.is_cuda:
+            return masks
+        m = masks if isinstance(masks, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(masks)))
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8)
+        elif m.dtype != torch.uint8:
+            m = m.ne(0).view(torch.uint8)                              # multi-threaded on the host: 1 byte per pixel crosses PCIe
+        return m.to(self.estimator.device, non_blocking=False)
 
     # ------------------------------------------------------------------ the same pipeline without leaving the device
     def estimate_device(self, K, rgb1, mask1, E1, rgb2, mask2, E2):
@@ -255,6 +308,15 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                                       seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
         # use_depth False (interface_v5.py:340-346): NOCS matches of the two views -> scale -> EPnP-RANSAC + VVS on the ORIGINAL
         # intrinsics and the chosen points' pixels in the original frame
+        if not getattr(self, "_pnp_warned", False):
+            self._pnp_warned = True
+            msg = ("AdaPoseEstimator_v5: direct_regression=False with use_depth=False runs csrc/pnp.hip, a restatement of OpenCV's "
+                   "triangulatePoints / solvePnPRansac(EPNP) / solvePnPRefineVVS whose RANSAC subset stream and tie-breaks are NOT "
+                   "pinned against cv2 (no OpenCV in the build image; DESIGN.md section 2): poses agree with ground truth, inlier sets "
+                   "may differ from the reference's")
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            if self.logger is not None:
+                self.logger.warning(msg)
         return postprocess_pnp(pred["view1_nocs"], pts2d[0], pred["view2_nocs"], pts2d[1], K, E1, E2,
                                seed=int(self.cfg.get("hip_ransac_seed", 0)))[0]
 

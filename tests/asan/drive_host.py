@@ -88,6 +88,52 @@ for dtype, modes in ((_lib.F32, (0, 1)), (_lib.BF16, (0,)), (_lib.F16, (0,)), (_
         _lib.check(lib.rgbm_adapose_destroy(h), "destroy")
         runs += 1
 
+# the hipGraph cache of rgbm_adapose_forward_graph: capture, replay, least-recently-used eviction past 8 entries, invalidation by an
+# option change, the null-stream refusal, destroy with live graphs (the stub's graph handles are heap blocks: leaks / double frees show)
+h = create(_lib.BF16, 0)
+keep = []
+
+
+def fwd_graph(B, slot, stream=C.c_void_p(1)):
+    key = (B, slot)
+    bufs = next((b for k, b in keep if k == key), None)
+    if bufs is None:
+        n = C.c_size_t()
+        _lib.check(lib.rgbm_adapose_workspace_bytes(h, B, C.byref(n)), "workspace_bytes")
+        ws = np.empty(n.value + 256, dtype=np.uint8)
+        inp = synth.adapose_inputs(B, seed=1)
+        arrs = [np.ascontiguousarray(inp[k], dtype=np.float32) for k in ("img1", "img2")] + \
+               [np.ascontiguousarray(inp[k], dtype=np.int32) for k in ("choose1", "choose2")] + \
+               [np.ascontiguousarray(inp[k], dtype=np.float32) for k in ("P1", "P2", "depths")]
+        outs = [np.empty(sh, np.float32) for sh in ((B, 1024, 3), (B, 1024, 3), (B, 1024), (B, 1024), (B, 3, 3), (B, 3, 3), (B, 3), (B, 3),
+                                                    (B, 3), (B, 3))]
+        bufs = (ws, arrs, outs, n.value)
+        keep.append((key, bufs))
+    ws, arrs, outs, nbytes = bufs
+    base = ws.ctypes.data + ((-ws.ctypes.data) % 256)
+    out = _lib.AdaposeOut(*[o.ctypes.data for o in outs])
+    nodes, cap = C.c_int32(), C.c_int32()
+    rc = lib.rgbm_adapose_forward_graph(h, B, *[vp(a) for a in arrs], C.c_void_p(base), nbytes, C.byref(out), stream, C.byref(nodes),
+                                        C.byref(cap))
+    return rc, nodes.value, cap.value
+
+
+assert fwd_graph(1, 0) == (0, 7, 1) and fwd_graph(1, 0) == (0, 7, 0)          # capture, then replay
+assert fwd_graph(1, 0, stream=None)[0] != 0                                    # the null stream cannot be captured
+for slot in range(1, 10):                                                      # ten distinct pointer sets: evicts the oldest two
+    assert fwd_graph(2, slot)[2] == 1
+assert fwd_graph(2, 9)[2] == 0 and fwd_graph(1, 0)[2] == 1                     # the newest is cached, the oldest was evicted
+_lib.check(lib.rgbm_adapose_set_option(h, b"sparse_dec", 0), "set_option")     # settings changed: every graph is dropped
+assert fwd_graph(2, 9)[2] == 1
+_lib.check(lib.rgbm_prof_start(), "prof_start")                                # profiler on: eager, reported as -1
+assert fwd_graph(2, 9)[2] == -1
+stats = (C.c_double * (4 * _lib.PROF_ROWS))()
+_lib.check(lib.rgbm_prof_stop(stats), "prof_stop")
+_lib.check(lib.rgbm_adapose_graph_clear(h), "graph_clear")
+assert fwd_graph(2, 9)[2] == 1
+_lib.check(lib.rgbm_adapose_destroy(h), "destroy")                             # with a live graph
+runs += 1
+
 # the post-processing launchers' host code (the kernels themselves are no-ops here)
 B, P = 3, 1024
 f32 = lambda *s: np.zeros(s, np.float32)      # noqa: E731

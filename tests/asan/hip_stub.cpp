@@ -34,6 +34,15 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+// stream capture / graphs: handles are small heap blocks (so leaks and double frees of the library's graph cache are visible to the
+// sanitizer); a "captured" stream still executes nothing, like every launch of this stand-in
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = reinterpret_cast<hipGraph_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { *n = 7; return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = reinterpret_cast<hipGraphExec_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { std::free(e); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { std::free(g); return hipSuccess; }
 // registration of the (absent) device code objects
 void** __hipRegisterFatBinary(const void*) { static void* h[4]; return h; }
 void __hipUnregisterFatBinary(void**) {}

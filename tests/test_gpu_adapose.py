@@ -170,6 +170,66 @@ def test_bf16x3_intermediates_vs_oracle(inputs, oracle_taps):
         assert e < RTOL_FP32, (k, errs)
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+def test_pf96_tap_after_a_full_forward(inputs, oracle_taps, dtype):
+    """`pf96` ([view][point][32 depth-fused feature channels | 64 nocs_pts_mlp channels]) fetched AFTER a whole forward: a split-pair
+    net has converted the buffer in place to hi / lo pairs for the pose MLP by then, and the tap has to undo that (round-3 advisor:
+    it used to reinterpret the pair bits as fp32)."""
+    _, taps = oracle_taps
+    net = _net(dtype)
+    _run(net, inputs)
+    pf = net.fetch(2, "pf96", 4 * 1024 * 96).view(4, 1024, 96)[:2].cpu().numpy()
+    assert np.isfinite(pf).all()
+    e = _rel(np.transpose(pf[:, :, :32], (0, 2, 1)), taps["v1_fg"].numpy())
+    print(dtype, "pf96[:32] vs oracle fg", e)
+    assert e < RTOL_FP32, e
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+def test_3d_taps_are_refused_under_sparse_cost_regularisation(inputs, dtype):
+    """With the default (sparse_dec = 2) c0 .. u9 are written only inside the chosen pixels' dependency cones: fetching them must
+    fail loudly instead of returning partly stale tensors; with sparse_dec = 0 the same call works."""
+    from rgbmanip_amd import _lib
+    net = _net(dtype)
+    _run(net, inputs, stop_after=2)
+    for name in ("c0", "c2", "c4", "c6", "u7", "u9"):
+        with pytest.raises(_lib.RgbmError, match="sparse_dec"):
+            net.fetch(2, name, 4 * 24 * 224 * 224 * 8)
+    assert net.fetch(2, "prob", 4 * 1024 * 24).numel() == 4 * 1024 * 24
+    dense = _net(dtype, options={"sparse_dec": 0})
+    _run(dense, inputs, stop_after=2)
+    assert dense.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).numel() == 4 * 24 * 224 * 224 * 8
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "fp32"])
+def test_graph_replay_is_bit_identical_to_eager(dtype):
+    """`AdaPoseNet(graph=True)` (rgbm_adapose_forward_graph: the forward of a batch size captured once into a hipGraph, static
+    buffers, one hipGraphLaunch per call) against the eager launch sequence at B = 1, 2 and 8, alternating batch sizes and inputs:
+    every output bit-identical, the capture happens once per batch size, and a changed option drops the stale graph."""
+    eager = _net(dtype)
+    graph = _net(dtype, graph=True)
+    nodes = {}
+    for rnd, (B, seed) in enumerate([(1, 3), (8, 4), (1, 5), (2, 6), (8, 7), (2, 6)]):
+        inp = synth.adapose_inputs(B, seed=seed)
+        a = _run(eager, inp)
+        b = _run(graph, inp)
+        assert graph.last_graph_nodes > 50, graph.last_graph_nodes      # a whole forward: ~150 kernel launches + copies
+        nodes.setdefault(B, graph.last_graph_nodes)
+        assert nodes[B] == graph.last_graph_nodes
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{dtype} round {rnd} B={B} {k}")
+    print(dtype, "graph nodes per batch size:", nodes)
+    # an option change invalidates the captured graphs (the dense decoder launches other kernels)
+    from rgbmanip_amd import _lib
+    if dtype != "fp32":
+        _lib.check(graph.lib.rgbm_adapose_set_option(graph._h, b"sparse_dec", 0))
+        _lib.check(eager.lib.rgbm_adapose_set_option(eager._h, b"sparse_dec", 0))
+        inp = synth.adapose_inputs(2, seed=9)
+        a, b = _run(eager, inp), _run(graph, inp)
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{dtype} after option change {k}")
+
+
 def test_fp32_batch_invariance_and_chunking():
     """B=3 with a chunked cost volume (4 views per chunk, ragged last chunk) equals per-pose results."""
     inp3 = synth.adapose_inputs(3, seed=5)
@@ -448,6 +508,16 @@ def test_estimate_device_prepare_matches_host_prepare():
     assert np.array_equal(b_host[2], b_dev[2])            # empty mask -> default bbox on both paths
     assert np.allclose(b_host[2], np.asarray([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]]) + 10.0)
     np.testing.assert_allclose(b_dev, b_host, rtol=1e-6, atol=1e-7)
+    # the upload path of estimate(): float64 frames (what rl_pose.py:210-218 hands over) and bool masks through pinned chunks — several
+    # chunks per call when the staging buffers are small — give the float32 frames' boxes bit for bit; uint8 frames are scaled by 1/255
+    # on the device exactly as the host path scales them
+    dev._CHUNK_BYTES = 3 * 480 * 640 * 3 * 4 // 2          # one frame per chunk
+    b64 = dev.estimate(K, rgb.astype(np.float64), mask.astype(bool), E1, rgb2.astype(np.float64), mask2.astype(bool), E2)
+    np.testing.assert_array_equal(b64, b_dev)
+    u1, u2 = (np.clip(np.rint(x * 255.0), 0, 255).astype(np.uint8) for x in (rgb, rgb2))
+    b_u8_host = host.estimate(K, u1, mask, E1, u2, mask2, E2)
+    b_u8_dev = dev.estimate(K, u1, mask.astype(np.float32), E1, u2, mask2.astype(np.float32), E2)
+    np.testing.assert_allclose(b_u8_dev, b_u8_host, rtol=1e-6, atol=1e-7)
 
 
 def test_device_control_queue_matches_reference_golden(golden_dir):

@@ -156,10 +156,15 @@ def test_sparse_cost_regularisation_is_bit_identical_to_dense(inputs256, dtype):
         ch[2] = torch.full((1024,), 100 * 224 + 7).to(ch)
         ch[3] = torch.sort(torch.randperm(224 * 224, generator=g)[:1024])[0].to(ch)
     outs = {}
-    for sd in (0, 1, 2):
-        net = _net(dtype, options={"sparse_dec": sd})
-        _forward(net, args)                                                # twice: the second run sees the first one's values in the skipped tiles
+    # The sparse nets run FIRST and with a poisoned workspace (every byte 0xFF = NaN / -1 in front of each forward): torch.empty +
+    # the caching allocator would otherwise hand them the block a previous dense net left behind — correct dense values in the same
+    # layout, so that a read of a skipped tile could not fail (round-3 verdict).  The dense reference runs last, also poisoned.
+    for sd in (2, 1, 0):
+        net = _net(dtype, options={"sparse_dec": sd}, poison_workspace=True)
+        _forward(net, args)
         outs[sd] = {k: v.clone() for k, v in _forward(net, args).items()}
+        net.close()
+        del net
     for sd in (1, 2):
         for k in OUT_KEYS:
             assert torch.equal(outs[sd][k].view(torch.int32), outs[0][k].view(torch.int32)), (dtype, sd, k,
@@ -174,10 +179,12 @@ def test_sparse_cost_regularisation_with_a_chunked_cost_volume(inputs256, dtype)
     ragged last chunk) with sparse_dec = 2 must give the dense result of the same chunking bit for bit (another chunk size may pick
     other kernels for some layers, i.e. another summation order)."""
     args = _dev_inputs(inputs256, 20)
-    ref = {k: v.clone() for k, v in _forward(_net(dtype, max_chunk_views=24, options={"sparse_dec": 0}), args).items()}
-    net = _net(dtype, max_chunk_views=24)
+    net = _net(dtype, max_chunk_views=24, poison_workspace=True)      # sparse net first, workspace poisoned before every forward
     _forward(net, args)
-    cur = _forward(net, args)
+    cur = {k: v.clone() for k, v in _forward(net, args).items()}
+    net.close()
+    del net
+    ref = {k: v.clone() for k, v in _forward(_net(dtype, max_chunk_views=24, options={"sparse_dec": 0}, poison_workspace=True), args).items()}
     for k in OUT_KEYS:
         assert torch.equal(cur[k].view(torch.int32), ref[k].view(torch.int32)), (dtype, k, float((cur[k] - ref[k]).abs().max()))
 

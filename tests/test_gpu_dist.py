@@ -119,3 +119,27 @@ def test_bench_two_gpus_smoke():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["dist_backend"] == "nccl"
     assert line["config"]["parallelism"] == "dp2" and line["value"] > 0 and line["ppo"]["env_steps_per_sec"] > 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_device():
+    """The multi-rank code path of bench.py (rank-local inputs, max-over-ranks timing, the per-rank ms / tile-fraction table, the PPO
+    leg's per-rank times) on this box's ONE GPU: two ranks share cuda:0 and talk over gloo (RGBM_BENCH_ONE_DEVICE=1,
+    RGBM_DIST_BACKEND=gloo) — launched exactly as the driver launches `--gpus 2`.  RCCL itself needs one device per rank
+    (test_bench_two_gpus_smoke, armed for multi-GPU boxes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RGBM_BENCH_ONE_DEVICE="1", RGBM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16", "--no-modes", "--ppo-envs", "16", "--ppo-iters", "1", "--no-prepare", "--no-mixed"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["dist_backend"] == "gloo" and line["scaling"] == "weak"
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["sweep_tiles_needed_frac"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"]
+    assert abs(line["ms_per_step"] - pr["ms_per_step_max"]) / line["ms_per_step"] < 0.25      # `value` is priced on the slowest rank
+    assert pr["sweep_tiles_needed_frac"][0] != pr["sweep_tiles_needed_frac"][1]               # rank-local inputs (seeded by rank)
+    assert len(line["ppo"]["per_rank"]["collection_s"]) == 2 and line["ppo"]["env_steps_per_sec_all_ranks"] > 0
