@@ -94,6 +94,14 @@ int rgbm_adapose_forward(rgbm_adapose_t* h, int B, const float* img1, const floa
 int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, const float* depth1, const float* r1,
                              const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
                              int32_t* valid, void* stream);
+/* The same post-processing with caller-provided device scratch (rgbm_adapose_postprocess_scratch_bytes(B) bytes, 8-byte aligned,
+ * contents irrelevant; 0 bytes = not needed at this batch size): small batches cut the three passes over the 523 776 point pairs of
+ * the exact-median search into up to 32 slices per pose (one workgroup each) instead of running one workgroup per pose — 1.1 ms of
+ * a 2.9 ms B = 1 call otherwise.  Results are bit-identical to rgbm_adapose_postprocess. */
+int rgbm_adapose_postprocess_scratch_bytes(int B, size_t* bytes);
+int rgbm_adapose_postprocess_ws(int B, int P, int img_size, const float* nocs1, const float* depth1, const float* r1,
+                                const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
+                                int32_t* valid, void* scratch, size_t scratch_bytes, void* stream);
 
 /* The `direct_regression: False`, `use_depth: True` tail of predict: back-projected predicted depth vs
  * predicted NOCS, 128-hypothesis Umeyama RANSAC, final fit over the inliers, bbox to the world frame.
@@ -141,6 +149,13 @@ int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* mask_dev, c
                                 int N, int H, int W, int S, int P, uint32_t seed, float* img_out, int32_t* choose_out,
                                 float* pts2d_out, double* Kcrop_out, int32_t* window_out, int32_t* valid_out, uint8_t* scratch,
                                 void* stream);
+/* Both of the above with a hash offset: frame f of this call draws its 1024-subset as frame frame0 + f would in one call over the
+ * whole batch, so a batch prepared in pieces (estimate() uploads and prepares host frames chunk by chunk while the previous chunk
+ * computes) chooses the same pixels as the unchunked call.  frame_map_dev may be null (frames in order). */
+int rgbm_prepare_inputs_ex(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, const int32_t* frame_map_dev,
+                           int frame0, int N, int H, int W, int S, int P, uint32_t seed, float* img_out, int32_t* choose_out,
+                           float* pts2d_out, double* Kcrop_out, int32_t* window_out, int32_t* valid_out, uint8_t* scratch,
+                           void* stream);
 
 /* Per-env mask extent for the controller's view queue.
  * Replaces: the np.nonzero / np.where loop of ControlInterface.add_view   models/controller/rl_pose.py:130-149
@@ -349,6 +364,10 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
  *                                                                                  (default since round 3: channel block outer, taps inner) */
 int rgbm_debug_flags(int flags);
+/* dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
+ * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = per storage type:
+ * 1024 for 16-bit storage, 8192 for fp32 / split pairs (measured at B = 1 and B = 8; rounds 1-3 used 65536 for all). */
+int rgbm_set_tuning(const char* key, long long value);
 /* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
  * flags are then ignored */
 int rgbm_has_experiments(void);

@@ -101,6 +101,8 @@ SIGNATURES = {
     "rgbm_adapose_graph_clear": (_i, [_vp]),
     "rgbm_adapose_fetch": (_i, [_vp, _i, _vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "rgbm_adapose_postprocess": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_adapose_postprocess_scratch_bytes": (_i, [_i, C.POINTER(_sz)]),
+    "rgbm_adapose_postprocess_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rgbm_adapose_postprocess_ransac": (_i, [_i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_adapose_postprocess_pnp": (_i, [_i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_gae": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
@@ -123,6 +125,7 @@ SIGNATURES = {
     "rgbm_conv0_sweep_dt": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_prepare_inputs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_prepare_inputs_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbm_prepare_inputs_ex": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_projection": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rgbm_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rgbm_lookat_quat": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -132,6 +135,7 @@ SIGNATURES = {
     "rgbm_synth_camera": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_synth_render": (_i, [C.POINTER(SynthScene), _vp, _vp, _vp, _vp]),
     "rgbm_debug_flags": (_i, [_i]),
+    "rgbm_set_tuning": (_i, [C.c_char_p, _i64]),
     "rgbm_prof_rows": (_i, []),
     "rgbm_has_experiments": (_i, []),
     "rgbm_prof_start": (_i, []),

@@ -208,9 +208,13 @@ def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_
     bbox = torch.empty(B, 8, 3, dtype=torch.float64, device=dev)
     ts = torch.empty(B, 4, dtype=torch.float64, device=dev)
     valid = torch.empty(B, dtype=torch.int32, device=dev)
-    _lib.check(lib.rgbm_adapose_postprocess(B, P, img_size, _lib.ptr(nocs), _lib.ptr(depth), _lib.ptr(r), _lib.ptr(ch),
-                                            _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(ts), _lib.ptr(valid),
-                                            _lib.stream_ptr(stream)), "rgbm_adapose_postprocess")
+    # small batches: the exact-median search is sliced over several workgroups per pose (needs device scratch; bit-identical)
+    nb = C.c_size_t()
+    _lib.check(lib.rgbm_adapose_postprocess_scratch_bytes(B, C.byref(nb)), "rgbm_adapose_postprocess_scratch_bytes")
+    scratch = torch.empty(nb.value // 8, dtype=torch.int64, device=dev) if nb.value else None
+    _lib.check(lib.rgbm_adapose_postprocess_ws(B, P, img_size, _lib.ptr(nocs), _lib.ptr(depth), _lib.ptr(r), _lib.ptr(ch),
+                                               _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(ts), _lib.ptr(valid),
+                                               _lib.ptr(scratch), nb.value, _lib.stream_ptr(stream)), "rgbm_adapose_postprocess_ws")
     return bbox, ts, valid
 
 
@@ -256,7 +260,7 @@ def postprocess_pnp(view1_nocs, view1_pts2d, view2_nocs, view2_pts2d, K, E1, E2,
 
 
 def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: int = 0, want_pts2d: bool = False, stream=None,
-                   frame_map=None):
+                   frame_map=None, frame0: int = 0):
     """Batched device-side `AdaPoseEstimator_v5.prepare_model_input` (`interface_v5.py:58-170`).
 
     rgb [N,H,W,3] float32 in [0,1], mask [N,H,W] (0/1), K [N,3,3]: torch CUDA tensors (or anything torch.as_tensor accepts).
@@ -288,7 +292,10 @@ def prepare_inputs(rgb, mask, K, img_size: int = 224, n_pts: int = 1024, seed: i
     scratch = torch.empty(N * S * S, dtype=torch.uint8, device=dev)
     tail = (N, H, W, S, P, int(seed) & 0xFFFFFFFF, _lib.ptr(img), _lib.ptr(choose), _lib.ptr(pts2d), _lib.ptr(Kcrop), _lib.ptr(window),
             _lib.ptr(valid), _lib.ptr(scratch), _lib.stream_ptr(stream))
-    if frame_map is None:
+    if frame0:          # a piece of a larger batch: frame f hashes as frame frame0 + f of the whole batch would
+        _lib.check(lib.rgbm_prepare_inputs_ex(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), _lib.ptr(frame_map), int(frame0), *tail),
+                   "rgbm_prepare_inputs_ex")
+    elif frame_map is None:
         _lib.check(lib.rgbm_prepare_inputs(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), *tail), "rgbm_prepare_inputs")
     else:
         _lib.check(lib.rgbm_prepare_inputs_indexed(_lib.ptr(rgb), _lib.ptr(mask), _lib.ptr(K), _lib.ptr(frame_map), *tail),

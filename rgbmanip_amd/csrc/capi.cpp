@@ -22,7 +22,7 @@ struct ForwardGraph {
   size_t ws_bytes = 0;
   rgbm_adapose_out out;
   int opt_version = 0;
-  int debug_flags = 0;
+  int tuning_version = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   size_t nodes = 0;
@@ -154,7 +154,7 @@ int rgbm_adapose_forward_graph(rgbm_adapose_t* h, int B, const float* img1, cons
   ForwardGraph* hit = nullptr;
   for (size_t i = 0; i < h->graphs.size();) {
     ForwardGraph& g = h->graphs[i];
-    if (g.opt_version != h->opt_version || g.debug_flags != g_debug_flags) {      // settings changed since the capture
+    if (g.opt_version != h->opt_version || g.tuning_version != g_tuning_version) {      // settings changed since the capture
       drop_graph(g);
       h->graphs.erase(h->graphs.begin() + i);
       continue;
@@ -169,7 +169,7 @@ int rgbm_adapose_forward_graph(rgbm_adapose_t* h, int B, const float* img1, cons
     if (int rc = h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out), s, 0)) return rc;
     ForwardGraph g;
     g.B = B; memcpy(g.in, in, sizeof(in)); g.ws = workspace; g.ws_bytes = workspace_bytes; g.out = *out;
-    g.opt_version = h->opt_version; g.debug_flags = g_debug_flags;
+    g.opt_version = h->opt_version; g.tuning_version = g_tuning_version;
     RGBM_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = h->net.forward(B, img1, img2, choose1, choose2, P1, P2, depths, workspace, workspace_bytes, to_out(out), s, 0);
     const hipError_t ee = hipStreamEndCapture(s, &g.graph);
@@ -243,6 +243,20 @@ int rgbm_adapose_postprocess(int B, int P, int img_size, const float* nocs1, con
                              int32_t* valid, void* stream) {
   RGBM_REQUIRE(B > 0 && nocs1 && depth1 && r1 && choose1 && Kcrop && E1 && bbox_world && ts && valid, "postprocess arguments");
   return launch_postprocess(nocs1, depth1, r1, choose1, Kcrop, E1, bbox_world, ts, valid, B, P, img_size, (hipStream_t)stream);
+}
+
+int rgbm_adapose_postprocess_scratch_bytes(int B, size_t* bytes) {
+  RGBM_REQUIRE(B > 0 && bytes, "postprocess_scratch_bytes arguments");
+  *bytes = postprocess_slices(B) > 1 ? postprocess_scratch_bytes(B) : 0;
+  return 0;
+}
+
+int rgbm_adapose_postprocess_ws(int B, int P, int img_size, const float* nocs1, const float* depth1, const float* r1,
+                                const int32_t* choose1, const double* Kcrop, const double* E1, double* bbox_world, double* ts,
+                                int32_t* valid, void* scratch, size_t scratch_bytes, void* stream) {
+  RGBM_REQUIRE(B > 0 && nocs1 && depth1 && r1 && choose1 && Kcrop && E1 && bbox_world && ts && valid, "postprocess arguments");
+  return launch_postprocess(nocs1, depth1, r1, choose1, Kcrop, E1, bbox_world, ts, valid, B, P, img_size, (hipStream_t)stream,
+                            scratch, scratch_bytes);
 }
 
 int rgbm_adapose_postprocess_ransac(int B, int P, int img_size, uint32_t seed, const float* nocs1, const float* depth1,
@@ -434,6 +448,15 @@ extern "C" int rgbm_prepare_inputs_indexed(const float* rgb_dev, const uint8_t* 
                                Kcrop_out, window_out, valid_out, scratch, (hipStream_t)stream);
 }
 
+extern "C" int rgbm_prepare_inputs_ex(const float* rgb_dev, const uint8_t* mask_dev, const double* K_dev, const int32_t* frame_map_dev,
+                                      int frame0, int N, int H, int W, int S, int P, uint32_t seed, float* img_out, int32_t* choose_out,
+                                      float* pts2d_out, double* Kcrop_out, int32_t* window_out, int32_t* valid_out, uint8_t* scratch,
+                                      void* stream) {
+  RGBM_REQUIRE(frame0 >= 0, "prepare_inputs_ex frame0");
+  return launch_prepare_inputs(rgb_dev, mask_dev, K_dev, frame_map_dev, N, H, W, S, P, seed, img_out, choose_out, pts2d_out,
+                               Kcrop_out, window_out, valid_out, scratch, (hipStream_t)stream, frame0);
+}
+
 extern "C" int rgbm_adapose_postprocess_pnp(int B, int P, uint32_t seed, const float* nocs1, const float* pts2d1, const float* nocs2,
                                             const float* pts2d2, const double* K, const double* E1, const double* E2, double* bbox_out,
                                             double* srt_out, int32_t* info_out, int32_t* valid_out, void* stream) {
@@ -476,7 +499,16 @@ extern "C" int rgbm_synth_render(const rgbm_synth_scene* scene, const double* ra
                                    (hipStream_t)stream);
 }
 
-extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; return 0; }
+extern "C" int rgbm_debug_flags(int flags) { rgbm::g_debug_flags = flags; ++rgbm::g_tuning_version; return 0; }
+
+extern "C" int rgbm_set_tuning(const char* key, long long value) {
+  RGBM_REQUIRE(key != nullptr, "set_tuning arguments");
+  const std::string k = key;
+  if (k == "ws_min_rows") { RGBM_REQUIRE(value >= 0, "ws_min_rows"); rgbm::g_ws_min_rows = value; }
+  else { set_error("unknown tuning key " + k); return -1; }
+  ++rgbm::g_tuning_version;
+  return 0;
+}
 
 // ---- PPO policy -------------------------------------------------------------------------------------------------
 static_assert(sizeof(rgbm_policy_layout) == sizeof(rgbm::PolicyLayout), "policy layout ABI mismatch");

@@ -90,6 +90,7 @@ struct SweepDesc {
 struct Corner {                     // everything the blend of one plane needs besides the gathered data
   unsigned off[4];                  // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
   float w[4];                       // bilinear weights: 0 for a corner outside the image, NaN for a non-finite projection
+  unsigned wp[2];                   // blend mode 2: {bf16(w0) | bf16(w1) << 16, bf16(w2) | bf16(w3) << 16}
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -120,18 +121,61 @@ template <> struct Sw16<f16_t> {
   }
 };
 
-template <typename T>
+// Blend modes of the bf16 producers (template parameter BL of the kernel; rgbm_debug_flags 2097152 / 4194304 select 1 / 0 for A/B):
+//   0  packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add_f32 on unpacked channel pairs): 8 unpack + 5 packed + 1 convert per
+//      dword.  Packed fp32 instructions next to another wave's MFMA stream on the same SIMD cost far more than their issue slot
+//      (MI355X_MICROARCH.md: one v_pk_fma_f32 instead of two v_fma_f32 = +22 cycles) — and three of the four producers share
+//      their SIMD with a consumer.
+//   1  the same sum on scalar v_fma_f32 (inline asm: the SLP vectoriser would re-pack plain C): 8 unpack + 10 + 1 per dword,
+//      bit-identical to mode 0.
+//   2  [default] channel pairs stay packed: v_perm_b32 puts the low (high) halves of two corners' dwords side by side and
+//      v_dot2_f32_bf16 multiplies them by the corner weights as a bf16 pair, accumulating in fp32 on top of the reference feature:
+//      4 perm + 4 dot2 + 1 convert per dword, no packed-fp32 instruction.  The products are exact (bf16 x bf16 in fp32), the weights
+//      carry 8 significant bits — the rounding the gathered features already have; a corner outside the image keeps weight 0 exactly,
+//      a non-finite projection keeps NaN.
+template <typename T, int BL>
 __device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
-                                             const float* w) {
+                                             const Corner& cn) {
+  const float* w = cn.w;
   const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
   const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
   unsigned o[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {       // one dword = two 16-bit channels -> one packed-f32 lane pair
-    const f32x2 fr = Sw16<T>::unpack(rr[q]), fa = Sw16<T>::unpack(aa[q]), fb = Sw16<T>::unpack(bb[q]);
-    const f32x2 fc = Sw16<T>::unpack(cc[q]), fe = Sw16<T>::unpack(ee[q]);
-    const f32x2 v = fr + (((fa * w[0] + fb * w[1]) + fc * w[2]) + fe * w[3]);
-    o[q] = Sw16<T>::pack(v);
+  for (int q = 0; q < 4; ++q) {       // one dword = two 16-bit channels
+    if constexpr (BL == 2) {
+      const f32x2 fr = Sw16<T>::unpack(rr[q]);
+      const unsigned ab_lo = __builtin_amdgcn_perm(bb[q], aa[q], 0x05040100u), ab_hi = __builtin_amdgcn_perm(bb[q], aa[q], 0x07060302u);
+      const unsigned ce_lo = __builtin_amdgcn_perm(ee[q], cc[q], 0x05040100u), ce_hi = __builtin_amdgcn_perm(ee[q], cc[q], 0x07060302u);
+      // (the builtin, not inline asm: a dot instruction's result needs three wait states before a VALU instruction of another
+      // kind may read it on gfx940+, which hipcc only honours for instructions it can see — an asm version of these four lines
+      // gave run-to-run different voxels)
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      const bf2 w01 = __builtin_bit_cast(bf2, cn.wp[0]), w23 = __builtin_bit_cast(bf2, cn.wp[1]);
+      float t0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ab_lo), w01, fr.x, false);
+      float t1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ab_hi), w01, fr.y, false);
+      t0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ce_lo), w23, t0, false);
+      t1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ce_hi), w23, t1, false);
+      o[q] = Sw16<T>::pack(f32x2{t0, t1});
+    } else if constexpr (BL == 1) {
+      const f32x2 fr = Sw16<T>::unpack(rr[q]), fa = Sw16<T>::unpack(aa[q]), fb = Sw16<T>::unpack(bb[q]);
+      const f32x2 fc = Sw16<T>::unpack(cc[q]), fe = Sw16<T>::unpack(ee[q]);
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float t;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(fa[h]), "v"(w[0]));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(fb[h]), "v"(w[1]), "v"(t));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(fc[h]), "v"(w[2]), "v"(t));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(fe[h]), "v"(w[3]), "v"(t));
+        asm("v_add_f32 %0, %1, %2" : "=v"(v[h]) : "v"(fr[h]), "v"(t));
+      }
+      o[q] = Sw16<T>::pack(f32x2{v[0], v[1]});
+    } else {
+      const f32x2 fr = Sw16<T>::unpack(rr[q]), fa = Sw16<T>::unpack(aa[q]), fb = Sw16<T>::unpack(bb[q]);
+      const f32x2 fc = Sw16<T>::unpack(cc[q]), fe = Sw16<T>::unpack(ee[q]);
+      const f32x2 v = fr + (((fa * w[0] + fb * w[1]) + fc * w[2]) + fe * w[3]);
+      o[q] = Sw16<T>::pack(v);
+    }
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -141,10 +185,10 @@ __device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, con
 // MODE.FP16_OVFL, so the final v_cvt_pk_f16_f32 saturates at +-65504 by itself (NaN stays NaN) — sat_f16() in front of it
 // costs 6 more instructions per dword.
 #define SW_MIX(HI, D, H, W, C) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(D) : "v"(H), "v"(W), "v"(C))
-template <>
-__device__ __forceinline__ uint4 blend_chunk<f16_t>(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
-                                                    const float* w) {
+__device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
+                                                 const Corner& cn) {
   typedef Sw16<f16_t>::h2 h2;
+  const float* w = cn.w;
   // (element copies: indexing the u32x4 references with the unrolled loop counter made hipcc use element 0 for all four)
   const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
   const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
@@ -171,7 +215,7 @@ __device__ __forceinline__ uint4 blend_chunk<f16_t>(const uint4& r, const u32x4&
 // min 3 waves per SIMD (<= 168 VGPRs): the hardware then starts the next workgroup's producers while this one's consumers
 // finish (12 wave slots per CU for 7-wave workgroups).  The bf16 instantiation needs 164 anyway; uncapped, the f16_t one
 // took 170 and lost that overlap.
-template <typename T>
+template <typename T, int BL>
 __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -250,6 +294,10 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       c.w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
       c.w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
       if (inb && !fin) c.w[0] = __builtin_nanf("");
+      if constexpr (BL == 2) {
+        c.wp[0] = pack2_bf16(c.w[0], c.w[1]);
+        c.wp[1] = pack2_bf16(c.w[2], c.w[3]);
+      }
       const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
       c.off[0] = (r0 + (unsigned)xc0) * 64u;
       c.off[1] = (r0 + (unsigned)xc1) * 64u;
@@ -268,6 +316,10 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
     // ended every step in `s_waitcnt vmcnt(0)` (seen in the ISA), i.e. no prefetch at all.  The asm results must not be
     // touched before gather_wait(): the empty-bodied asm there names them as in/out so every use is ordered after it.
     Corner cur, nxt;
+    auto blend = [](const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e, const Corner& cn) {
+      if constexpr (std::is_same<T, f16_t>::value) return blend_chunk_f16(r, a, b, c, e, cn);
+      else return blend_chunk<T, BL>(r, a, b, c, e, cn);
+    };
     u32x4 g[4][4];                                       // [chunk][corner]
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -300,22 +352,22 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
         unsigned char* dst = dst0 + (z % SW_NSLOT) * SW_SLOT;
         SW_WAIT12(0);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst) = blend_chunk<T>(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur.w);
+        *reinterpret_cast<uint4*>(dst) = blend(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur);
         SW_GATHER4(0, nxt);
         SW_WAIT12(1);
 #endif
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 16) = blend_chunk<T>(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 16) = blend(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur);
 #endif
         SW_GATHER4(1, nxt);
         SW_WAIT12(2);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 32) = blend_chunk<T>(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 32) = blend(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur);
 #endif
         SW_GATHER4(2, nxt);
         SW_WAIT12(3);
 #if !(SW_ABL & 1)
-        *reinterpret_cast<uint4*>(dst + 48) = blend_chunk<T>(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur.w);
+        *reinterpret_cast<uint4*>(dst + 48) = blend(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur);
 #endif
         SW_GATHER4(3, nxt);
         cur = nxt;
@@ -508,11 +560,16 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   RGBM_REQUIRE((d.tile_list == nullptr) == (d.tile_count == nullptr), "conv0 sweep: tile list and count go together");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short>), SW_LDS)) return rc;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t>), SW_LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 0>), SW_LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 1>), SW_LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 2>), SW_LDS)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t, 0>), SW_LDS)) return rc;
   prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
-  if (dtype == BF16) hipLaunchKernelGGL(conv0_sweep_kernel<unsigned short>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
-  else hipLaunchKernelGGL(conv0_sweep_kernel<f16_t>, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  // bf16 blend mode (see blend_chunk): debug flag 4194304 = packed fp32 (rounds 1-3), 2097152 = scalar fp32, default = perm + dot2
+  if (dtype == BF16 && (g_debug_flags & (1 << 22))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  else if (dtype == BF16 && (g_debug_flags & (1 << 21))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 1>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  else if (dtype == BF16) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 2>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  else hipLaunchKernelGGL((conv0_sweep_kernel<f16_t, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

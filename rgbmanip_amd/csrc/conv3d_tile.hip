@@ -93,6 +93,8 @@ __device__ __forceinline__ void warp_ixy(const float* __restrict__ hm, float x, 
 }
 
 int g_debug_flags = 0;
+long long g_ws_min_rows = 0;              // GEMM rows from which the persistent role-specialised implicit-GEMM kernels are used; 0 = per storage type (conv_igemm_glds.hip: ws_min_rows), set by rgbm_set_tuning
+int g_tuning_version = 0;                 // bumped by rgbm_debug_flags / rgbm_set_tuning: captured forward graphs of older settings are dropped
 
 template <int N> struct IC { static constexpr int value = N; };
 // compile-time loop: f(IC<0>{}), ..., f(IC<N-1>{}) — register arrays indexed by the loop variable stay registers

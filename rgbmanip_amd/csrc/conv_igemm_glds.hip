@@ -22,6 +22,7 @@
 namespace rgbm {
 
 extern int g_debug_flags;
+extern long long g_ws_min_rows;
 __device__ uint4 g_zero_page[4];     // zero-initialised device memory: the source of every padded chunk
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -2237,6 +2238,12 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
   return 0;
 }
 
+// GEMM rows (output pixels) from which the persistent role-specialised kernels replace the generic tiles.  Rounds 1-3 used 65 536
+// (one 256-pixel tile per CU); measured at small batches in round 4 (forward + post-processing latency, same box): bf16 B = 8
+// (12 544 rows in layer3) 3.11 -> 2.74 ms with the threshold at 8192, B = 1 (1568 rows) 2.08 -> 1.85 ms at 1024; split pairs
+// B = 8 5.40 -> 5.28 ms, B = 1 3.49 -> 3.57 ms (worse) — so 16-bit storage switches from 1024 rows, 4-byte storage from 8192.
+static long long ws_min_rows(size_t elem_bytes) { return g_ws_min_rows > 0 ? g_ws_min_rows : (elem_bytes == 2 ? 1024 : 8192); }
+
 // every K tile inside one tap (see the UNI comment at the 2-stage kernel)
 static bool conv_uniform_taps(const ConvDesc& d, int bk) {
   if (d.KD > 8 || d.KH > 8 || d.KW > 8) return false;
@@ -2291,7 +2298,7 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);
   }
   // >= 128 output channels and enough pixel tiles to fill the chip: the 256x128 three-stage kernel
-  if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= 256 * 256) {
+  if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= ws_min_rows(sizeof(T))) {
     // role-specialised (uniform taps, 16-byte aligned output / residual rows)
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
 #ifdef RGBM_EXPERIMENTS
@@ -2324,7 +2331,7 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   RGBM_REQUIRE(d.w2 == nullptr, "a fused 1x1 needs the ws64 kernel (check conv_ws64_eligible first)");
   // 33..64 output channels where there is no ws64 kernel (split pairs, fp32) or it does not apply (residual adds): the
   // role-specialised kernel with a 64 x 256 tile and four multiply waves
-  if (conv_ch_tile(d.Cout) == 64 && uni && d.M >= 256 * 256 && d.M < (1ll << 31) && !(g_debug_flags & (8 | 64 | 262144))) {
+  if (conv_ch_tile(d.Cout) == 64 && uni && d.M >= ws_min_rows(sizeof(T)) && d.M < (1ll << 31) && !(g_debug_flags & (8 | 64 | 262144))) {
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
     if ((al & 15ull) == 0ull) return launch_ws<T, false, false, true>(d, s);
   }
@@ -2334,7 +2341,7 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
 bool conv_ws64_eligible(const ConvDesc& d, int dtype) {
   if ((dtype != BF16 && dtype != F16) || (g_debug_flags & (4 | 16 | 128))) return false;
   if (!conv_uniform_taps(d, 64) || conv_ch_tile(d.Cout) != 64 || d.res_mode != RES_NONE || d.KT < 2) return false;
-  if (d.M < 256 * 256 || d.M >= (1ll << 31)) return false;
+  if (d.M < ws_min_rows(2) || d.M >= (1ll << 31)) return false;
   if (d.w2) return d.Cout == 64 && d.kpad2 == 64 && (d.cout2 == 16 || d.cout2 == 32) && d.ldo2 % 4 == 0;
   return (((unsigned long long)d.out | ((unsigned long long)d.ldo * 2ull)) & 15ull) == 0ull;
 }

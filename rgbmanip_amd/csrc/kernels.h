@@ -71,6 +71,8 @@ struct Conv3dTileDesc {
                                     // output tile is never read: sparse decoder, see launch_decoder_tile_masks); all depth tiles share a byte
 };
 extern int g_debug_flags;
+extern long long g_ws_min_rows;
+extern int g_tuning_version;
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed);
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);
@@ -100,7 +102,7 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
 // prepare.hip — batched device-side AdaPoseEstimator_v5.prepare_model_input
 int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
-                          unsigned char* small_scratch, hipStream_t s);
+                          unsigned char* small_scratch, hipStream_t s, int frame0 = 0);
 
 int launch_umeyama_ransac(const float* nocs, const float* depth, const int* choose, const double* Kc, const double* E1,
                           double* bbox, double* srt, int* valid, int B, int P, int img, unsigned seed, hipStream_t s);
@@ -114,7 +116,10 @@ int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext,
 
 // postproc.hip
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
-                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s);
+                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s,
+                       void* scratch = nullptr, size_t scratch_bytes = 0);
+size_t postprocess_scratch_bytes(int B);      // device scratch of the split (small-batch) form, per call
+int postprocess_slices(int B);                // workgroups per pose the split form would use (1 = one-kernel form)
 
 // ppo_kernels.hip
 int launch_gae(int T, int N, const float* rewards, const unsigned char* dones, const float* values, const float* last_values,

@@ -56,10 +56,24 @@ __device__ double block_sum(double v, double* red) {
   return r;
 }
 
+// Split form for small batches (one workgroup per pose leaves 255 CUs idle for 1.1 ms at B = 1: 37 % of a B = 1 forward, 28 % at
+// B = 8).  The three passes over the 523 776 pairs that the selection normally needs — the two 12-bit histograms and the collection
+// of the selected bucket's keys — are cut into G slices per pose, one workgroup each (pp_split_kernel, STAGE 0 / 1 / 2; the slices
+// of a pose add their histograms / keys into global scratch), and the finishing kernel (postprocess_kernel<true>, one workgroup per
+// pose) picks the state up from there: same integer histograms, same bucket, same key set, hence the same median bit for bit.  If a
+// bucket holds more than PP_CAND keys the finishing kernel simply continues with the remaining radix passes on its own.
+struct PPScratch {                    // per pose, in caller-provided device memory (zeroed in front of every call)
+  unsigned hist0[4096], hist1[4096];
+  unsigned long long cand[PP_CAND];
+  unsigned ncand, pad[3];
+};
+
+template <bool PRE>
 __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
     const float* __restrict__ nocs /*[B,P,3]*/, const float* __restrict__ depth /*[B,P]*/, const float* __restrict__ rot /*[B,9]*/,
     const int* __restrict__ choose /*[B,P]*/, const double* __restrict__ Kc /*[B,9]*/, const double* __restrict__ E1 /*[B,16]*/,
-    double* __restrict__ bbox /*[B,8,3]*/, double* __restrict__ ts_out /*[B,4]: t(3), s*/, int* __restrict__ valid, int P, int img) {
+    double* __restrict__ bbox /*[B,8,3]*/, double* __restrict__ ts_out /*[B,4]: t(3), s*/, int* __restrict__ valid, int P, int img,
+    const PPScratch* __restrict__ pre) {
   __shared__ double cx[PP_MAXP], cy[PP_MAXP], cz[PP_MAXP];
   __shared__ float nx[PP_MAXP], ny[PP_MAXP], nz[PP_MAXP];
   __shared__ double red[PP_THREADS];
@@ -106,18 +120,23 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
   unsigned lt_total = 0;                // number of elements strictly below the selected bucket (overall)
   bool used_cand = false;
   for (int pass = 0; pass < 6; ++pass) {
-    for (int i = t; i < 4096; i += PP_THREADS) hist[i] = 0u;
-    __syncthreads();
     const int sh = shifts[pass], wd = widths[pass];
-    if (worker) {
-      for (int q = q_lo; q < q_hi; ++q) {
-        int i, j;
-        pair_ij(P, r, q, i, j);
-        double ratio;
-        if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
-        const unsigned long long key = (unsigned long long)__double_as_longlong(ratio);
-        if (pass > 0 && (key >> (sh + wd)) != prefix) continue;
-        atomicAdd(&hist[(unsigned)((key >> sh) & ((1u << wd) - 1u))], 1u);
+    if (PRE && pass < 2) {                 // the slices of pp_split_kernel have already counted this digit
+      const unsigned* gh = pass == 0 ? pre[b].hist0 : pre[b].hist1;
+      for (int i = t; i < 4096; i += PP_THREADS) hist[i] = gh[i];
+    } else {
+      for (int i = t; i < 4096; i += PP_THREADS) hist[i] = 0u;
+      __syncthreads();
+      if (worker) {
+        for (int q = q_lo; q < q_hi; ++q) {
+          int i, j;
+          pair_ij(P, r, q, i, j);
+          double ratio;
+          if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
+          const unsigned long long key = (unsigned long long)__double_as_longlong(ratio);
+          if (pass > 0 && (key >> (sh + wd)) != prefix) continue;
+          atomicAdd(&hist[(unsigned)((key >> sh) & ((1u << wd) - 1u))], 1u);
+        }
       }
     }
     __syncthreads();
@@ -171,9 +190,11 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
     // Short cut: after two passes the bucket is 2^-12 wide in relative terms and holds a few hundred of the 523 776 ratios.
     // Collect its keys once and finish the selection on that list instead of four more passes over all pairs.
     if (pass == 1 && sel_eq <= (unsigned)PP_CAND) {
-      if (t == 0) { ncand = 0u; cand_lt = 0u; cand_below = 0ull; }
+      if (t == 0) { ncand = PRE ? sel_eq : 0u; cand_lt = 0u; cand_below = 0ull; }
       __syncthreads();
-      if (worker) {
+      if (PRE) {                                   // the bucket's keys, collected by the slices (in any order: only values matter below)
+        for (unsigned c = t; c < sel_eq; c += PP_THREADS) cand[c] = pre[b].cand[c];
+      } else if (worker) {
         for (int q = q_lo; q < q_hi; ++q) {
           int i, j;
           pair_ij(P, r, q, i, j);
@@ -271,11 +292,142 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
   }
 }
 
+// One slice (blockIdx.x = pose * G + slice) of the pair passes of the split form: STAGE 0 counts the first digit, STAGE 1 re-derives
+// the selected first digit from the pose's summed histogram and counts the second, STAGE 2 re-derives both and collects the keys of the
+// selected 24-bit bucket (only if they fit PP_CAND, the finishing kernel's own condition).  Bucket selection is the finishing
+// kernel's arithmetic on the same counts, done here by thread 0 (a 4096-bin walk: ~10 us, once or twice per workgroup).
+template <int STAGE>
+__global__ __launch_bounds__(PP_THREADS) void pp_split_kernel(const float* __restrict__ nocs, const float* __restrict__ depth,
+                                                              const int* __restrict__ choose, const double* __restrict__ Kc,
+                                                              PPScratch* __restrict__ scr, int P, int img, int G) {
+  __shared__ double cx[PP_MAXP], cy[PP_MAXP], cz[PP_MAXP];
+  __shared__ float nx[PP_MAXP], ny[PP_MAXP], nz[PP_MAXP];
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_rank, s_eq, s_total;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, t = threadIdx.x;
+  const double fx = Kc[b * 9 + 0], fy = Kc[b * 9 + 4], pcx = Kc[b * 9 + 2], pcy = Kc[b * 9 + 5];
+  if (t < P) {
+    const int ch = choose[(long long)b * P + t];
+    const double u = (double)(ch % img), v = (double)(ch / img);
+    const double z = (double)depth[(long long)b * P + t];
+    cx[t] = ((u - pcx) * z) / fx;
+    cy[t] = ((v - pcy) * z) / fy;
+    cz[t] = z;
+    nx[t] = nocs[((long long)b * P + t) * 3 + 0];
+    ny[t] = nocs[((long long)b * P + t) * 3 + 1];
+    nz[t] = nocs[((long long)b * P + t) * 3 + 2];
+  }
+  PPScratch& S = scr[b];
+  __shared__ unsigned wsum[PP_THREADS / 64];
+  __shared__ unsigned f_digit, f_below, f_eq, f_total;
+  // block-wide: the first bin of `hist` whose cumulative count exceeds rank rk (rk = total / 2 when half is set) — the rule of
+  // postprocess_kernel's selection, 4 bins per thread + a scan over the threads' sums
+  auto find_digit = [&](bool half, unsigned rk_in) {
+    unsigned c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = hist[4 * t + k];
+    const unsigned tsum = c[0] + c[1] + c[2] + c[3];
+    unsigned incl = tsum;
+    const int ln = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off);
+      if (ln >= off) incl += o;
+    }
+    if (ln == 63) wsum[wv] = incl;
+    if (t == 0) { f_digit = 4095u; f_below = 0u; f_eq = 0u; }
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+    for (int k = 0; k < PP_THREADS / 64; ++k) { const unsigned w = wsum[k]; if (k < wv) wbase += w; total += w; }
+    const unsigned excl = wbase + incl - tsum;
+    const unsigned rk = half ? total / 2 : rk_in;
+    if (t == 0) f_total = total;
+    if (rk >= excl && rk < excl + tsum) {
+      unsigned acc = excl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (acc + c[k] > rk) { f_digit = (unsigned)(4 * t + k); f_below = acc; f_eq = c[k]; break; }
+        acc += c[k];
+      }
+    }
+    __syncthreads();
+  };
+  if (STAGE >= 1) {
+    for (int i = t; i < 4096; i += PP_THREADS) hist[i] = S.hist0[i];
+    __syncthreads();
+    find_digit(true, 0u);
+    unsigned long long pf = (unsigned long long)f_digit;
+    const unsigned total = f_total;
+    unsigned rk = total / 2 - f_below, eq = f_eq;
+    __syncthreads();
+    if (STAGE >= 2 && total > 0) {
+      for (int i = t; i < 4096; i += PP_THREADS) hist[i] = S.hist1[i];
+      __syncthreads();
+      find_digit(false, rk);
+      pf = (pf << 12) | (unsigned long long)f_digit;
+      eq = f_eq;
+      __syncthreads();
+    }
+    if (t == 0) { s_prefix = pf; s_rank = rk; s_eq = eq; s_total = total; }
+    __syncthreads();
+  }
+  for (int i = t; i < 4096; i += PP_THREADS) hist[i] = 0u;
+  __syncthreads();
+  if (STAGE >= 1 && s_total == 0) return;
+  if (STAGE == 2 && s_eq > (unsigned)PP_CAND) return;        // the finishing kernel will run the remaining radix passes itself
+  const unsigned long long prefix = STAGE >= 1 ? s_prefix : 0ull;
+  // the pairs of this slice: row pair r, a 1 / (parts * G) share of its P - 1 partners (postprocess_kernel's map, cut G times finer)
+  const int npair_rows = P / 2, per_row = P - 1;
+  const int parts = (PP_THREADS / npair_rows) * G;
+  const int r = t % npair_rows, part = (t / npair_rows) * G + g;
+  if (t / npair_rows < PP_THREADS / npair_rows) {
+    const int q_lo = (int)(((long long)per_row * part) / parts), q_hi = (int)(((long long)per_row * (part + 1)) / parts);
+    for (int q = q_lo; q < q_hi; ++q) {
+      int i, j;
+      pair_ij(P, r, q, i, j);
+      double ratio;
+      if (!pair_ratio(cx, cy, cz, nx, ny, nz, i, j, ratio)) continue;
+      const unsigned long long key = (unsigned long long)__double_as_longlong(ratio);
+      if (STAGE == 0) atomicAdd(&hist[(unsigned)(key >> 52) & 4095u], 1u);
+      else if (STAGE == 1) { if ((key >> 52) == prefix) atomicAdd(&hist[(unsigned)(key >> 40) & 4095u], 1u); }
+      else if ((key >> 40) == prefix) S.cand[atomicAdd(&S.ncand, 1u)] = key;
+    }
+  }
+  if (STAGE < 2) {
+    __syncthreads();
+    unsigned* gh = STAGE == 0 ? S.hist0 : S.hist1;
+    for (int i = t; i < 4096; i += PP_THREADS) { const unsigned c = hist[i]; if (c) atomicAdd(&gh[i], c); }
+  }
+}
+
+size_t postprocess_scratch_bytes(int B) { return (size_t)B * sizeof(PPScratch); }
+
+// slices per pose of the split form: fill the chip (256 CUs) without exceeding 32 slices; 1 = the one-kernel form
+int postprocess_slices(int B) {
+  int g = 1;
+  while (g < 32 && (long long)B * g * 2 <= 256) g *= 2;
+  return g;
+}
+
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
-                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s) {
+                       const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s,
+                       void* scratch, size_t scratch_bytes) {
   RGBM_REQUIRE(P >= 2 && P <= PP_MAXP && (P % 2) == 0 && (PP_THREADS % (P / 2)) == 0, "postprocess needs even P<=1024 dividing 2048");
-  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(PP_THREADS), 0, s, nocs, depth, rot, choose, Kc, E1, bbox, ts_out,
-                     valid, P, img);
+  const int G = scratch ? postprocess_slices(B) : 1;
+  if (G > 1 && !(g_debug_flags & (1 << 23))) {        // debug flag 8388608: one-kernel form even when scratch is given (A/B)
+    RGBM_REQUIRE(scratch_bytes >= postprocess_scratch_bytes(B) && ((uintptr_t)scratch & 7) == 0, "postprocess scratch too small or misaligned");
+    PPScratch* scr = reinterpret_cast<PPScratch*>(scratch);
+    RGBM_CHECK_HIP(hipMemsetAsync(scr, 0, postprocess_scratch_bytes(B), s));
+    hipLaunchKernelGGL(pp_split_kernel<0>, dim3(B * G), dim3(PP_THREADS), 0, s, nocs, depth, choose, Kc, scr, P, img, G);
+    hipLaunchKernelGGL(pp_split_kernel<1>, dim3(B * G), dim3(PP_THREADS), 0, s, nocs, depth, choose, Kc, scr, P, img, G);
+    hipLaunchKernelGGL(pp_split_kernel<2>, dim3(B * G), dim3(PP_THREADS), 0, s, nocs, depth, choose, Kc, scr, P, img, G);
+    hipLaunchKernelGGL(postprocess_kernel<true>, dim3(B), dim3(PP_THREADS), 0, s, nocs, depth, rot, choose, Kc, E1, bbox, ts_out,
+                       valid, P, img, (const PPScratch*)scr);
+  } else {
+    hipLaunchKernelGGL(postprocess_kernel<false>, dim3(B), dim3(PP_THREADS), 0, s, nocs, depth, rot, choose, Kc, E1, bbox, ts_out,
+                       valid, P, img, (const PPScratch*)nullptr);
+  }
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -121,7 +121,8 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb /*[N,H,W,3]*/, 
 // ---- 3. choose: nonzero indices of the resized mask, ordered random P-subset or wrap padding -------------------------
 __global__ __launch_bounds__(PRE_THREADS) void choose_kernel(const unsigned char* __restrict__ small, const int* __restrict__ window,
                                                               int S, int P, unsigned seed, int* __restrict__ choose /*[N,P]*/,
-                                                              float* __restrict__ pts2d /*[N,P,2] or null*/, int* __restrict__ valid) {
+                                                              float* __restrict__ pts2d /*[N,P,2] or null*/, int* __restrict__ valid,
+                                                              int frame0 /*hash index of frame 0: a batch prepared in pieces*/) {
   extern __shared__ unsigned short idx[];           // candidate pixel indices, in order (S*S <= 65536)
   __shared__ int wsum[PRE_THREADS / 64];
   __shared__ int s_total, s_cnt;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(PRE_THREADS) void choose_kernel(const unsigned char
     while (tlo < thi) {
       const unsigned mid = tlo + ((thi - tlo) >> 1);
       int c = 0;
-      for (int i = t; i < n; i += PRE_THREADS) c += mix32(seed, (unsigned)f, (unsigned)idx[i]) <= mid ? 1 : 0;
+      for (int i = t; i < n; i += PRE_THREADS) c += mix32(seed, (unsigned)(f + frame0), (unsigned)idx[i]) <= mid ? 1 : 0;
       if (t == 0) s_cnt = 0;
       __syncthreads();
       atomicAdd(&s_cnt, c);
@@ -179,14 +180,14 @@ __global__ __launch_bounds__(PRE_THREADS) void choose_kernel(const unsigned char
     const int per2 = (n + PRE_THREADS - 1) / PRE_THREADS;
     const int a = min(t * per2, n), b = min(a + per2, n);
     int c_lt = 0, c_eq = 0;
-    for (int i = a; i < b; ++i) { const unsigned k = mix32(seed, (unsigned)f, (unsigned)idx[i]); c_lt += k < T; c_eq += k == T; }
+    for (int i = a; i < b; ++i) { const unsigned k = mix32(seed, (unsigned)(f + frame0), (unsigned)idx[i]); c_lt += k < T; c_eq += k == T; }
     int n_lt, n_eq;
     int p_lt = excl_scan(c_lt, n_lt);
     int p_eq = excl_scan(c_eq, n_eq);
     const int eq_keep = P - n_lt;                   // ties kept (>= 1)
     // output position of element i = (#kept with smaller index): kept_lt before + min(eq before, eq_keep)
     for (int i = a; i < b; ++i) {
-      const unsigned k = mix32(seed, (unsigned)f, (unsigned)idx[i]);
+      const unsigned k = mix32(seed, (unsigned)(f + frame0), (unsigned)idx[i]);
       if (k < T) { out[p_lt + min(p_eq, eq_keep)] = idx[i]; ++p_lt; }
       else if (k == T) { if (p_eq < eq_keep) out[p_lt + p_eq] = idx[i]; ++p_eq; }
     }
@@ -258,7 +259,7 @@ unsigned prepare_mix32(unsigned seed, unsigned frame, unsigned idx) { return mix
 
 int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,
                           unsigned seed, float* img, int* choose, float* pts2d, double* Kcrop, int* window, int* valid,
-                          unsigned char* small_scratch, hipStream_t s) {
+                          unsigned char* small_scratch, hipStream_t s, int frame0) {
   RGBM_REQUIRE(rgb && mask && K && img && choose && Kcrop && window && valid && small_scratch, "prepare_inputs arguments");
   // the crop window is a square of up to 440 pixels shifted back into the frame (lib/utils.py:10-38 does it for 480 x 640): a
   // smaller frame could not hold it and the shifted window would start at a negative row / column
@@ -268,7 +269,7 @@ int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const dou
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rgb, mask, frame_map, window, N, H, W, S, img, small_scratch);
   const size_t lds = (size_t)S * S * sizeof(unsigned short);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(choose_kernel), 150 * 1024)) return rc;
-  hipLaunchKernelGGL(choose_kernel, dim3(N), dim3(PRE_THREADS), lds, s, small_scratch, window, S, P, seed, choose, pts2d, valid);
+  hipLaunchKernelGGL(choose_kernel, dim3(N), dim3(PRE_THREADS), lds, s, small_scratch, window, S, P, seed, choose, pts2d, valid, frame0);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

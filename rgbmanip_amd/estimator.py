@@ -14,6 +14,7 @@ is then a seeded hash, cfg["hip_prepare_seed"]); `estimate_device` takes device-
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -99,6 +100,29 @@ def _mix32(seed, frame, idx):
     return h.astype(np.uint32)
 
 
+_HOST_THREADS = max(1, min(32, (os.cpu_count() or 1)))
+_POOL = None
+
+
+def _host_pool():
+    """Thread pool of the host-side frame conversion (created on first use)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_HOST_THREADS, thread_name_prefix="rgbm-upload")
+    return _POOL
+
+
+def _nonzero_into(dst_u8, src):
+    np.not_equal(src, 0, out=dst_u8.view(np.bool_))
+
+
+def _split(n, parts):
+    """[lo, hi) ranges cutting n rows into at most `parts` nearly equal pieces"""
+    parts = max(1, min(parts, n))
+    return [(n * i // parts, n * (i + 1) // parts) for i in range(parts)]
+
+
 class AdaPoseEstimator_v5(BasePoseEstimator):
     def __init__(self, env, cfg, logger, state_dict=None, dtype=None, device=0, net=None):
         """`net`: an already built `AdaPoseNet` to share (weights + workspace) instead of building one from `state_dict`."""
@@ -114,10 +138,11 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 if logger is not None:
                     logger.warning("AdaPoseEstimator_v5: cfg.load is False -> synthetic (seeded) weights")
         self.dtype = dtype or cfg.get("hip_dtype", "bf16x3")      # the fastest mode inside north_star's 1e-4 (fp32: 4x slower, bf16: 2.4x faster at 1e-2)
-        # hip_graph: batches of at most hip_graph_max_batch poses replay a captured hipGraph (the per-env / num_envs: 8 deployment path)
+        # hip_graph (default off: measured, small batches are bound by their kernels, not by the ~100 launches): batches of at most
+        # hip_graph_max_batch poses replay a captured hipGraph
         self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device,
                                                                 norm_mode=cfg.get("hip_norm_mode", "eval"),
-                                                                graph=bool(cfg.get("hip_graph", True)),
+                                                                graph=bool(cfg.get("hip_graph", False)),
                                                                 graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)))
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
@@ -167,11 +192,8 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         S = self.cfg["img_size"]
         n = len(rgb1_batch)
         if self.prepare_mode == "device":
-            # host frames -> device through pinned, double-buffered chunks (conversion to float32 on all host cores, copy overlapped);
-            # the controller hands [N,480,640,3] float64 arrays over (rl_pose.py:210-218): 3.8 GB per call at N = 256
-            return self.estimate_device(np.asarray(camera_intrinsic_batch), self._upload_frames(rgb1_batch), self._upload_masks(view1_mask_batch),
-                                        np.asarray(view1_extrinsic_batch), self._upload_frames(rgb2_batch),
-                                        self._upload_masks(view2_mask_batch), np.asarray(view2_extrinsic_batch)).cpu().numpy()
+            return self._estimate_host_frames(camera_intrinsic_batch, rgb1_batch, view1_mask_batch, view1_extrinsic_batch, rgb2_batch,
+                                              view2_mask_batch, view2_extrinsic_batch)
         out = np.repeat(DEFAULT_BBOX[None], n, axis=0)
         rows, img1, img2, ch1, ch2, P1, P2, K1, E1 = [], [], [], [], [], [], [], [], []
         pt1, pt2, E2, K0 = [], [], [], []                    # the PnP branch also needs the pixels, the second extrinsic and the original K
@@ -208,38 +230,118 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
     # ------------------------------------------------------------------ host frames -> HBM
     _CHUNK_BYTES = 64 << 20
 
+    def _estimate_host_frames(self, K, rgb1, mask1, E1, rgb2, mask2, E2):
+        """`estimate` with `hip_prepare: device` for host arrays (what rl_pose.py:210-218 hands over: [N,480,640,3] float64 frames,
+        3.8 GB per call at N = 256).  Batches larger than `hip_upload_chunk` poses (default 64) run as a three-stage pipeline over
+        chunks of poses: host threads copy chunk c + 1 into pinned staging buffers while the copy engine moves chunk c to the device
+        on its own stream and the kernels (dtype conversion, crop / resize / subset, network, post-processing) work on chunk c - 1.
+        Every pose's box equals the unchunked call's (poses are independent; a chunk is a smaller batch of the same kernels)."""
+        n = len(rgb1)
+        chunk = int(self.cfg.get("hip_upload_chunk", 64))
+        on_dev = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (rgb1, rgb2))
+        if on_dev or n <= chunk or chunk <= 0:
+            return self.estimate_device(np.asarray(K), self._upload_frames(rgb1), self._upload_masks(mask1), np.asarray(E1),
+                                        self._upload_frames(rgb2), self._upload_masks(mask2), np.asarray(E2)).cpu().numpy()
+        dev = self.estimator.device
+        srcs = [x.numpy() if isinstance(x, torch.Tensor) else np.ascontiguousarray(np.asarray(x)) for x in (rgb1, rgb2, mask1, mask2)]
+        for a in srcs[:2]:
+            if a.dtype != np.uint8 and a.dtype.kind != "f":
+                raise TypeError(f"estimate: rgb frames must be float images in [0, 1] or uint8, got {a.dtype}")
+        Kd = torch.as_tensor(np.asarray(K)).to(dev)
+        E1d, E2d = torch.as_tensor(np.asarray(E1)).to(dev), torch.as_tensor(np.asarray(E2)).to(dev)
+        tdt = [torch.from_numpy(a[:0]).dtype for a in srcs[:2]] + [torch.uint8, torch.uint8]
+        shp = [tuple(a.shape[1:]) for a in srcs]
+        key = ("pipe", chunk, tuple(shp), tuple(tdt))
+        if getattr(self, "_pipe_key", None) != key:
+            self._pipe_pin = [[torch.empty((chunk,) + shp[i], dtype=tdt[i], pin_memory=True) for i in range(4)] for _ in range(2)]
+            self._pipe_np = [[t.numpy() for t in slot] for slot in self._pipe_pin]
+            self._pipe_dev = [[torch.empty((chunk,) + shp[i], dtype=tdt[i], device=dev) for i in range(4)] for _ in range(2)]
+            self._pipe_h2d = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pipe_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pipe_stream = torch.cuda.Stream(device=dev)
+            self._pipe_key = key
+        pool = _host_pool()
+        cur = torch.cuda.current_stream(dev)
+        out = torch.empty(n, 8, 3, dtype=torch.float64, device=dev)
+        used = [False, False]
+
+        def stage(slot, a, b):
+            tasks = []
+            for i in range(4):
+                dst, src = self._pipe_np[slot][i], srcs[i]
+                for lo, hi in _split(b - a, max(1, _HOST_THREADS // 2)):
+                    if i < 2 or src.dtype == np.uint8:
+                        tasks.append((np.copyto, dst[lo:hi], src[a + lo:a + hi]))
+                    elif src.dtype == np.bool_:
+                        tasks.append((np.copyto, dst[lo:hi], src[a + lo:a + hi].view(np.uint8)))
+                    else:                                  # any number type: non-zero = object, one byte per pixel crosses PCIe
+                        tasks.append((_nonzero_into, dst[lo:hi], src[a + lo:a + hi]))
+            list(pool.map(lambda t: t[0](t[1], t[2]), tasks))
+
+        for c, a in enumerate(range(0, n, chunk)):
+            b = min(a + chunk, n)
+            slot = c & 1
+            if used[slot]:
+                self._pipe_h2d[slot].synchronize()         # the copy that last read this slot's pinned buffers has finished
+            stage(slot, a, b)                              # host threads; overlaps the device's work on the previous chunks
+            with torch.cuda.stream(self._pipe_stream):
+                if used[slot]:
+                    self._pipe_stream.wait_event(self._pipe_done[slot])      # the kernels that read this slot's device buffers are done
+                for i in range(4):
+                    self._pipe_dev[slot][i][: b - a].copy_(self._pipe_pin[slot][i][: b - a], non_blocking=True)
+                self._pipe_h2d[slot].record(self._pipe_stream)
+            cur.wait_event(self._pipe_h2d[slot])
+            d = [t[: b - a] for t in self._pipe_dev[slot]]
+            out[a:b] = self.estimate_device(Kd[a:b], self._upload_frames(d[0]), d[2], E1d[a:b], self._upload_frames(d[1]), d[3], E2d[a:b], frame0=a)
+            self._pipe_done[slot].record(cur)
+            used[slot] = True
+        return out.cpu().numpy()
+
     def _upload_frames(self, frames):
         """[N,H,W,3] host frames (float64 / float32 in [0,1], or uint8) -> CUDA float32 [N,H,W,3] in [0,1].  Frames that already are
-        CUDA tensors pass through.  The conversion to float32 runs multi-threaded (torch CPU copy) straight into one of two pinned
-        staging buffers while the previous chunk's copy is in flight; uint8 frames travel as bytes and are scaled on the device."""
+        CUDA tensors pass through.  The frames cross PCIe in their own dtype and are converted on the device: a pool of host threads
+        copies each chunk into one of two pinned staging buffers (plain memcpy, ~10 GB/s per thread; a dtype-converting numpy copy
+        runs at 0.6-1 GB/s per thread, and 3.8 GB of float64 frames arrive per call at N = 256) while the previous chunk's copy is in
+        flight; the device-side conversion of a chunk is a stream-ordered elementwise kernel."""
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
-            return frames.to(torch.float32) if frames.dtype != torch.uint8 else frames.to(torch.float32) / 255.0
-        src = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(frames)))
+            return frames.to(torch.float32) if frames.dtype != torch.uint8 else (frames.to(torch.float64) / 255.0).to(torch.float32)      # (device-side dtype conversion of an uploaded chunk)
+        src = frames.numpy() if isinstance(frames, torch.Tensor) else np.ascontiguousarray(np.asarray(frames))
         dev = self.estimator.device
-        as_bytes = src.dtype == torch.uint8
-        if not as_bytes and not src.dtype.is_floating_point:
+        if src.dtype != np.uint8 and src.dtype.kind != "f":
             raise TypeError(f"estimate: rgb frames must be float images in [0, 1] or uint8, got {src.dtype}")
-        stage_dt = torch.uint8 if as_bytes else torch.float32
+        tdt = torch.from_numpy(src[:0]).dtype
         n = src.shape[0]
-        per = max(1, int(np.prod(src.shape[1:])))
-        rows = max(1, min(n, self._CHUNK_BYTES // (per * (1 if as_bytes else 4))))
-        key = (rows, tuple(src.shape[1:]), stage_dt)
+        per = max(1, int(np.prod(src.shape[1:]))) * src.dtype.itemsize
+        rows = max(1, min(n, self._CHUNK_BYTES // per))
+        key = (rows, tuple(src.shape[1:]), tdt)
         if getattr(self, "_stage_key", None) != key:
-            self._stage = [torch.empty((rows,) + tuple(src.shape[1:]), dtype=stage_dt, pin_memory=True) for _ in range(2)]
+            self._stage = [torch.empty((rows,) + tuple(src.shape[1:]), dtype=tdt, pin_memory=True) for _ in range(2)]
+            self._stage_np = [t.numpy() for t in self._stage]
+            self._stage_dev = [torch.empty((rows,) + tuple(src.shape[1:]), dtype=tdt, device=dev) for _ in range(2)]
             self._stage_ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._stage_key = key
             self._stage_used = [False, False]
-        out = torch.empty(tuple(src.shape), dtype=stage_dt, device=dev)
+        out = torch.empty(tuple(src.shape), dtype=torch.float32, device=dev)
+        pool = _host_pool()
         for i, a in enumerate(range(0, n, rows)):
             b = min(a + rows, n)
             k = i & 1
             if self._stage_used[k]:
                 self._stage_ev[k].synchronize()                    # the copy that last read this staging buffer has finished
-            self._stage[k][: b - a].copy_(src[a:b])                # dtype conversion + gather into pinned memory, on the host cores
-            out[a:b].copy_(self._stage[k][: b - a], non_blocking=True)
+            dst = self._stage_np[k]
+            list(pool.map(lambda p: np.copyto(dst[p[0]:p[1]], src[a + p[0]:a + p[1]]), _split(b - a, _HOST_THREADS)))
+            self._stage_dev[k][: b - a].copy_(self._stage[k][: b - a], non_blocking=True)
             self._stage_ev[k].record()
             self._stage_used[k] = True
-        return out.to(torch.float32) / 255.0 if as_bytes else out
+            # stream-ordered: this conversion runs before the copy that next overwrites _stage_dev[k] (two chunks later)
+            if src.dtype == np.uint8:
+                # x / 255 through float64: torch's float32 division on ROCm is not correctly rounded (126 of the 256 byte values
+                # differ from numpy's float32(x) / float32(255) by one ulp, tools/check_div.py); the float64 quotient rounded to
+                # float32 equals the correctly rounded float32 quotient for every byte value
+                out[a:b].copy_(self._stage_dev[k][: b - a].to(torch.float64) / 255.0)
+            else:
+                out[a:b].copy_(self._stage_dev[k][: b - a])
+        return out
 
     def _upload_masks(self, masks):
         """[N,H,W] host masks (bool / uint8 / any number type, non-zero = object) -> CUDA uint8."""
@@ -253,7 +355,7 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         return m.to(self.estimator.device, non_blocking=False)
 
     # ------------------------------------------------------------------ the same pipeline without leaving the device
-    def estimate_device(self, K, rgb1, mask1, E1, rgb2, mask2, E2):
+    def estimate_device(self, K, rgb1, mask1, E1, rgb2, mask2, E2, frame0: int = 0):
         """`estimate` for frames that already live on the GPU (or get uploaded once): K [N,3,3], rgb [N,H,W,3] float32 in [0,1],
         mask [N,H,W], E [N,4,4] world->camera.  Returns a CUDA tensor [N,8,3] float64; samples the reference would skip
         (empty mask) or reject (non-finite box) hold `default_bbox`."""
@@ -261,8 +363,8 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         dev = self.estimator.device
         Kd = torch.as_tensor(K).to(dev)
         wp = self._pnp_branch()
-        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), Kd, S, 1024, self.prepare_seed, want_pts2d=wp)
-        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), Kd, S, 1024, self.prepare_seed + 1, want_pts2d=wp)
+        a = prepare_inputs(torch.as_tensor(rgb1).to(dev), torch.as_tensor(mask1).to(dev), Kd, S, 1024, self.prepare_seed, want_pts2d=wp, frame0=frame0)
+        b = prepare_inputs(torch.as_tensor(rgb2).to(dev), torch.as_tensor(mask2).to(dev), Kd, S, 1024, self.prepare_seed + 1, want_pts2d=wp, frame0=frame0)
         return self._estimate_prepared(a, b, E1, E2, Kd)
 
     def estimate_device_indexed(self, K, rgb_pool, mask_pool, E1, E2, map1, map2):
