@@ -511,7 +511,10 @@ def main():
         from rgbmanip_amd.config import ADAPOSE_CFGS
         from rgbmanip_amd.estimator import AdaPoseEstimator_v5
         ecfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False)
-        est_d = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device"), None, dtype=args.dtype, net=net)
+        # the estimator as the plugin ships it: its own network with the view-2 heads skipped (estimate() builds the box from the view-1
+        # outputs alone, interface_v5.py:318-374)
+        est_d = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device"), None, state_dict=sd0, dtype=args.dtype)
+        est_full = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device"), None, dtype=args.dtype, net=net)      # all ten outputs computed
         Kh, E1h, E2h = frames["K"].cpu().numpy(), frames["E1"].cpu().numpy(), frames["E2"].cpu().numpy()
         # what rl_pose.py:210-218 hands over: [N,480,640,3] float64 frames and [N,480,640] masks, host numpy
         r1, r2 = frames["rgb1"].cpu().numpy().astype(np.float64), frames["rgb2"].cpu().numpy().astype(np.float64)
@@ -523,7 +526,7 @@ def main():
             bb = est_d.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
         e_s = (time.perf_counter() - t1) / 2
         # the same call without the chunk pipeline (upload everything, then compute), and the upload alone
-        est_1 = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device", hip_upload_chunk=0), None, dtype=args.dtype, net=net)
+        est_1 = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="device", hip_upload_chunk=0), None, dtype=args.dtype, net=est_d.estimator)
         est_1.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
         t1 = time.perf_counter()
         bb1 = est_1.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
@@ -536,6 +539,10 @@ def main():
         del ups, est_1
         dev_s = time_steps(lambda: est_d.estimate_device(frames["K"], frames["rgb1"], frames["mask1"], frames["E1"], frames["rgb2"], frames["mask2"],
                                                          frames["E2"]), 1, 3)
+        devf_s = time_steps(lambda: est_full.estimate_device(frames["K"], frames["rgb1"], frames["mask1"], frames["E1"], frames["rgb2"], frames["mask2"],
+                                                             frames["E2"]), 1, 3)
+        bb_full = est_full.estimate_device(frames["K"], frames["rgb1"], frames["mask1"], frames["E1"], frames["rgb2"], frames["mask2"], frames["E2"]).cpu().numpy()
+        bb_v1 = est_d.estimate_device(frames["K"], frames["rgb1"], frames["mask1"], frames["E1"], frames["rgb2"], frames["mask2"], frames["E2"]).cpu().numpy()
         r1f, r2f = r1.astype(np.float32), r2.astype(np.float32)
         m1b, m2b = m1 != 0, m2 != 0
         est_d.estimate(Kh, r1f, m1b, E1h, r2f, m2b, E2h)
@@ -544,7 +551,7 @@ def main():
             est_d.estimate(Kh, r1f, m1b, E1h, r2f, m2b, E2h)
         e32_s = (time.perf_counter() - t1) / 2
         # the reference's own structure (per-frame numpy crop / resize on the host, then one batched forward): bounded sample of 16 poses
-        est_h = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="host"), None, dtype=args.dtype, net=net)
+        est_h = AdaPoseEstimator_v5(None, dict(ecfg, hip_prepare="host"), None, dtype=args.dtype, net=est_d.estimator)
         nh = min(16, B)
         est_h.estimate(Kh[:2], r1[:2], m1[:2], E1h[:2], r2[:2], m2[:2], E2h[:2])
         t1 = time.perf_counter()
@@ -562,13 +569,17 @@ def main():
                                "upload_alone_ms": round(up_s * 1e3, 1), "upload_alone_host_GBps": round(gb / up_s, 1),
                                "upload_share_of_unpipelined_call": round(up_s / e1_s, 3),
                                "device_resident_ms": round(dev_s * 1e3, 1), "device_resident_poses_per_sec": round(B / dev_s, 1),
+                               "device_resident_with_view2_heads_ms": round(devf_s * 1e3, 1),
+                               "view1_only_boxes_bit_identical_to_full_forward": bool(np.array_equal(bb_full, bb_v1)),
+                               "view2_heads": "skipped (hip_view2_heads default: the box tail reads view-1 outputs only; all ten outputs stay the "
+                                              "network API's default and are what `value` times)",
                                "float32_frames_bool_masks": {"poses_per_sec": round(B / e32_s, 1), "ms_per_call": round(e32_s * 1e3, 1)},
                                "note": "hip_prepare: device — frames cross PCIe in their own dtype through pinned double-buffered staging (host "
                                        "thread pool) and are converted on the device; crop / resize / subset / network / post-processing on the GPU"},
             "host_prepare": {"poses_per_sec": round(nh / h_s, 2), "ms_per_pose": round(h_s / nh * 1e3, 1), "sample_poses": nh,
                              "note": "hip_prepare: host — the reference's per-frame numpy crop / resize on one host core, then one batched forward"},
             "finite": bool(np.isfinite(bb).all())}
-        del r1, r2, m1, m2, r1f, r2f, est_d, est_h
+        del r1, r2, m1, m2, r1f, r2f, est_d, est_h, est_full
     frames = None
     torch.cuda.empty_cache()
 
@@ -687,8 +698,9 @@ def main():
             from rgbmanip_amd.control_interface import ControlInterface
             from rgbmanip_amd.estimator import AdaPoseEstimator_v5
             from rgbmanip_amd.synthetic_env import SyntheticManipulation, SyntheticMultiVecEnv
+            # the estimator builds its own network: view-2 heads skipped, as the plugin ships (ControlInterface reads the box only)
             est = AdaPoseEstimator_v5(None, dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="device"), None,
-                                      dtype=args.dtype, net=net)
+                                      state_dict=sd0, dtype=args.dtype, device=local_rank)
             venv = SyntheticMultiVecEnv(args.ppo_envs, device, seed=0, env_id_offset=rank * args.ppo_envs)
             env = ControlInterface(venv, est, SyntheticManipulation(venv), cfg, device=device)
             env_name = ("ControlInterface.step over SyntheticMultiVecEnv: render 480x640 -> view queue -> prepare_model_input -> "
@@ -703,6 +715,7 @@ def main():
         ppo_res = {"env_steps_per_sec": round(ppo.last_fps, 1), "num_envs_per_gpu": args.ppo_envs, "transitions_per_env": 16,
                    "collection_s": round(ppo.last_collection_time, 3), "learn_s": round(ppo.last_learn_time, 4),
                    "optimizer_steps": 32, "env": env_name,
+                   "estimator_view2_heads": (bool(est.view2_heads) if args.ppo_env == "full" else True),
                    "lr_after": ppo.step_size}
         if dist is not None:      # per-rank collection / learn times: a straggler of the PPO loop is visible the day SCALE runs
             allr = torch.zeros(world, 3, dtype=torch.float64, device=device)

@@ -75,6 +75,9 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
  * "sparse_dec" (sparse cost regularisation with the sparse tail: the probability volume is read only at the chosen pixels, so every 3-D
  * layer has a dependency cone per axis; 2 [default] = the plane sweep, conv1..conv5, conv7 and conv9 run only on the tiles inside those
  * cones — c0..c5 / u7 / u9 are undefined elsewhere, every network output is bit-identical; 1 = conv7 / conv9 only; 0 = dense).
+ * "view2_heads" (1 [default] = all ten outputs; 0 = the probability volume, the point heads and the pose regression run for the
+ * view-1 crops only and the five view-2 outputs are filled with NaN: what AdaPoseEstimator_v5.estimate consumes,
+ * interface_v5.py:318-374, at about three quarters of the time; the backbone still runs on both views).
  * Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);

@@ -426,6 +426,7 @@ int AdaPose::pspnet(const Buffers& bf, int V, const float* img1, const float* im
 
 int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, hipStream_t s) const {
   const int S = img, D = n_depth, P = n_pts;
+  const int Vh = view2_heads ? V : B;      // views whose probability volume is computed (partners are looked up among all V)
   const int Vc0 = chunk_views(V);
   const bool b16 = dtype_size(dtype) == 2;      // 16-bit storage: the depth-sweeping conv0, implicit-GEMM conv6 and the sparse tail exist for these
   // halo-tiled path (cost_impl >= 1): one launch per layer; conv0 optionally builds its input on the fly
@@ -469,8 +470,8 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
   // other tiles, the depth-sweeping conv0 walks the list of needed ones.  conv6 stays dense (a 0.3 ms GEMM): what it computes from
   // unwritten input tiles is never read by anything that is read.
   const bool sparse_ok = sparse_active();
-  for (int v0 = 0; norm_mode == 0 && cost_impl >= 1 && v0 < V; v0 += Vc0) {
-    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+  for (int v0 = 0; norm_mode == 0 && cost_impl >= 1 && v0 < Vh; v0 += Vc0) {
+    const int Vc = Vh - v0 < Vc0 ? Vh - v0 : Vc0;
     const unsigned char* mk[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     sweep_sparse = false;
     if (sparse_ok) {
@@ -512,8 +513,8 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 1, s)) return rc;
   }
   // norm_mode 1: every layer = un-normalised conv (generic implicit GEMM) -> per-view batch statistics -> normalise + ReLU (+ skip)
-  for (int v0 = 0; norm_mode == 1 && v0 < V; v0 += Vc0) {
-    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+  for (int v0 = 0; norm_mode == 1 && v0 < Vh; v0 += Vc0) {
+    const int Vc = Vh - v0 < Vc0 ? Vh - v0 : Vc0;
     if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
     auto layer = [&](int i, const void* in, void* out, const void* res, int Di, int Hi, int Wi, int C) -> int {
       const ConvLayer& L = i >= 7 ? dc_raw[i - 7] : c3d_raw[i];
@@ -535,8 +536,8 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (int rc = launch_prob_softmax_depth(dtype, bf.u11, wprob, bf.choose, depths, bf.prob, bf.depth, v0, Vc, B, P, D, S, S, 0, s)) return rc;
   }
   if (norm_mode == 1) return 0;
-  for (int v0 = 0; cost_impl == 0 && v0 < V; v0 += Vc0) {
-    const int Vc = V - v0 < Vc0 ? V - v0 : Vc0;
+  for (int v0 = 0; cost_impl == 0 && v0 < Vh; v0 += Vc0) {
+    const int Vc = Vh - v0 < Vc0 ? Vh - v0 : Vc0;
     if (int rc = launch_build_volume(dtype, bf.feat, bf.homog, depths, bf.vol, v0, Vc, V, B, D, S, S, s)) return rc;
     if (int rc = c3d[0].run(bf.vol, bf.c[0], Vc, D, S, S, 8, nullptr, 0, nullptr, 0, s)) return rc;
     if (int rc = c3d[1].run(bf.c[0], bf.c[1], Vc, D, S, S, 16, nullptr, 0, nullptr, 0, s)) return rc;
@@ -585,59 +586,69 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   }
   if (stop_after == 1) return 0;
 
+  const int Vh = view2_heads ? V : B;      // views that get heads: both crops of every pose, or the view-1 crops only (option view2_heads)
   // ---- per-point NOCS branch (network_v5.py:432-444) ----
-  if (int rc = launch_gather_points(fdt, featg, bf.choose, bf.X0, V, P, S * S, 32, s)) return rc;
-  if (int rc = inst.run(bf.X0, bf.X1, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[0].run(bf.X1, bf.H128, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[1].run(bf.H128, bf.H64, V, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[2].run(bf.H64, bf.nocs4, V, 1, 1, P, 4, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = npm[0].run(bf.nocs4, bf.N32, V, 1, 1, P, 32, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = npm[1].run(bf.N32, bf.PF96 + 32, V, 1, 1, P, 96, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_gather_points(fdt, featg, bf.choose, bf.X0, Vh, P, S * S, 32, s)) return rc;
+  if (int rc = inst.run(bf.X0, bf.X1, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[0].run(bf.X1, bf.H128, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[1].run(bf.H128, bf.H64, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = nh[2].run(bf.H64, bf.nocs4, Vh, 1, 1, P, 4, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = npm[0].run(bf.nocs4, bf.N32, Vh, 1, 1, P, 32, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = npm[1].run(bf.N32, bf.PF96 + 32, Vh, 1, 1, P, 96, nullptr, 0, nullptr, 0, s)) return rc;
 
   // ---- plane-sweep cost volume -> probability at the sampled pixels -> depth ----
   if (int rc = cost_volume(bf, V, B, depths, s)) return rc;
   if (stop_after == 2) return 0;
 
   // ---- depth-guided fusion + pose regression (network_v5.py:457-508) ----
-  if (int rc = launch_fuse_points(fdt, featg, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s)) return rc;
+  if (int rc = launch_fuse_points(fdt, featg, bf.homog, depths, bf.choose, bf.prob, bf.PF96, V, B, P, D, S, S, 96, 0, s, Vh)) return rc;
   // bf16 nets: the four big per-point layers of the pose MLP run in fp16 storage (fp32 they took 1.8 ms per 512 views at
   // 78 TFLOP/s on the fp32 matrix path); PF96 is produced in fp32 by its two writers and converted once
   const int pdt = pose_dtype();
   const void* pf_in = bf.PF96;
   if (pdt == F16) {
-    if (int rc = launch_f32_to_f16(bf.PF96, bf.PF96h, (long long)VP * 96, s)) return rc;
+    if (int rc = launch_f32_to_f16(bf.PF96, bf.PF96h, (long long)Vh * P * 96, s)) return rc;
     pf_in = bf.PF96h;
   } else if (pdt == BF16X3) {
-    if (int rc = launch_f32_to_bx3(bf.PF96, bf.PF96, (long long)VP * 96, s)) return rc;      // in place: same 4-byte slots
+    if (int rc = launch_f32_to_bx3(bf.PF96, bf.PF96, (long long)Vh * P * 96, s)) return rc;      // in place: same 4-byte slots
   }
-  if (int rc = pm1[0].run(pf_in, bf.Q128a, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, V, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, V, P, 128, s)) return rc;
-  if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, V, 128, 256, 256, 128, 0, s)) return rc;
-  if (int rc = pm2[0].run(bf.Q128b, bf.G256a, V, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
-  if (int rc = pm2[1].run(bf.G256a, bf.G256b, V, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, V, P, 256, s)) return rc;
+  if (int rc = pm1[0].run(pf_in, bf.Q128a, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, Vh, P, 128, s)) return rc;
+  if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, Vh, 128, 256, 256, 128, 0, s)) return rc;
+  if (int rc = pm2[0].run(bf.Q128b, bf.G256a, Vh, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
+  if (int rc = pm2[1].run(bf.G256a, bf.G256b, Vh, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, Vh, P, 256, s)) return rc;
   float* hout[3] = {bf.r6, bf.tv, bf.sv};
   const int hdim[3] = {6, 3, 3};
   for (int h = 0; h < 3; ++h) {
-    if (int rc = launch_view_linear(bf.pf2, head_w[h][0], head_b[h][0], bf.h1, V, 256, 256, 256, 0, 1, s)) return rc;
-    if (int rc = launch_view_linear(bf.h1, head_w[h][1], head_b[h][1], bf.h2, V, 256, 128, 256, 0, 1, s)) return rc;
-    if (int rc = launch_view_linear(bf.h2, head_w[h][2], head_b[h][2], hout[h], V, 128, hdim[h], 128, 0, 0, s)) return rc;
+    if (int rc = launch_view_linear(bf.pf2, head_w[h][0], head_b[h][0], bf.h1, Vh, 256, 256, 256, 0, 1, s)) return rc;
+    if (int rc = launch_view_linear(bf.h1, head_w[h][1], head_b[h][1], bf.h2, Vh, 256, 128, 256, 0, 1, s)) return rc;
+    if (int rc = launch_view_linear(bf.h2, head_w[h][2], head_b[h][2], hout[h], Vh, 128, hdim[h], 128, 0, 0, s)) return rc;
   }
-  if (int rc = launch_ortho6d(bf.r6, bf.R, V, s)) return rc;
+  if (int rc = launch_ortho6d(bf.r6, bf.R, Vh, s)) return rc;
 
   // ---- outputs (fp32, reference shapes) ----
   const size_t BP = (size_t)B * P;
   if (int rc = launch_copy_cols(bf.nocs4, out.nocs1, (long long)BP, 4, 3, 3, s)) return rc;
-  if (int rc = launch_copy_cols(bf.nocs4 + BP * 4, out.nocs2, (long long)BP, 4, 3, 3, s)) return rc;
   RGBM_CHECK_HIP(hipMemcpyAsync(out.depth1, bf.depth, BP * 4, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.depth2, bf.depth + BP, BP * 4, hipMemcpyDeviceToDevice, s));
   RGBM_CHECK_HIP(hipMemcpyAsync(out.r1, bf.R, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.r2, bf.R + (size_t)B * 9, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
   RGBM_CHECK_HIP(hipMemcpyAsync(out.t1, bf.tv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.t2, bf.tv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
   RGBM_CHECK_HIP(hipMemcpyAsync(out.s1, bf.sv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.s2, bf.sv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  if (view2_heads) {
+    if (int rc = launch_copy_cols(bf.nocs4 + BP * 4, out.nocs2, (long long)BP, 4, 3, 3, s)) return rc;
+    RGBM_CHECK_HIP(hipMemcpyAsync(out.depth2, bf.depth + BP, BP * 4, hipMemcpyDeviceToDevice, s));
+    RGBM_CHECK_HIP(hipMemcpyAsync(out.r2, bf.R + (size_t)B * 9, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
+    RGBM_CHECK_HIP(hipMemcpyAsync(out.t2, bf.tv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+    RGBM_CHECK_HIP(hipMemcpyAsync(out.s2, bf.sv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
+  } else {
+    // not computed: every byte 0xFF = NaN, so that a consumer of a view-2 output fails loudly instead of reading stale numbers
+    RGBM_CHECK_HIP(hipMemsetAsync(out.nocs2, 0xFF, BP * 12, s));
+    RGBM_CHECK_HIP(hipMemsetAsync(out.depth2, 0xFF, BP * 4, s));
+    RGBM_CHECK_HIP(hipMemsetAsync(out.r2, 0xFF, (size_t)B * 36, s));
+    RGBM_CHECK_HIP(hipMemsetAsync(out.t2, 0xFF, (size_t)B * 12, s));
+    RGBM_CHECK_HIP(hipMemsetAsync(out.s2, 0xFF, (size_t)B * 12, s));
+  }
   (void)VP;
   return 0;
 }

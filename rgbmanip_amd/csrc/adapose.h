@@ -54,6 +54,9 @@ struct AdaPose {
   Tile3d t3d[10];               // halo-tiled versions: 0..6 conv0..6, 7..9 conv7/9/11
   int igemm_conv6 = 1;          // bf16 + cost_impl 3: conv6 through the implicit-GEMM path instead of the halo-tile kernel
   int fuse_final = 1;           // bf16: PSPNet `final` 1x1 fused into up_3's kernel (0 = two launches; `u3` is then materialised)
+  int view2_heads = 1;          // 0: the cost volume, the point heads and the pose regression run for the view-1 crops only (the view-2 outputs are
+                                // filled with NaN): what `AdaPoseEstimator_v5.estimate` consumes — interface_v5.py:318-374 builds the box from
+                                // view1_nocs / view1_depth / view1_r and drops the rest — at ~3/4 of the time; the backbone still runs on both views
   int sparse_tail = 1;          // cost_impl 3: evaluate conv11 + prob only where prob is gathered (0 = dense conv11, for A/B and tests)
   void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (16-bit nets; bf16x3 nets: hi + lo operand arrays of conv0_sweep_x3.hip)
   int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,

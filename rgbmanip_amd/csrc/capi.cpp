@@ -97,6 +97,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "upconv") { RGBM_REQUIRE(value >= 0 && value <= 7, "upconv"); h->net.upconv = value; }
   else if (k == "sparse_dec") { RGBM_REQUIRE(value >= 0 && value <= 2, "sparse_dec"); h->net.sparse_dec = value; }
   else if (k == "stem") { RGBM_REQUIRE(value == 0 || value == 1, "stem"); h->net.stem = value; }
+  else if (k == "view2_heads") { RGBM_REQUIRE(value == 0 || value == 1, "view2_heads"); h->net.view2_heads = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   ++h->opt_version;

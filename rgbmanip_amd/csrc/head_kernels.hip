@@ -162,10 +162,10 @@ template <> __device__ __forceinline__ float round_through<f16_t>(float f) { ret
 template <typename T, bool ROUND_BF16>
 __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __restrict__ homog, const float* __restrict__ depths,
                                    const int* __restrict__ choose, const float* __restrict__ prob, float* __restrict__ out,
-                                   int V, int B, int P, int D, int H, int W, int ldo, int ch_off) {
-  // one thread per (point, 4-channel group): 8 threads per point for C=32
+                                   int V, int B, int P, int D, int H, int W, int ldo, int ch_off, int Vn) {
+  // one thread per (point, 4-channel group): 8 threads per point for C=32; views 0 .. Vn - 1 (their partners are any of the V)
   constexpr int C = 32;
-  const long long total = (long long)V * P * (C / 4);
+  const long long total = (long long)Vn * P * (C / 4);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i & 7);
     const long long vp = i >> 3;
@@ -231,22 +231,23 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
 
 int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
                        const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
-                       hipStream_t s) {
-  const long long total = (long long)V * P * 8;
+                       hipStream_t s, int Vn) {
+  if (Vn < 0) Vn = V;
+  const long long total = (long long)Vn * P * 8;
   RGBM_REQUIRE(D >= 1 && D <= 24 && total > 0 && (total + 255) / 256 < (1ll << 31), "fuse_points supports up to 24 depth planes");
   const unsigned g = (unsigned)((total + 255) / 256);
   if (dtype == BF16)
     hipLaunchKernelGGL((fuse_points_kernel<unsigned short, true>), dim3(g), dim3(256), 0, s, (const unsigned short*)feat,
-                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off, Vn);
   else if (dtype == F16)
     hipLaunchKernelGGL((fuse_points_kernel<f16_t, true>), dim3(g), dim3(256), 0, s, (const f16_t*)feat,
-                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off, Vn);
   else if (dtype == BF16X3)
     hipLaunchKernelGGL((fuse_points_kernel<bx3_t, false>), dim3(g), dim3(256), 0, s, (const bx3_t*)feat,
-                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+                       homog, depths, choose, prob, out, V, B, P, D, H, W, ldo, ch_off, Vn);
   else
     hipLaunchKernelGGL((fuse_points_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)feat, homog, depths,
-                       choose, prob, out, V, B, P, D, H, W, ldo, ch_off);
+                       choose, prob, out, V, B, P, D, H, W, ldo, ch_off, Vn);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

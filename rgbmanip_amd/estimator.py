@@ -15,6 +15,8 @@ is then a seeded hash, cfg["hip_prepare_seed"]); `estimate_device` takes device-
 from __future__ import annotations
 
 import os
+import sys
+import time
 import warnings
 
 import numpy as np
@@ -139,11 +141,16 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                     logger.warning("AdaPoseEstimator_v5: cfg.load is False -> synthetic (seeded) weights")
         self.dtype = dtype or cfg.get("hip_dtype", "bf16x3")      # the fastest mode inside north_star's 1e-4 (fp32: 4x slower, bf16: 2.4x faster at 1e-2)
         # hip_graph (default off: measured, small batches are bound by their kernels, not by the ~100 launches): batches of at most
-        # hip_graph_max_batch poses replay a captured hipGraph
+        # hip_graph_max_batch poses replay a captured hipGraph.
+        # hip_view2_heads (default: only where the box tail reads view-2 outputs, i.e. the PnP branch): the reference network returns
+        # ten outputs and `predict` builds the box from view1_nocs / view1_depth / view1_r alone (interface_v5.py:318-374), so the
+        # cost volume, point heads and pose regression of the view-2 crops are skipped — the backbone still runs on both views
+        self.view2_heads = bool(cfg.get("hip_view2_heads", not cfg.get("direct_regression", True) and not cfg.get("use_depth", True)))
         self.estimator = net if net is not None else AdaPoseNet(state_dict, dtype=self.dtype, device=device,
                                                                 norm_mode=cfg.get("hip_norm_mode", "eval"),
                                                                 graph=bool(cfg.get("hip_graph", False)),
-                                                                graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)))
+                                                                graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)),
+                                                                options={"view2_heads": int(self.view2_heads)})
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
         self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))
@@ -278,12 +285,17 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                         tasks.append((_nonzero_into, dst[lo:hi], src[a + lo:a + hi]))
             list(pool.map(lambda t: t[0](t[1], t[2]), tasks))
 
+        trace = [] if os.environ.get("RGBM_UPLOAD_TRACE") == "1" else None
         for c, a in enumerate(range(0, n, chunk)):
             b = min(a + chunk, n)
             slot = c & 1
+            t0 = time.perf_counter()
             if used[slot]:
                 self._pipe_h2d[slot].synchronize()         # the copy that last read this slot's pinned buffers has finished
+            t1 = time.perf_counter()
             stage(slot, a, b)                              # host threads; overlaps the device's work on the previous chunks
+            if trace is not None:
+                trace.append((round((t1 - t0) * 1e3, 2), round((time.perf_counter() - t1) * 1e3, 2)))
             with torch.cuda.stream(self._pipe_stream):
                 if used[slot]:
                     self._pipe_stream.wait_event(self._pipe_done[slot])      # the kernels that read this slot's device buffers are done
@@ -295,7 +307,10 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             out[a:b] = self.estimate_device(Kd[a:b], self._upload_frames(d[0]), d[2], E1d[a:b], self._upload_frames(d[1]), d[3], E2d[a:b], frame0=a)
             self._pipe_done[slot].record(cur)
             used[slot] = True
-        return out.cpu().numpy()
+        res = out.cpu().numpy()
+        if trace is not None:
+            print("[rgbm upload trace] per chunk (wait for slot ms, stage ms):", trace, file=sys.stderr)
+        return res
 
     def _upload_frames(self, frames):
         """[N,H,W,3] host frames (float64 / float32 in [0,1], or uint8) -> CUDA float32 [N,H,W,3] in [0,1].  Frames that already are
