@@ -408,11 +408,17 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             _lib.check(_lib.load().rgbm_projection(_lib.ptr(Kc.contiguous()), _lib.ptr(E.contiguous()), _lib.ptr(P), n, _lib.stream_ptr()),
                        "rgbm_projection")
             return P
-        depths = torch.from_numpy(np.tile(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)[None], (n, 1))).to(dev)
+        # constants live on the device: a pageable host -> device copy here would block the host until the stream has drained, i.e.
+        # serialise the chunk pipeline of _estimate_host_frames (measured: staging, copy and kernels ran back to back)
+        consts = getattr(self, "_dev_consts", None)
+        if consts is None or consts[0].device != dev:
+            consts = self._dev_consts = (torch.from_numpy(DEFAULT_BBOX).to(dev),
+                                         torch.from_numpy(np.arange(0.1, 0.1 * (24 - 0.5) + 0.1, 0.1, dtype=np.float32)).to(dev))
+        depths = consts[1][None].expand(n, 24).contiguous()
         pred = self.estimator(a["img"], a["choose"], b["img"], b["choose"], proj(a["Kcrop"], E1d), proj(b["Kcrop"], E2d), depths)
         bbox = self._bbox_tail(pred, a["choose"], a["Kcrop"], E1d, pts2d=(a.get("pts2d"), b.get("pts2d")), E2=E2d, K=K)
         ok = ((a["valid"] != 0) & (b["valid"] != 0)).view(n, 1, 1)
-        return torch.where(ok, bbox, torch.from_numpy(DEFAULT_BBOX).to(dev).expand(n, 8, 3))
+        return torch.where(ok, bbox, consts[0].expand(n, 8, 3))
 
     def _bbox_tail(self, pred, choose, Kcrop, E1, pts2d=None, E2=None, K=None):
         """interface_v5.py:318-374: scale / translation from the regressed rotation (`direct_regression`, the shipped configs)
