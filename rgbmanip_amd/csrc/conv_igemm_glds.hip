@@ -1342,408 +1342,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
 }
 
 #ifdef RGBM_EXPERIMENTS      // experiment kernels (slower than the shipped ones; kept with their parity tests): build with RGBM_EXPERIMENTS=1 build.sh
-// ---------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves of 128 channels x 64 pixels, two wave groups in ping-pong (layers whose output channels are a multiple
-// of 256: layer3, layer4, up_1 — 96 % of the implicit GEMM's flops).
-// Why: the role-specialised kernel above spends one 12-wave barrier, one 48 KB LDS fill and 16 fragment reads per wave for every
-// 32 MFMAs per wave; its counters show the multiply waves 38 % of their cycles in s_waitcnt / s_barrier and the matrix pipe 45 %
-// busy.  Here a K tile (64 channels of one tap) carries 64 MFMAs per wave for 24 fragment reads, the bytes that cross L2 -> LDS
-// per flop drop by a third, and the schedule is the two-group alternation the CDNA4 guide measures fastest for this tile:
-//   * a K tile is four phases, one accumulator quadrant (4 x 2 fragments x K=64 = 16 MFMAs) each, in the order Q00 Q01 Q11 Q10 so
-//     that every phase needs at most one new operand half (phase 1: W half 0 + X half 0, 2: X half 1, 3: W half 1, 4: none);
-//   * a phase is [fragment reads + one half-tile of LDS-DMA] s_barrier [16 MFMAs] s_barrier; waves 4-7 run one barrier behind
-//     waves 0-3, so on every SIMD (it hosts one wave of each group) one wave multiplies while the other reads and requests;
-//   * the operand stream is one half-tile (16 KB = 2 pieces per wave) per phase, in the order W0 X0 X1 W1 per K tile, and a
-//     half-tile slot is refilled three phases after the phase that read it: W0/X0 of K tile g+2 during phases 3/4 of g, X1/W1 of
-//     g+1 during phases 1/2 of g — two 64 KB stages, every request 5-6 phases ahead of its first use;
-//   * one counted wait per K tile: in phase 4, before the phase's first barrier, vmcnt(4) leaves only W0/X0 of g+2 in flight, so
-//     all of K tile g+1 has landed; its first read is in the next phase, behind a barrier every wave passed after its own wait
-//     (both groups: the later group's wait precedes the barrier that releases the earlier group into that phase).
-// vmcnt also counts the epilogue's stores, which retire out of order with respect to loads, so the K tile that follows an
-// epilogue (and the last two of the stream) waits with vmcnt(0) instead; once per tile.
-// Every wave issues its own eighth of each half-tile with the wave-uniform tap walk of the kernel above; the K-tile stream runs
-// on across tile boundaries (persistent workgroups, XCD-aware tile order).
-// ---------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_igemm_w256_kernel(const ConvDesc d) {
-  constexpr int BCH = 256, BPIX = 256;
-  constexpr int E = 8, BK = 64;
-  constexpr int STAGE = (BCH + BPIX) * 8;    // uint4 slots per stage (64 KB): W half 0 | W half 1 | X half 0 | X half 1, 128 rows each
-  extern __shared__ __attribute__((aligned(16))) uint4 lds3[];
-  static_assert(sizeof(T) == 2, "16-bit storage types only");
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
-  const int grp = wave >> 2;                 // channel half of the tile, and the ping-pong group
-  const int wc = wave & 3;                   // pixel quarter
-  const int KT = d.KT;
-  const int n_my = ((int)d.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = n_my * KT;
-  auto tile_of = [&](int k, int& pix_tile, int& ch_tile) {
-    const int v = (int)blockIdx.x + k * (int)gridDim.x;
-    const int nblk = d.n_tiles, bq = nblk >> 3, br = nblk & 7, xcd = v & 7, bidx = v >> 3;
-    const int lid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
-    pix_tile = lid / d.n_ch_tiles;
-    ch_tile = lid - pix_tile * d.n_ch_tiles;
-  };
-  float* lbias = reinterpret_cast<float*>(lds3 + 2 * STAGE);
-  const bool bias_lds = d.bias != nullptr && d.bias_stride == 0 && d.Cout <= 2048;
-  if (bias_lds)
-    for (int i = tid; i < d.Cout; i += 512) lbias[i] = d.bias[i];
-  __syncthreads();
-  if (total == 0) return;
-
-  // ---- request side.  Half-tile h of an operand = LDS rows h*128 .. h*128+127 of its region; this wave fills rows q = i*64 + 8*wave
-  // + r8 (i = 0, 1) of each half.  W row (h, q) holds tile channel (q>>6)*128 + h*64 + (q&63); X row (h, q) holds tile pixel
-  // (q>>5)*64 + h*32 + (q&31) — each wave's fragments of one half are 64 (W) / 32 (X) consecutive LDS rows.  Lane (r8, j) of a
-  // piece fills slot (row, j) with source chunk j ^ swizzle(LDS row).
-  const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(d.wgt);
-  const int j = lane & 7, r8 = lane >> 3;
-  const char* rowp[2][2];
-  unsigned rmask[2][2];
-  const char* wrow[2][2];
-  const char* zero = reinterpret_cast<const char*>(g_zero_page);
-  int tkd = 0, tkh = 0, tkw = 0, tc = 0;     // wave-uniform tap walker of the request stream
-  int ikt = 0, itile = 0, ist = 0;           // K tile within the tile, tile, stream step of the next request
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3)) + (unsigned)wave * 1024u;
-  auto enter_tile = [&](int k) {
-    int pix_tile, ch_tile;
-    tile_of(k, pix_tile, ch_tile);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int q = i * 64 + 8 * wave + r8;
-        const int lrow = h * 128 + q;
-        const long long m = (long long)pix_tile * BPIX + ((q >> 5) * 64 + h * 32 + (q & 31));
-        int xn = 0, xd0 = -(1 << 20), xh0 = 0, xw0 = 0;
-        if (m < d.M) {
-          unsigned n, qd, qh, qw;
-          decode_row(d, (unsigned)m, n, qd, qh, qw);
-          xn = (int)n * d.Di;
-          xd0 = (int)qd * d.sd - d.pd;
-          xh0 = (int)qh * d.sh - d.ph;
-          xw0 = (int)qw * d.sw - d.pw;
-        }
-        unsigned mk = 0;
-        for (int kk = 0; kk < d.KD; ++kk) mk |= (unsigned)((unsigned)(xd0 + kk * d.dild) < (unsigned)d.Di) << kk;
-        for (int kk = 0; kk < d.KH; ++kk) mk |= (unsigned)((unsigned)(xh0 + kk * d.dilh) < (unsigned)d.Hi) << (8 + kk);
-        for (int kk = 0; kk < d.KW; ++kk) mk |= (unsigned)((unsigned)(xw0 + kk * d.dilw) < (unsigned)d.Wi) << (16 + kk);
-        rmask[h][i] = mk;
-        const long long pix0 = ((long long)(xn + xd0) * d.Hi + xh0) * d.Wi + xw0;
-        rowp[h][i] = reinterpret_cast<const char*>(in) + (pix0 * d.Cin + (j ^ ((lrow >> 1) & 7)) * E) * 2ll;
-        const int ch = (q >> 6) * 128 + h * 64 + (q & 63);
-        wrow[h][i] = reinterpret_cast<const char*>(wgt + (long long)(ch_tile * BCH + ch) * d.Kpad + (j ^ swz_w(lrow)) * E);
-      }
-    tkd = tkh = tkw = tc = 0;
-  };
-  // one 1 KB piece of the stream: which = 0 W half 0 (its first piece enters a new tile when due), 1 X half 0, 2 X half 1, 3 W half 1
-  // (after its second piece the walker advances to the next K tile); i = 0, 1 the wave's two pieces of the half-tile
-  auto issue_piece = [&](auto whichc, auto ic) {
-    constexpr int which = decltype(whichc)::value, i = decltype(ic)::value;
-    if (ist >= total) return;
-    if ((W256_ABL & 2) && ist >= 2) {
-      if (which == 3 && i == 1) { if (++ikt == KT) { ikt = 0; ++itile; } ++ist; }
-      return;
-    }
-    if (which == 0 && i == 0 && ikt == 0) enter_tile(itile);
-    const unsigned sbase = lds0 + (unsigned)(ist & 1) * (STAGE * 16);
-    if (W256_ABL & 128) {
-      glds16(zero, sbase + ((which == 0 || which == 3 ? 0 : 256) + (which == 0 || which == 1 ? 0 : 128) + i * 64) * 128);
-    } else if (W256_ABL & 256) {
-      if (lane == 0) glds16(zero, sbase + ((which == 0 || which == 3 ? 0 : 256) + (which == 0 || which == 1 ? 0 : 128) + i * 64) * 128);
-    } else if (which == 0 || which == 3) {
-      constexpr int h = which == 0 ? 0 : 1;
-      const long long wk = (long long)ikt * BK * 2ll;
-      glds16((W256_ABL & 512) ? zero : wrow[h][i] + wk, sbase + (h * 128 + i * 64) * 128);
-    } else if (W256_ABL & 1024) {
-      constexpr int h = which - 1;
-      glds16(zero, sbase + (256 + h * 128 + i * 64) * 128);
-    } else {
-      constexpr int h = which - 1;
-      const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
-      const long long soff = ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * 2ll;
-      const bool ok = (rmask[h][i] & sel) == sel;
-      glds16(ok ? rowp[h][i] + soff : zero, sbase + (256 + h * 128 + i * 64) * 128);
-    }
-    if (which == 3 && i == 1) {
-      tc += BK;
-      if (tc >= d.Cin) {
-        tc = 0;
-        if (++tkw == d.KW) { tkw = 0; if (++tkh == d.KH) { tkh = 0; ++tkd; } }
-      }
-      if (++ikt == KT) { ikt = 0; ++itile; }
-      ++ist;
-    }
-  };
-  // pieces q0 .. q1-1 of the per-K-tile sequence X1a X1b W1a W1b (of K tile g+1) W0a W0b X0a X0b (of K tile g+2)
-  auto issue_seq = [&](auto q0c, auto q1c) {
-    constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
-    if (q0 <= 0 && 0 < q1) issue_piece(IC<2>{}, IC<0>{});
-    if (q0 <= 1 && 1 < q1) issue_piece(IC<2>{}, IC<1>{});
-    if (q0 <= 2 && 2 < q1) issue_piece(IC<3>{}, IC<0>{});
-    if (q0 <= 3 && 3 < q1) issue_piece(IC<3>{}, IC<1>{});
-    if (q0 <= 4 && 4 < q1) issue_piece(IC<0>{}, IC<0>{});
-    if (q0 <= 5 && 5 < q1) issue_piece(IC<0>{}, IC<1>{});
-    if (q0 <= 6 && 6 < q1) issue_piece(IC<1>{}, IC<0>{});
-    if (q0 <= 7 && 7 < q1) issue_piece(IC<1>{}, IC<1>{});
-  };
-  auto issue_half = [&](auto whichc) { issue_piece(whichc, IC<0>{}); issue_piece(whichc, IC<1>{}); };
-
-  // ---- multiply side ----
-  const int wch = grp * 128;
-  const int wpix = wc * 64;
-  const int lr = lane & 15, lg = lane >> 4;
-  f32x4 acc[8][4];
-  T* __restrict__ out = reinterpret_cast<T*>(d.out);
-  const T* __restrict__ res = reinterpret_cast<const T*>(d.res);
-  auto tile_interior = [&](int pix_tile, int ch_tile) {
-    return (d.bias == nullptr || bias_lds) && (long long)(pix_tile + 1) * BPIX <= d.M && (ch_tile + 1) * BCH <= d.Cout && d.act != ACT_TANH;
-  };
-  auto seed_acc = [&](int k) {
-    int pt, ct;
-    tile_of(k, pt, ct);
-    if (tile_interior(pt, ct) && d.bias) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        // fragment a = (half a >> 2, a & 3): the lane's channels are wch + (a>>2)*64 + lg*16 + (a&3)*4 .. +3
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + ct * BCH + wch + (a >> 2) * 64 + lg * 16 + (a & 3) * 4);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = b4;
-      }
-    } else {
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  // fragment slots of this lane inside a stage (uint4 units), without the k-step chunk: row * 8, and the row's swizzle
-  int wslot[4], wsw[4], xslot[2], xsw[2];
-#pragma unroll
-  for (int a2 = 0; a2 < 4; ++a2) {
-    const int row = grp * 64 + (lr >> 2) * 16 + a2 * 4 + (lr & 3);        // + half * 128; the ws kernel's row permutation per 64 channels
-    wslot[a2] = row * 8;
-    wsw[a2] = swz_w(row);
-  }
-#pragma unroll
-  for (int b2 = 0; b2 < 2; ++b2) {
-    const int row = wc * 32 + b2 * 16 + lr;                               // + half * 128
-    xslot[b2] = (256 + row) * 8;
-    xsw[b2] = (row >> 1) & 7;
-  }
-  uint4 af[2][4] = {}, b0f[2][2] = {}, b1f[2][2] = {};      // [k-step][fragment]
-  auto read_w = [&](const uint4* S, int h) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int a2 = 0; a2 < 4; ++a2) {
-        if (W256_ABL & 4) asm volatile("" : "+v"(af[s2][a2].x), "+v"(af[s2][a2].y), "+v"(af[s2][a2].z), "+v"(af[s2][a2].w));
-        else af[s2][a2] = S[h * 1024 + wslot[a2] + ((s2 * 4 + lg) ^ wsw[a2])];
-      }
-  };
-  auto read_x = [&](const uint4* S, int h, uint4 (&bf)[2][2]) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
-        if (W256_ABL & 4) asm volatile("" : "+v"(bf[s2][b2].x), "+v"(bf[s2][b2].y), "+v"(bf[s2][b2].z), "+v"(bf[s2][b2].w));
-        else bf[s2][b2] = S[h * 1024 + xslot[b2] + ((s2 * 4 + lg) ^ xsw[b2])];
-      }
-  };
-  auto quadrant = [&](int mh, int nh, const uint4 (&bf)[2][2], auto mid) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(W256_ABL & 8)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-      for (int a2 = 0; a2 < 4; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-          if (W256_ABL & 1) asm volatile("" : "+v"(acc[mh * 4 + a2][nh * 2 + b2]) : "v"(af[s2][a2].x), "v"(af[s2][a2].w), "v"(bf[s2][b2].x), "v"(bf[s2][b2].w));
-          else MmaG<T>::run(af[s2][a2], bf[s2][b2], acc[mh * 4 + a2][nh * 2 + b2]);
-        }
-      if (s2 == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto epilogue = [&](int k) {
-    int pix_tile, ch_tile;
-    tile_of(k, pix_tile, ch_tile);
-    const bool interior = tile_interior(pix_tile, ch_tile);
-    long long obase[4];
-    int nn[4];
-    bool pok[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const long long m = (long long)pix_tile * BPIX + wpix + b * 16 + lr;
-      pok[b] = m < d.M;
-      unsigned n, qd, qh, qw;
-      decode_row(d, pok[b] ? (unsigned)m : 0u, n, qd, qh, qw);
-      nn[b] = (int)n;
-      obase[b] = ((((long long)n * d.Do + (qd * d.osd + d.opd)) * d.Ho + (qh * d.osh + d.oph)) * d.Wo + (qw * d.osw + d.opw)) * d.ldo;
-    }
-    const float slope = d.slope;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {               // the wave's two 64-channel halves: 16 consecutive channels per lane each
-      const int chL = ch_tile * BCH + wch + half * 64 + lg * 16;
-      if (interior) {
-        auto fast = [&](auto actc, auto resc) {
-          constexpr int ACT = decltype(actc)::value, RES = decltype(resc)::value;
-          uint4 rr[2][4];
-          if (RES != RES_NONE) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-              for (int q = 0; q < 2; ++q) rr[q][b] = *reinterpret_cast<const uint4*>(res + obase[b] + chL + q * 8);
-          }
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              float v[8], rv[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = acc[half * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3];
-              if (RES != RES_NONE) unpack_chunk(rr[q][b], rv, T());
-              if (RES == RES_PRE_ACT) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                v[e] = ACT == ACT_RELU ? (v[e] < 0.f ? 0.f : v[e]) : ACT == ACT_PRELU ? (v[e] < 0.f ? v[e] * slope : v[e]) : v[e];
-              if (RES == RES_POST_ACT) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
-              }
-              *reinterpret_cast<uint4*>(out + obase[b] + chL + q * 8) = pack_chunk(v, T());
-            }
-        };
-        auto by_res = [&](auto actc) {
-          if (d.res_mode == RES_NONE) fast(actc, IC<RES_NONE>{});
-          else if (d.res_mode == RES_PRE_ACT) fast(actc, IC<RES_PRE_ACT>{});
-          else fast(actc, IC<RES_POST_ACT>{});
-        };
-        if (d.act == ACT_RELU) by_res(IC<ACT_RELU>{});
-        else if (d.act == ACT_PRELU) by_res(IC<ACT_PRELU>{});
-        else by_res(IC<ACT_NONE>{});
-        continue;
-      }
-      // ragged tiles (last pixel tile), per-sample bias, tanh: per-chunk checks
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int c = chL + q * 8;
-          if (!pok[b] || c >= d.Cout) continue;
-          float v[8], rv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] = acc[half * 4 + ((q * 8 + e) >> 2)][b][(q * 8 + e) & 3]; rv[e] = 0.f; }
-          if (d.bias) {
-            const float* bp = d.bias + (long long)nn[b] * d.bias_stride + c;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bp[e];
-          }
-          if (d.res_mode != RES_NONE) unpack_chunk(*reinterpret_cast<const uint4*>(res + obase[b] + c), rv, T());
-          if (d.res_mode == RES_PRE_ACT) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = apply_act_g(v[e], d.act, d.slope);
-          if (d.res_mode == RES_POST_ACT) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          }
-          *reinterpret_cast<uint4*>(out + obase[b] + c) = pack_chunk(v, T());
-        }
-    }
-  };
-
-  // prologue: all of K tile 0, W0/X0 of K tile 1
-  issue_half(IC<0>{}); issue_half(IC<1>{}); issue_half(IC<2>{}); issue_half(IC<3>{});
-  issue_half(IC<0>{}); issue_half(IC<1>{});
-  if (total > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  seed_acc(0);
-  RGBM_BARRIER();
-  if (grp == 1) RGBM_BARRIER();              // the second group runs one barrier behind the first from here on
-  int k = 0, kt = 0;
-  for (int g = 0; g < total; ++g) {
-    const uint4* S = lds3 + (g & 1) * STAGE;
-    // pieces requested per phase: W256_DIST digits (phases 1..4, sum 8).  Pieces 0-3 (X1, W1 of K tile g+1) may go in any phase;
-    // pieces 4-7 refill the W0 / X0 slots of THIS stage, read in phase 1, so they go in phases 3-4.
-    constexpr int D1 = W256_DIST / 1000, D2 = W256_DIST / 100 % 10, D3 = W256_DIST / 10 % 10, D4 = W256_DIST % 10;
-    static_assert(D1 + D2 + D3 + D4 == 8 && D1 + D2 <= 4, "piece schedule");
-    // phase 1: W half 0 x X half 0
-    read_w(S, 0);
-    read_x(S, 0, b0f);
-    issue_seq(IC<0>{}, IC<D1>{});
-    RGBM_BARRIER();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(0, 0, b0f, [&]() {});
-    RGBM_BARRIER();
-    // phase 2: W half 0 x X half 1
-    read_x(S, 1, b1f);
-    issue_seq(IC<D1>{}, IC<D1 + D2>{});
-    RGBM_BARRIER();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(0, 1, b1f, [&]() {});
-    RGBM_BARRIER();
-    // phase 3: W half 1 x X half 1
-    read_w(S, 1);
-    issue_seq(IC<D1 + D2>{}, IC<D1 + D2 + D3>{});
-    RGBM_BARRIER();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    quadrant(1, 1, b1f, [&]() {});
-    RGBM_BARRIER();
-    // phase 4: W half 1 x X half 0 (both in registers)
-    issue_seq(IC<D1 + D2 + D3>{}, IC<8>{});
-    if (W256_ABL & 32) {}
-    else if (kt == 0 || g + 2 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores of the last epilogue are counted too
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               // all of K tile g+1 has landed
-    RGBM_BARRIER();
-    quadrant(1, 0, b0f, [&]() {});
-    RGBM_BARRIER();
-    if (++kt == KT) {
-      epilogue(k);
-      kt = 0;
-      if (++k < n_my) seed_acc(k);
-    }
-  }
-  if (grp == 0) RGBM_BARRIER();              // pairs with the second group's last barrier
-}
-
-template <typename T>
-static int launch_w256(ConvDesc d, hipStream_t s) {
-  constexpr int BCH = 256, BPIX = 256;
-  constexpr size_t LDS = 2 * (BCH + BPIX) * 8 * sizeof(uint4) + 2048 * sizeof(float);      // two 64 KB stages + per-channel bias table
-  d.n_pix_tiles = (int)((d.M + BPIX - 1) / BPIX);
-  d.n_ch_tiles = (d.Cout + BCH - 1) / BCH;
-  const long long ntiles = (long long)d.n_pix_tiles * d.n_ch_tiles;
-  RGBM_REQUIRE(ntiles > 0 && ntiles < (1ll << 31) && d.M < (1ll << 31), "conv grid out of range");
-  d.n_tiles = (int)ntiles;
-  make_fastdiv(d.Wq, d.fd_m[0], d.fd_s[0]);
-  make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
-  make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_w256_kernel<T>), (int)LDS)) return rc;
-  int n_cu = 0;
-  if (int rc = persistent_grid_cus(&n_cu)) return rc;
-  const int grid = ntiles < n_cu ? (int)ntiles : n_cu;
-  prof_begin_launch(s, 30, d.algo_flops, d.algo_bytes);
-  hipLaunchKernelGGL((conv_igemm_w256_kernel<T>), dim3((unsigned)grid), dim3(512), LDS, s, d);
-  prof_end_launch(s);
-  RGBM_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
+#include "conv_igemm_experiments.inc"
 #endif  // RGBM_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------

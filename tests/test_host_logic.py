@@ -167,3 +167,35 @@ def test_prepare_model_input_uint8_follows_totensor():
     np.testing.assert_allclose(v8.numpy(), vf.numpy(), rtol=0, atol=1e-6)
     with pytest.raises(TypeError):
         est.prepare_model_input(rgb8.astype(np.int32), mask, K, 224)
+
+
+def test_upload_split_and_mask_helpers():
+    """host-side helpers of AdaPoseEstimator_v5's frame upload: row ranges cover a chunk exactly once, masks of any number type
+    become one byte per pixel"""
+    import numpy as np
+    from rgbmanip_amd import estimator as e
+    for n in (1, 5, 17, 64):
+        for parts in (1, 3, 16, 40):
+            pieces = e._split(n, parts)
+            assert pieces[0][0] == 0 and pieces[-1][1] == n and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+            assert all(hi > lo for lo, hi in pieces) and len(pieces) <= max(1, min(parts, n))
+    src = np.array([[0.0, 0.5], [-2.0, 0.0]])
+    dst = np.zeros((2, 2), np.uint8)
+    e._nonzero_into(dst, src)
+    assert dst.tolist() == [[0, 1], [1, 0]]
+
+
+def test_postprocess_split_planning_and_tuning_keys():
+    """rgbm_adapose_postprocess_scratch_bytes: small batches get scratch for the sliced exact-median search, large ones none;
+    rgbm_set_tuning rejects unknown keys (no GPU needed for either)."""
+    import ctypes as C
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    nb = C.c_size_t()
+    sizes = {}
+    for B in (1, 8, 64, 128, 129, 256):
+        assert lib.rgbm_adapose_postprocess_scratch_bytes(B, C.byref(nb)) == 0
+        sizes[B] = nb.value
+    assert sizes[1] > 0 and sizes[8] == 8 * sizes[1] and sizes[128] == 128 * sizes[1] and sizes[129] == 0 and sizes[256] == 0
+    assert lib.rgbm_set_tuning(b"ws_min_rows", 4096) == 0 and lib.rgbm_set_tuning(b"ws_min_rows", 0) == 0
+    assert lib.rgbm_set_tuning(b"no_such_key", 1) != 0 and b"unknown tuning key" in lib.rgbm_last_error()

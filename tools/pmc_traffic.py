@@ -38,7 +38,9 @@ with open(sys.argv[3], "w") as fh:
         fh.write('"%s",%d,%.1f,%.1f,%.4g\n' % (k[:110], n, fk, wk, b))
 from bench import tree_hash  # noqa: E402
 total = sum(n * b for k, n, fk, wk, b in rows if "rgbm::" in k)
+import socket  # noqa: E402
 json.dump({"_meta": {"tree": tree_hash(), "dtype": dtype, "forwards": forwards, "hbm_bytes_per_step": total / forwards,
+                     "box": socket.gethostname(), "inputs": "bench.py default (--inputs crop: masks span their crops)",
                      "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, summed over the library's kernels of one forward"},
            "bytes_per_launch": {k: b for k, n, fk, wk, b in rows}}, open(sys.argv[4], "w"), indent=0)
 print("wrote", sys.argv[3], sys.argv[4], len(rows), "kernels; whole-net GB per step %.2f" % (total / forwards / 1e9))
