@@ -24,7 +24,8 @@
 #include "prof.h"
 
 #ifndef SW_ABL
-#define SW_ABL 0      // ablation builds only (tools/abl_sweep.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel
+#define SW_ABL 0      // ablation builds only (tools/abl_build.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel,
+                      // 16 no output stores, 32 no per-plane projection (the first plane's corners are reused), 64 gathers from one address
 #endif
 
 namespace rgbm {
@@ -56,7 +57,18 @@ constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
 constexpr int SW_VS = SW_VS_BYTES;               // LDS bytes per voxel: 64 data + 16 pad (conflict-free b128 rows)
 constexpr int SW_SLOT = SW_NV * SW_VS;           // 20160
 constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
-constexpr int SW_NCW = SW_TH / 4;                // 3 consumer waves, 4 fragments (rows) each
+#ifndef SW_CR
+#define SW_CR 4       // tile rows (= 16-voxel fragments) per consumer wave: 4 -> 3 consumer waves (rounds 1-3), 2 -> 6 consumer waves.
+                      // Measured alone (no producer work at all) the 4-row consumer needs 2140 cycles per plane for 1152 cycles of MFMA: one
+                      // wave per SIMD has nobody to cover its LDS round trip at the start of a plane and its ~70 VALU of output epilogue at
+                      // the end.  With 2 rows per wave two of the SIMDs host two consumer waves each, whose streams the hardware interleaves —
+                      // measured in the full kernel: 17.0 ms against 16.9 ms (no gain: the consumers' bubbles are not what bounds it), and
+                      // the f16 instantiation lost its run-to-run stability (test_fp16_sweep_conv0_stable_and_matches_tile_conv0).  3 rows
+                      // (4 consumer waves, one per SIMD next to a producer: the balanced split): 16.2 ms against 16.8 ms in bf16, and the f16
+                      // instantiation fails its golden test.  4 stays.
+#endif
+constexpr int SW_CR_ = SW_CR;
+constexpr int SW_NCW = SW_TH / SW_CR_;           // consumer waves, SW_CR fragments (rows) each
 constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
 // Plane ring of THREE slots.  Two are what the barrier protocol needs on paper (producers fill slot z&1 while the consumers
 // read the other one), and the bf16 build never showed a problem with two — but the f16_t build with the shorter
@@ -74,7 +86,8 @@ constexpr int SW_NSLOT = SW_NSLOT_N;
 #define SW_EXIT_BARRIER 0  // experiment builds: one more barrier after the last plane, so that all waves of a workgroup retire together
 #endif
 constexpr int SW_LDS = SW_NSLOT * SW_SLOT + SW_LDS_PAD;
-static_assert(SW_TH % 4 == 0, "a consumer wave owns 4 rows");
+static_assert(SW_TH % SW_CR_ == 0 && !(SW_HAND && SW_CR_ != 4), "a consumer wave owns SW_CR rows");
+constexpr int SW_NPAIR = (SW_CR_ + 1) / 2;       // fragment pairs of the output epilogue; with an odd SW_CR the last fragment pairs with itself
 
 struct SweepDesc {
   const unsigned short* feat;     // [V][H][W][32] bf16
@@ -342,7 +355,14 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
     }
     for (int z = 0; z <= D; ++z) {
       if (act && z < D) {
+#if SW_ABL & 32
+        nxt = cur;
+#else
         corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
+#endif
+#if SW_ABL & 64
+        nxt.off[0] = nxt.off[1] = nxt.off[2] = nxt.off[3] = 0u;
+#endif
         if (sizeof(T) == 2 && !std::is_same<T, unsigned short>::value) {
           // f16_t: keep the reference feature packed (hipcc otherwise hoists its 32 conversions out of the plane loop:
           // 170 VGPRs instead of 164)
@@ -436,27 +456,30 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = d.bias[ch + r];
     const int ow = w0 + lr;
-    int oh[2];
-    bool ook[2];
+    int oh[SW_NPAIR];
+    bool ook[SW_NPAIR];
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      oh[pr] = h0 + cw * 4 + pr * 2 + (lg >> 1);
-      ook[pr] = oh[pr] < H && ow < W;
+    for (int pr = 0; pr < SW_NPAIR; ++pr) {
+      const bool self = 2 * pr + 1 >= SW_CR_;                    // odd row count: the last fragment pairs with itself, lanes lg < 2 store it
+      oh[pr] = h0 + cw * SW_CR_ + pr * 2 + (self ? 0 : (lg >> 1));
+      ook[pr] = oh[pr] < H && ow < W && !(self && lg >= 2);
     }
-    const int boff = ((cw * 4) * SW_HW + lr) * SW_VS + lg * 16;     // fragment 0, tap (0,0)
+    const int boff = ((cw * SW_CR_) * SW_HW + lr) * SW_VS + lg * 16;     // fragment 0, tap (0,0)
 
-    f32x4 Xp[4], Lp[2];
+    f32x4 Xp[SW_CR_], Lp[SW_NPAIR];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) Xp[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    Lp[0] = Lp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < SW_CR_; ++f) Xp[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < SW_NPAIR; ++pr) Lp[pr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto emit = [&](int o) {           // out plane o from Xp (= X[o]) and Lp (= rows 0-7 of X[o-1]); leaves Lp = rows 0-7 of X[o]
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
+      for (int pr = 0; pr < SW_NPAIR; ++pr) {
         f32x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[2 * pr][r]), __float_as_uint(Xp[2 * pr + 1][r]), false, false);
+          const int f1 = 2 * pr + 1 < SW_CR_ ? 2 * pr + 1 : 2 * pr;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[2 * pr][r]), __float_as_uint(Xp[f1][r]), false, false);
           lo[r] = __uint_as_float(sw[0]);      // lanes 0-31: rows 0-7 of frag 2pr, lanes 32-63: rows 0-7 of frag 2pr+1
           hi[r] = __uint_as_float(sw[1]);      // rows 8-15 likewise
         }
@@ -467,7 +490,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
             v[r] = (hi[r] + Lp[pr][r]) + bias[r];
             if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
           }
-          store4(reinterpret_cast<T*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
+          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(reinterpret_cast<T*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
         }
         Lp[pr] = lo;
       }
@@ -477,9 +500,9 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       if (z >= 1) {
         const int p = z - 1;
         const unsigned char* slot = planes + (p % SW_NSLOT) * SW_SLOT + boff;
-        f32x4 Xn[4];
+        f32x4 Xn[SW_CR_];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < SW_CR_; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if SW_HAND
         // 18 half-tap steps of 2 fragment reads + 4 MFMAs; the reads of step i + 2 are issued behind the MFMAs of step i into the
         // set step i - 2 multiplied from; at step i the reads of steps i and i + 1 are outstanding and LDS operations complete
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
 #pragma unroll
         for (int tp = 0; tp < ((SW_ABL & 2) ? 0 : 9); ++tp) {
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {
+          for (int f = 0; f < SW_CR_; ++f) {
             const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
             Xn[f] = Sw16<T>::mma(A01[tp], b, Xn[f]);
             Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
 #endif
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
-        for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
+        for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
       }
       // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
       // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
