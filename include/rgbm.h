@@ -365,11 +365,14 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *   4096  halo-tile conv0 instead of the plane-sweep kernels             8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
- *                                                                                  (default since round 3: channel block outer, taps inner) */
+ *                                                                                  (default since round 3: channel block outer, taps inner)
+ * 2097152  bf16 plane sweep: blend on scalar fp32 FMAs                    4194304  ... on packed fp32 (rounds 1-3; default: v_perm + v_dot2_f32_bf16)
+ * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches */
 int rgbm_debug_flags(int flags);
 /* dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
- * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = per storage type:
- * 1024 for 16-bit storage, 8192 for fp32 / split pairs (measured at B = 1 and B = 8; rounds 1-3 used 65536 for all). */
+ * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = 1024 (measured at
+ * B = 1 .. 8 in every storage type; rounds 1-3 used 65536).  Launches whose 64-channel x 256-pixel tiles fit one round of the
+ * persistent grid take that tile shape (debug flag 16777216 disables it). */
 int rgbm_set_tuning(const char* key, long long value);
 /* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
  * flags are then ignored */

@@ -1838,10 +1838,11 @@ static int launch_ws64(ConvDesc d, hipStream_t s) {
 }
 
 // GEMM rows (output pixels) from which the persistent role-specialised kernels replace the generic tiles.  Rounds 1-3 used 65 536
-// (one 256-pixel tile per CU); measured at small batches in round 4 (forward + post-processing latency, same box): bf16 B = 8
-// (12 544 rows in layer3) 3.11 -> 2.74 ms with the threshold at 8192, B = 1 (1568 rows) 2.08 -> 1.85 ms at 1024; split pairs
-// B = 8 5.40 -> 5.28 ms, B = 1 3.49 -> 3.57 ms (worse) — so 16-bit storage switches from 1024 rows, 4-byte storage from 8192.
-static long long ws_min_rows(size_t elem_bytes) { return g_ws_min_rows > 0 ? g_ws_min_rows : (elem_bytes == 2 ? 1024 : 8192); }
+// (one 256-pixel tile per CU).  Round 4, forward + post-processing latency at small batches on one box: with the 64 x 256 tile taken
+// for launches that fit one round of the grid (launch_dtype_g) the persistent kernels win from ~1000 rows on in every 16-bit and
+// split-pair case — bf16 B = 1 (1568 rows in layer3) 1.86 -> 1.54 ms, B = 8 2.65 -> 2.43 ms; split pairs B = 1 3.35 -> 2.51 ms, B = 2
+// 3.56 -> 2.83, B = 4 4.02 -> 3.36, B = 8 5.18 -> 4.62 ms — and fp32 does not care (7.1 / 8.3 / 11.0 / 17.6 ms either way).
+static long long ws_min_rows(size_t /*elem_bytes*/) { return g_ws_min_rows > 0 ? g_ws_min_rows : 1024; }
 
 // every K tile inside one tap (see the UNI comment at the 2-stage kernel)
 static bool conv_uniform_taps(const ConvDesc& d, int bk) {
@@ -1908,6 +1909,15 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     }
 #endif
     if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) {
+      // Small launches (B = 1 .. 8): the 256 x 128 / 128 x 256 tiles leave most CUs idle (layer3 at B = 1: 13 tiles), and every tile walks
+      // the whole K range.  The 64-channel x 256-pixel shape of the same kernel makes 2-4x as many tiles of a quarter / half of the work;
+      // taken while even those fit one round of the persistent grid (debug flag 16777216: never).
+      if (!(g_debug_flags & (1 << 24)) && d.Cout % 64 == 0 && d.M < (1ll << 31)) {
+        int n_cu = 0;
+        if (int rc = persistent_grid_cus(&n_cu)) return rc;
+        const long long slim_tiles = ((d.M + 255) / 256) * (d.Cout / 64);
+        if (slim_tiles <= n_cu) return launch_ws<T, false, false, true>(d, s);
+      }
       if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) {
 #ifdef RGBM_EXPERIMENTS
         if constexpr (sizeof(T) == 2) {
