@@ -507,6 +507,29 @@ def main():
         del du
         torch.cuda.empty_cache()
 
+    # ---- two batches in flight: consecutive steps of a serving loop on two HIP streams, each with its own network instance and
+    # workspace (the kernels of one fill the launch tails and quantisation gaps of the other; N = 1 information, not `value`) ----
+    two_res = None
+    if rank == 0 and world == 1 and not args.no_dense_leg:
+        nets2 = [net, AdaPoseNet(sd0, dtype=args.dtype, device=local_rank, max_chunk_views=args.chunk or None)]
+        st2 = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+
+        def pair():
+            for i in range(2):
+                with torch.cuda.stream(st2[i]):
+                    o = nets2[i](d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"], stream=st2[i])
+                    postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"], stream=st2[i])
+        torch.cuda.synchronize()
+        for s_ in st2:
+            s_.wait_stream(torch.cuda.current_stream(device))
+        t2 = time_steps(pair, 1, max(2, args.steps // 2)) / 2
+        torch.cuda.current_stream(device).wait_stream(st2[0])
+        torch.cuda.current_stream(device).wait_stream(st2[1])
+        two_res = {"poses_per_sec": round(B / t2, 1), "ms_per_step": round(t2 * 1e3, 2),
+                   "note": "two steps in flight on two HIP streams (two network instances, two workspaces); `value` is the one-stream figure"}
+        del nets2
+        torch.cuda.empty_cache()
+
     _mark("accuracy / modes / dense legs done")
     # ---- plugin boundary (the full estimate()-equivalent incl. H2D): AdaPoseEstimator_v5.estimate with numpy frames ----
     boundary_res = None
@@ -797,6 +820,9 @@ def main():
                 "note": "exact: outputs are bit-identical to the dense computation (tests/test_gpu_at_batch.py, poisoned workspace); data "
                         "dependent: `value` is on masks that span their crops like the reference's, value_worst_case needs every tile, "
                         "value_survey_masks is SURVEY 8d's ellipses of 5-50 % of the crop"}
+        if two_res is not None:
+            res["value_two_streams"] = two_res["poses_per_sec"]
+            res["two_streams"] = two_res
         if per_rank is not None:
             res["per_rank"] = per_rank
         # whole-net HBM rate: measured bytes per step (PMC, every kernel of one forward) against the algorithmic minimum of

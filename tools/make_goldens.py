@@ -569,7 +569,55 @@ def gen_align(out_dir):
     print("align golden:", {k: np.asarray(v).shape for k, v in save.items()})
 
 
+def gen_cv2(out_dir):
+    """The OpenCV pin (round-3 verdict): wherever `import cv2` works, record what the reference's three OpenCV call sites return on
+    seeded inputs — `cv2.resize` INTER_NEAREST / INTER_LINEAR of crop windows (interface_v5.py:91-94, 136-139) and
+    `cv2.triangulatePoints`, `cv2.solvePnPRansac(flags=SOLVEPNP_EPNP)`, `cv2.solvePnPRefineVVS` on the cases of
+    rgbmanip_amd.synth.pnp_case (lib/utils.py:121-195, lib/align.py:104-115) — into tests/golden/cv2_pin.npz.  The build image has
+    no OpenCV (SURVEY 8c), so there this target prints why it did nothing; tests/test_oracle_golden.py::test_cv2_pin compares the
+    restatements (oracle/postproc_ref.py resize_*, oracle/pnp_ref.py) with the file whenever it exists."""
+    try:
+        import importlib
+        sys.modules.pop("cv2", None)                       # the name stub of install_stubs() is not OpenCV
+        cv2 = importlib.import_module("cv2")
+        if not hasattr(cv2, "solvePnPRansac"):
+            raise ImportError("cv2 is the import stub")
+    except ImportError as e:
+        print(f"cv2 golden: OpenCV is not importable here ({e}); nothing written.  Run `python tools/make_goldens.py cv2` in an "
+              f"environment with opencv-python and commit tests/golden/cv2_pin.npz")
+        return
+    from rgbmanip_amd import synth
+    save = {"cv2_version": np.array(cv2.__version__)}
+    rng = np.random.default_rng(4242)
+    for i, win in enumerate((200, 240, 280, 440)):
+        img = rng.random((win, win, 3)).astype(np.float32)
+        msk = (rng.random((win, win)) < 0.3).astype(np.float32)
+        save[f"r{i}_img"], save[f"r{i}_mask"] = img, msk
+        save[f"r{i}_linear"] = cv2.resize(img, (224, 224), interpolation=cv2.INTER_LINEAR)
+        save[f"r{i}_nearest"] = cv2.resize(msk, (224, 224), interpolation=cv2.INTER_NEAREST)
+    for case in range(5):
+        c = synth.pnp_case(case)
+        P1, P2 = c["K"] @ c["E1"][:3], c["K"] @ c["E2"][:3]
+        X = cv2.triangulatePoints(P1, P2, c["pts1"][:64].T.astype(np.float64), c["pts2"][:64].T.astype(np.float64))
+        save[f"p{case}_tri"] = X
+        pw = (c["nocs1"].astype(np.float64) * c["scale"])
+        cv2.setRNGSeed(100 + case)
+        ok, rvec, tvec, inl = cv2.solvePnPRansac(pw, c["pts1"].astype(np.float64), c["K"], None, flags=cv2.SOLVEPNP_EPNP)
+        save[f"p{case}_ok"] = np.array(bool(ok))
+        if ok:
+            rv, tv = cv2.solvePnPRefineVVS(pw[inl[:, 0]], c["pts1"].astype(np.float64)[inl[:, 0]], c["K"], None, rvec, tvec)
+            save[f"p{case}_rvec"], save[f"p{case}_tvec"], save[f"p{case}_inliers"] = rvec, tvec, inl[:, 0]
+            save[f"p{case}_rvec_vvs"], save[f"p{case}_tvec_vvs"] = rv, tv
+    np.savez_compressed(os.path.join(out_dir, "cv2_pin.npz"), **save)
+    print("cv2 golden:", cv2.__version__, {k: np.asarray(v).shape for k, v in save.items() if k != "cv2_version"})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["cv2"]:                 # needs OpenCV, not the reference: no import stubs
+        out_dir = os.path.join(ROOT, "tests", "golden")
+        os.makedirs(out_dir, exist_ok=True)
+        gen_cv2(out_dir)
+        sys.exit(0)
     install_stubs()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
