@@ -570,10 +570,7 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   const size_t VP = (size_t)V * P;
 
   // ---- stage inputs: views = [view1 batch ; view2 batch] ----
-  RGBM_CHECK_HIP(hipMemcpyAsync(bf.Pviews, P1, (size_t)B * 64, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(bf.Pviews + (size_t)B * 16, P2, (size_t)B * 64, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose, choose1, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(bf.choose + (size_t)B * P, choose2, (size_t)B * P * 4, hipMemcpyDeviceToDevice, s));
+  if (int rc = launch_stage_in(P1, P2, choose1, choose2, bf.Pviews, bf.choose, B, P, s)) return rc;
   if (int rc = pspnet(bf, V, img1, img2, s)) return rc;
   if (int rc = launch_homography(bf.Pviews, bf.homog, V, B, s)) return rc;
   // bf16x3 nets: everything that GATHERS from the feature map (plane sweep, point heads) reads a plain fp32 copy of it
@@ -621,33 +618,18 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, Vh, P, 256, s)) return rc;
   float* hout[3] = {bf.r6, bf.tv, bf.sv};
   const int hdim[3] = {6, 3, 3};
-  for (int h = 0; h < 3; ++h) {
-    if (int rc = launch_view_linear(bf.pf2, head_w[h][0], head_b[h][0], bf.h1, Vh, 256, 256, 256, 0, 1, s)) return rc;
-    if (int rc = launch_view_linear(bf.h1, head_w[h][1], head_b[h][1], bf.h2, Vh, 256, 128, 256, 0, 1, s)) return rc;
-    if (int rc = launch_view_linear(bf.h2, head_w[h][2], head_b[h][2], hout[h], Vh, 128, hdim[h], 128, 0, 0, s)) return rc;
-  }
+  if (int rc = launch_pose_heads(bf.pf2, head_w, head_b, hout, hdim, Vh, s)) return rc;
   if (int rc = launch_ortho6d(bf.r6, bf.R, Vh, s)) return rc;
 
-  // ---- outputs (fp32, reference shapes) ----
-  const size_t BP = (size_t)B * P;
-  if (int rc = launch_copy_cols(bf.nocs4, out.nocs1, (long long)BP, 4, 3, 3, s)) return rc;
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.depth1, bf.depth, BP * 4, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.r1, bf.R, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.t1, bf.tv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-  RGBM_CHECK_HIP(hipMemcpyAsync(out.s1, bf.sv, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-  if (view2_heads) {
-    if (int rc = launch_copy_cols(bf.nocs4 + BP * 4, out.nocs2, (long long)BP, 4, 3, 3, s)) return rc;
-    RGBM_CHECK_HIP(hipMemcpyAsync(out.depth2, bf.depth + BP, BP * 4, hipMemcpyDeviceToDevice, s));
-    RGBM_CHECK_HIP(hipMemcpyAsync(out.r2, bf.R + (size_t)B * 9, (size_t)B * 36, hipMemcpyDeviceToDevice, s));
-    RGBM_CHECK_HIP(hipMemcpyAsync(out.t2, bf.tv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-    RGBM_CHECK_HIP(hipMemcpyAsync(out.s2, bf.sv + (size_t)B * 3, (size_t)B * 12, hipMemcpyDeviceToDevice, s));
-  } else {
-    // not computed: every byte 0xFF = NaN, so that a consumer of a view-2 output fails loudly instead of reading stale numbers
-    RGBM_CHECK_HIP(hipMemsetAsync(out.nocs2, 0xFF, BP * 12, s));
-    RGBM_CHECK_HIP(hipMemsetAsync(out.depth2, 0xFF, BP * 4, s));
-    RGBM_CHECK_HIP(hipMemsetAsync(out.r2, 0xFF, (size_t)B * 36, s));
-    RGBM_CHECK_HIP(hipMemsetAsync(out.t2, 0xFF, (size_t)B * 12, s));
-    RGBM_CHECK_HIP(hipMemsetAsync(out.s2, 0xFF, (size_t)B * 12, s));
+  // ---- outputs (fp32, reference shapes); view2_heads = 0: the view-2 outputs are filled with NaN, so that a consumer of one fails
+  // loudly instead of reading stale numbers ----
+  {
+    float* const on[2] = {out.nocs1, out.nocs2};
+    float* const od[2] = {out.depth1, out.depth2};
+    float* const orr[2] = {out.r1, out.r2};
+    float* const ot[2] = {out.t1, out.t2};
+    float* const os[2] = {out.s1, out.s2};
+    if (int rc = launch_stage_out(bf.nocs4, bf.depth, bf.R, bf.tv, bf.sv, on, od, orr, ot, os, B, P, view2_heads, s)) return rc;
   }
   (void)VP;
   return 0;

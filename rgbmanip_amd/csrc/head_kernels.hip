@@ -326,6 +326,122 @@ int launch_view_linear(const float* x, const float* W, const float* bias, float*
   return 0;
 }
 
+// ---------------------------------------------------------------- the three regression heads in one launch
+// rotation / translation / size estimators (network_v5.py:485-494): Linear(256,256) ReLU Linear(256,128) ReLU Linear(128,6|3|3) on the
+// pooled pose feature of a view.  One workgroup per (view, head); every output is the same sequential fma chain view_linear_kernel
+// runs (bit-identical), the hidden vectors stay in LDS: one launch instead of nine (8 % of a B = 1 forward were launch latencies
+// of these and of the staging copies below).
+struct PoseHeadsDesc {
+  const float* w[3][3];
+  const float* b[3][3];
+  float* out[3];
+  int odim[3];
+};
+
+__global__ __launch_bounds__(256) void pose_heads_kernel(const float* __restrict__ pf2, const PoseHeadsDesc d) {
+  __shared__ float x0[256], x1[256], x2[128];
+  const int v = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+  x0[t] = pf2[(long long)v * 256 + t];
+  __syncthreads();
+  {
+    float acc = d.b[h][0][t];
+    const float* wr = d.w[h][0] + (long long)t * 256;
+    for (int i = 0; i < 256; ++i) acc = fmaf(wr[i], x0[i], acc);
+    x1[t] = acc < 0.f ? 0.f : acc;               // NaN propagates, like torch.relu
+  }
+  __syncthreads();
+  if (t < 128) {
+    float acc = d.b[h][1][t];
+    const float* wr = d.w[h][1] + (long long)t * 256;
+    for (int i = 0; i < 256; ++i) acc = fmaf(wr[i], x1[i], acc);
+    x2[t] = acc < 0.f ? 0.f : acc;
+  }
+  __syncthreads();
+  if (t < d.odim[h]) {
+    float acc = d.b[h][2][t];
+    const float* wr = d.w[h][2] + (long long)t * 128;
+    for (int i = 0; i < 128; ++i) acc = fmaf(wr[i], x2[i], acc);
+    d.out[h][(long long)v * d.odim[h] + t] = acc;
+  }
+}
+
+int launch_pose_heads(const float* pf2, float* const w[3][3], float* const b[3][3], float* const out[3], const int odim[3], int V,
+                      hipStream_t s) {
+  PoseHeadsDesc d;
+  for (int h = 0; h < 3; ++h) {
+    for (int l = 0; l < 3; ++l) { d.w[h][l] = w[h][l]; d.b[h][l] = b[h][l]; }
+    d.out[h] = out[h];
+    d.odim[h] = odim[h];
+  }
+  hipLaunchKernelGGL(pose_heads_kernel, dim3(V, 3), dim3(256), 0, s, pf2, d);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- input / output staging of a forward in one launch each
+// (were 4 + 10 device-to-device copies of a few KB: per-launch latency is what a small-batch forward consists of)
+__global__ void stage_in_kernel(const float* __restrict__ P1, const float* __restrict__ P2, const int* __restrict__ c1,
+                                const int* __restrict__ c2, float* __restrict__ Pviews, int* __restrict__ choose, int B, int P) {
+  const long long nP = (long long)B * 16, nC = (long long)B * P;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 2 * (nP + nC); i += (long long)gridDim.x * blockDim.x) {
+    if (i < nP) Pviews[i] = P1[i];
+    else if (i < 2 * nP) Pviews[i] = P2[i - nP];
+    else if (i < 2 * nP + nC) choose[i - 2 * nP] = c1[i - 2 * nP];
+    else choose[i - 2 * nP] = c2[i - 2 * nP - nC];
+  }
+}
+
+int launch_stage_in(const float* P1, const float* P2, const int* c1, const int* c2, float* Pviews, int* choose, int B, int P, hipStream_t s) {
+  const long long n = 2ll * B * (16 + P);
+  hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, P1, P2, c1, c2, Pviews, choose, B, P);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+struct StageOutDesc {
+  const float *nocs4, *depth, *R, *tv, *sv;      // [V*P][4], [V*P], [V][9], [V][3], [V][3]; views = [view-1 batch ; view-2 batch]
+  float *nocs[2], *dep[2], *r[2], *t[2], *s[2];  // reference shapes: [B,P,3], [B,P], [B,3,3], [B,3], [B,3]
+  int B, P, view2;                               // view2 = 0: the view-2 outputs were not computed and are filled with NaN
+};
+
+__global__ void stage_out_kernel(const StageOutDesc d) {
+  const long long BP = (long long)d.B * d.P;
+  const long long n_nocs = BP * 3, n_small = (long long)d.B * 15, per_side = n_nocs + BP + n_small;
+  const float qnan = __uint_as_float(0xffffffffu);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 2 * per_side; i += (long long)gridDim.x * blockDim.x) {
+    const int side = i >= per_side;
+    long long j = i - side * per_side;
+    const bool have = side == 0 || d.view2;
+    if (j < n_nocs) {
+      const long long pt = j / 3;
+      const int c = (int)(j - pt * 3);
+      d.nocs[side][j] = have ? d.nocs4[(side * BP + pt) * 4 + c] : qnan;
+    } else if ((j -= n_nocs) < BP) {
+      d.dep[side][j] = have ? d.depth[side * BP + j] : qnan;
+    } else {
+      j -= BP;
+      const long long b = j / 15;
+      const int e = (int)(j - b * 15);
+      const long long v = (long long)side * d.B + b;
+      if (e < 9) d.r[side][b * 9 + e] = have ? d.R[v * 9 + e] : qnan;
+      else if (e < 12) d.t[side][b * 3 + (e - 9)] = have ? d.tv[v * 3 + (e - 9)] : qnan;
+      else d.s[side][b * 3 + (e - 12)] = have ? d.sv[v * 3 + (e - 12)] : qnan;
+    }
+  }
+}
+
+int launch_stage_out(const float* nocs4, const float* depth, const float* R, const float* tv, const float* sv, float* const nocs[2],
+                     float* const dep[2], float* const r[2], float* const t[2], float* const sz[2], int B, int P, int view2, hipStream_t s) {
+  StageOutDesc d;
+  d.nocs4 = nocs4; d.depth = depth; d.R = R; d.tv = tv; d.sv = sv;
+  for (int k = 0; k < 2; ++k) { d.nocs[k] = nocs[k]; d.dep[k] = dep[k]; d.r[k] = r[k]; d.t[k] = t[k]; d.s[k] = sz[k]; }
+  d.B = B; d.P = P; d.view2 = view2;
+  const long long n = 2ll * ((long long)B * P * 4 + (long long)B * 15);
+  hipLaunchKernelGGL(stage_out_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, d);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- Ortho6d -> rotation matrix (rotation_utils.py:18-27)
 __global__ void ortho6d_kernel(const float* __restrict__ r6, float* __restrict__ R, int V) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -51,6 +51,13 @@ int launch_f32_to_bx3(const float* in, void* out, long long n, hipStream_t s);  
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
+// the three regression heads (3 x Linear + ReLU each) of every view in one launch; out[h] is [V][odim[h]]
+int launch_pose_heads(const float* pf2, float* const w[3][3], float* const b[3][3], float* const out[3], const int odim[3], int V,
+                      hipStream_t s);
+// input / output staging of AdaPose::forward in one launch each
+int launch_stage_in(const float* P1, const float* P2, const int* c1, const int* c2, float* Pviews, int* choose, int B, int P, hipStream_t s);
+int launch_stage_out(const float* nocs4, const float* depth, const float* R, const float* tv, const float* sv, float* const nocs[2],
+                     float* const dep[2], float* const r[2], float* const t[2], float* const sz[2], int B, int P, int view2, hipStream_t s);
 int launch_copy_cols(const float* in, float* out, long long rows, int ldi, int ldo, int n, hipStream_t s);
 
 // conv3d_tile.hip — halo-tiled 3-D conv for the cost-regularisation stack
