@@ -589,7 +589,7 @@ def main():
                     "(interface_v5.py:213-227 as rl_pose.py:210-218 calls it)", "poses": B, "dtype": args.dtype,
             "frames": f"[{B},480,640,3] float64 + [{B},480,640] float64 masks per view, {gb:.2f} GB of host arrays per call",
             "device_prepare": {"poses_per_sec": round(B / e_s, 1), "ms_per_call": round(e_s * 1e3, 1),
-                               "pipeline": "chunks of 64 poses: host threads stage chunk c+1 into pinned memory | copy engine moves chunk c | kernels run chunk c-1",
+                               "pipeline": "chunks of 32 poses: host threads stage chunk c+1 into pinned memory | copy engine moves chunk c | kernels run chunk c-1",
                                "unpipelined_ms_per_call": round(e1_s * 1e3, 1), "unpipelined_poses_per_sec": round(B / e1_s, 1),
                                "pipelined_equals_unpipelined": bool(np.allclose(bb, bb1, rtol=2e-2, atol=1e-3)),
                                "upload_alone_ms": round(up_s * 1e3, 1), "upload_alone_host_GBps": round(gb / up_s, 1),

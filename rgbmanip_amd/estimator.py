@@ -239,12 +239,13 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
 
     def _estimate_host_frames(self, K, rgb1, mask1, E1, rgb2, mask2, E2):
         """`estimate` with `hip_prepare: device` for host arrays (what rl_pose.py:210-218 hands over: [N,480,640,3] float64 frames,
-        3.8 GB per call at N = 256).  Batches larger than `hip_upload_chunk` poses (default 64) run as a three-stage pipeline over
+        3.8 GB per call at N = 256).  Batches larger than `hip_upload_chunk` poses (default 32: measured best of 8 .. 128 for float64 and
+        float32 frames in bf16 and bf16x3, tools/boundary_chunks.py; 1 GB of pinned staging for float64 frames) run as a three-stage pipeline over
         chunks of poses: host threads copy chunk c + 1 into pinned staging buffers while the copy engine moves chunk c to the device
         on its own stream and the kernels (dtype conversion, crop / resize / subset, network, post-processing) work on chunk c - 1.
         Every pose's box equals the unchunked call's (poses are independent; a chunk is a smaller batch of the same kernels)."""
         n = len(rgb1)
-        chunk = int(self.cfg.get("hip_upload_chunk", 64))
+        chunk = int(self.cfg.get("hip_upload_chunk", 32))
         on_dev = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (rgb1, rgb2))
         if on_dev or n <= chunk or chunk <= 0:
             return self.estimate_device(np.asarray(K), self._upload_frames(rgb1), self._upload_masks(mask1), np.asarray(E1),
