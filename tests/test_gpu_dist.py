@@ -143,3 +143,39 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     assert abs(line["ms_per_step"] - pr["ms_per_step_max"]) / line["ms_per_step"] < 0.25      # `value` is priced on the slowest rank
     assert pr["sweep_tiles_needed_frac"][0] != pr["sweep_tiles_needed_frac"][1]               # rank-local inputs (seeded by rank)
     assert len(line["ppo"]["per_rank"]["collection_s"]) == 2 and line["ppo"]["env_steps_per_sec_all_ranks"] > 0
+
+
+def test_bench_single_process_line_has_every_leg():
+    """`python bench.py` as the driver runs it at N = 1, shrunk (batch 16, 1 step): every leg of the line must come back — a crash in
+    one of them at round end would lose the whole bench record.  Checks the keys the round-3 verdict asked for (dense / worst-case /
+    survey legs promoted to top level, the renamed algorithmic figure, plugin boundary, small batches) and basic sanity of each."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--batch", "16", "--steps", "1", "--warmup", "1", "--ppo-envs", "16", "--ppo-iters", "1",
+           "--mode-steps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["metric"] == "adapose_poses_per_sec_batch256" and line["n_gpus"] == 1 and line["value"] > 0 and line["dtype"] == "bf16"
+    assert line["config"]["inputs"] == "crop" and 0.0 < line["sweep_tiles_needed_frac"] <= 1.0
+    for k in ("value_dense", "value_worst_case", "value_survey_masks", "value_two_streams", "mfma_frac_executed_flops_dense",
+              "algorithmic_tflops_over_peak", "value_plugin_boundary", "value_within_tolerance"):
+        assert line[k] is not None and line[k] > 0, k
+    assert "whole_net_frac_of_mfma_peak" not in line                                  # renamed: a speed figure, not a utilisation
+    rl = line["roofline"]
+    assert rl["bound"] == "mfma" and rl["peak"] == 2500.0 and 0 < rl["frac"] < 1 and "traffic" in rl
+    assert not any(k["kernel"] == "unused" for k in line["conv_kernels"])
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    ab = line["accuracy"]["at_batch"]
+    assert ab["workspace_poisoned"] and ab["poisoned_run_bit_identical_to_timed_step"] is True
+    pb = line["plugin_boundary"]["device_prepare"]
+    assert pb["pipelined_equals_unpipelined"] and pb["view1_only_boxes_bit_identical_to_full_forward"] and line["plugin_boundary"]["finite"]
+    sm = line["small_batch"]["entries"]
+    assert {(e["dtype"], e["batch"]) for e in sm} == {("bf16", 1), ("bf16", 8), ("bf16x3", 1), ("bf16x3", 8)}
+    assert all(e["eager_ms"] > 0 and e["graph_ms"] > 0 and e["graph_nodes"] > 50 for e in sm)
+    assert line["modes"]["bf16x3"]["accuracy"]["at_batch"]["meets_1e-4"] and line["dtype_within_tolerance"] == "bf16x3"
+    assert line["ppo"]["env_steps_per_sec"] > 0 and line["ppo"]["estimator_view2_heads"] is False
+    assert line["mixed_object"]["poses_per_sec"] > 0 and line["prepare_model_input"]["valid_frames"] > 0
