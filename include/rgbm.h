@@ -367,7 +367,9 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
  *                                                                                  (default since round 3: channel block outer, taps inner)
  * 2097152  bf16 plane sweep: blend on scalar fp32 FMAs                    4194304  ... on packed fp32 (rounds 1-3; default: v_perm + v_dot2_f32_bf16)
- * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches */
+ * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches
+ * 33554432 post-processing: generic fp64 radix selection of the median only (the fall-back of the default selection on fp32
+ *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose */
 int rgbm_debug_flags(int flags);
 /* dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
  * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = 1024 (measured at

@@ -362,6 +362,68 @@ def test_postprocess_split_form_is_bit_identical_to_one_kernel_form(golden_dir, 
     assert split[2].sum() >= B // 2                         # most cases are regular poses
 
 
+def _pp_cases(golden_dir, B, seed):
+    """Post-processing inputs: the golden cases (incl. the empty-valid and NaN ones) cycled to the batch; beyond the first cycle
+    perturbed copies, and every third of those replaced by a near-perfect pose (camera points = s R nocs + t projected to integer
+    pixels: ratios concentrated within a few per cent of s, the shape trained weights give)."""
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    n = int(g["n_cases"])
+    rng = np.random.default_rng(seed)
+    idx = [i % n for i in range(B)]
+    nocs = np.stack([g[f"c{i}_in_nocs"] for i in idx]).astype(np.float32)
+    depth = np.stack([g[f"c{i}_in_depth"] for i in idx]).astype(np.float32)
+    choose = np.stack([g[f"c{i}_in_choose"] for i in idx]).copy()
+    K = np.stack([g[f"c{i}_in_K"] for i in idx])
+    img = 224
+    for b in range(n, B):
+        if not np.isfinite(nocs[b]).all():
+            continue
+        if b % 3 == 0:
+            P = nocs.shape[1]
+            s = rng.uniform(0.15, 0.9)
+            q = rng.normal(size=(3, 3)); Rm, _ = np.linalg.qr(q)
+            pts = rng.uniform(-0.45, 0.45, (P, 3))
+            cam = s * pts @ Rm.T + np.array([0.0, 0.0, rng.uniform(0.6, 1.2)])
+            u = np.clip(np.round(cam[:, 0] / cam[:, 2] * K[b][0, 0] + K[b][0, 2]), 0, img - 1)
+            v = np.clip(np.round(cam[:, 1] / cam[:, 2] * K[b][1, 1] + K[b][1, 2]), 0, img - 1)
+            choose[b] = (v * img + u).astype(choose.dtype)
+            nocs[b] = (pts + rng.normal(0, [0.0, 1e-3, 1e-2][(b // 3) % 3], pts.shape)).astype(np.float32)
+            depth[b] = cam[:, 2].astype(np.float32)
+            if (b // 3) % 4 == 1:                           # an odd number of valid pairs: knock one point out of the 0.3 m range
+                depth[b, 0] = 5.0
+        else:
+            nocs[b] = np.clip(nocs[b] + rng.normal(0, 0.02, nocs[b].shape).astype(np.float32), -0.5, 0.5)
+            depth[b] = depth[b] * np.float32(rng.uniform(0.8, 1.2)) + rng.normal(0, 1e-3, depth[b].shape).astype(np.float32)
+    return (torch.from_numpy(nocs).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(np.stack([g[f"c{i}_in_R"] for i in idx])).cuda(),
+            choose, K, np.stack([g[f"c{i}_in_E"] for i in idx]))
+
+
+def _pp_bits(outs):
+    return [x.view(np.int64) if x.dtype == np.float64 else x for x in outs]
+
+
+@pytest.mark.parametrize("B", [8, 64, 256])
+def test_postprocess_fast_selection_is_bit_identical_to_generic(golden_dir, B):
+    """The default median selection works on fp32 approximations of the pair ratios and evaluates fp64 ratios only next to the
+    median (postproc.hip); debug flag 33554432 runs the generic fp64 radix selection it falls back to, 67108864 forces the guard
+    band (the rare lower-middle-outside-the-bucket case) in every even-count pose.  Same 64-bit medians, boxes and validity in all
+    three, in the one-kernel and (B = 8) the split form, on golden, perturbed and concentrated-ratio poses."""
+    from rgbmanip_amd.adapose import postprocess
+    lib = _lib.load()
+    args = _pp_cases(golden_dir, B, 100 + B)
+    outs = {}
+    try:
+        for name, flags in (("fast", 0), ("generic", 1 << 25), ("guard", 1 << 26), ("fast_one_kernel", 1 << 23), ("guard_one_kernel", (1 << 26) | (1 << 23))):
+            _lib.check(lib.rgbm_debug_flags(flags))
+            outs[name] = _pp_bits([x.cpu().numpy() for x in postprocess(*args)])
+    finally:
+        _lib.check(lib.rgbm_debug_flags(0))
+    for name in outs:
+        for a, b, nm in zip(outs[name], outs["generic"], ("bbox", "ts", "valid")):
+            np.testing.assert_array_equal(a, b, err_msg=f"{name}: {nm}")
+    assert outs["fast"][2].sum() >= B // 2
+
+
 C3T = {0: (32, 8, 1, False), 1: (8, 16, 2, False), 2: (16, 16, 1, False), 3: (16, 32, 2, False), 4: (32, 32, 1, False),
        5: (32, 64, 2, False), 6: (64, 64, 1, False), 7: (64, 32, 2, True), 8: (32, 16, 2, True), 9: (16, 8, 2, True)}
 

@@ -1,4 +1,5 @@
 """CPU: host-side logic of the plugin layer (no GPU, no HIP calls)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -199,3 +200,19 @@ def test_postprocess_split_planning_and_tuning_keys():
     assert sizes[1] > 0 and sizes[8] == 8 * sizes[1] and sizes[128] == 128 * sizes[1] and sizes[129] == 0 and sizes[256] == 0
     assert lib.rgbm_set_tuning(b"ws_min_rows", 4096) == 0 and lib.rgbm_set_tuning(b"ws_min_rows", 0) == 0
     assert lib.rgbm_set_tuning(b"no_such_key", 1) != 0 and b"unknown tuning key" in lib.rgbm_last_error()
+
+
+def test_postprocess_squared_nocs_threshold_is_equivalent():
+    """postproc.hip decides the reference's `nocs_dist > 0.01` (fp32, lib/utils.py:92-96) on the SQUARED fp32 sum: sqrtf is correctly
+    rounded and monotone, so sqrtf(s) > 0.01f <=> s > PP_ND2 with PP_ND2 the largest float whose root rounds to 0.01f or less.
+    Checked over +-4096 ulps around the constant (double sqrt rounded to float is the correctly rounded float sqrt)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rgbmanip_amd", "csrc", "postproc.hip")).read()
+    m = re.search(r"constexpr float PP_ND2 = (0x[0-9a-fA-F.]+p[-+]?\d+)f;", src)
+    assert m, "PP_ND2 not found"
+    nd2 = np.float32(float.fromhex(m.group(1)))
+    assert float(nd2) == float.fromhex(m.group(1))                # representable
+    bits = np.arange(int(nd2.view(np.uint32)) - 4096, int(nd2.view(np.uint32)) + 4097, dtype=np.int64).astype(np.uint32)
+    s = bits.view(np.float32)
+    root = np.sqrt(s.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(root > np.float32(0.01), s > nd2)
