@@ -7,6 +7,8 @@ Pinned by tests/test_oracle_golden.py against tests/golden/control.npz, which to
 the reference class itself on the seeded view stream of rgbmanip_amd.synth.control_view.
 The camera frame size is the reference's CAMERA_INTRINSIC[-1], [-2] = 480, 640.
 """
+import os
+
 import numpy as np
 
 H_IMG, W_IMG = 480, 640
@@ -179,7 +181,28 @@ class ControlInterfaceRef(ControlQueueRef):
         self.proper_pos = np.asarray([[0.0, 0.0, 0.9]])
         self.proper_ori = np.asarray([[1.0, 0.0, -0.2]])
         self.last_done = np.zeros((self.num_envs,))
+        self.obj_saved_num = {}                              # rl_pose.py:49-52
+        self.save_path = "saves/third_stage"
         self.reset_robot()
+
+    def _save_data(self):                                    # rl_pose.py:56-83
+        """Eval-time dataset export.  As in the reference the per-env view indices select a STEP slot of the queues, so every
+        file holds that slot's arrays of ALL envs, and the ground truth is the queue's last slot (not yet written at the step
+        that exports: zeros)."""
+        current_obj_config = self.env.get_attr("current_obj_config")
+        first = np.clip(self.available_num - 1, 0, None)
+        second = np.clip(self.available_num - 2, 0, None)
+        for e, obj_config in enumerate(current_obj_config):
+            obj = obj_config["name"]
+            self.obj_saved_num[obj] = self.obj_saved_num.get(obj, 0) + 1
+            root = os.path.join(self.save_path, obj, str(self.obj_saved_num[obj]))
+            os.makedirs(root, exist_ok=True)
+            id1, id2 = first[e], second[e]
+            for name, arr in (("camera_intrinsic", self.intrinsic_queue[id1]), ("rgb1", self.image_queue[id1].astype(np.float64)),
+                              ("rgb2", self.image_queue[id2].astype(np.float64)), ("view1_mask", self.mask_queue[id1]),
+                              ("view2_mask", self.mask_queue[id2]), ("view1_extrinsic", self.extrinsic_queue[id1]),
+                              ("view2_extrinsic", self.extrinsic_queue[id2]), ("ground_truth", self.gt_bbox[-1])):
+                np.savez_compressed(os.path.join(root, name + ".npy"), arr)      # numpy appends ".npz": "<name>.npy.npz", key arr_0
 
     def reset_robot(self):                                   # rl_pose.py:99-116
         pos = np.array([self.pose_min[0], 0.0, (self.pose_min[2] + self.pose_max[2]) / 2])
@@ -293,6 +316,8 @@ class ControlInterfaceRef(ControlQueueRef):
             success = self.env.get_observation(gt=True)["success"][:, 0]
         reward, info = self.get_reward(action, move_res, weight, success)
         self.accumulate_steps += 1
+        if self.accumulate_steps == self.max_steps - 1 and eval:      # rl_pose.py:446-447
+            self._save_data()
         done = self.get_done()
         self.last_done = done
         return obs, reward, done, info

@@ -17,13 +17,17 @@ Reference quirks that change values are reproduced and tested against goldens re
 `quat_to_axis` scrambles its batch (utils/transform.py:234), `LOSS:far` reports the scaled far term (:247, :322).  Two
 things differ on purpose: the target quaternion's sign is canonical (first non-zero component positive) where the reference
 inherits LAPACK's eigenvector sign, and `available` keeps 0/1 where the reference scales the current slot by
-`have_bbox_coef` in place (:253, :327; only its truth value is ever read).  `_save_data` (eval-time dataset export, :56-83)
-is not provided.  The vec-env may return numpy arrays (the reference's `MultiVecEnv`) or CUDA tensors
+`have_bbox_coef` in place (:253, :327; only its truth value is ever read).  `_save_data` (eval-time dataset export, :56-83,
+run by `step(eval=True)` at the last-but-one step of an episode, :446-447) writes the reference's files — same paths, array
+shapes and dtypes, the 0/1 mask the queue keeps in place of the raw mask values (tests/golden/control_save.npz).
+`action_type: joint` is refused: in the reference it cannot be constructed either (`pose_min` / `pose_max` exist only for
+"pose", :29-32, and `reset_robot`, called from `__init__`, reads them unconditionally, :108-110).  The vec-env may return numpy arrays (the reference's `MultiVecEnv`) or CUDA tensors
 (`rgbmanip_amd.synthetic_env.SyntheticMultiVecEnv`).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -53,8 +57,11 @@ class ControlInterface:
         self.num_envs = int(vec_env.num_envs)
         self.max_steps = int(cfg["controller"]["max_steps"]) + 1
         self.action_type = cfg["controller"]["action_type"]
-        if self.action_type != "pose":               # "joint" drives the simulator's joint controller 1024 steps (:421-429)
-            raise NotImplementedError("action_type 'joint' needs the simulator; only 'pose' is provided")
+        if self.action_type != "pose":
+            # "joint" (:242, :296, :421-429) is dead code in the reference: its __init__ -> reset_robot reads pose_min / pose_max,
+            # which only "pose" sets (:29-32, :108-110), so the class raises AttributeError before the first step
+            raise NotImplementedError("action_type 'joint': the reference's ControlInterface cannot be constructed with it "
+                                      "(rl_pose.py:29-32,108-110); only 'pose' is provided")
         self.pose_min = np.asarray(cfg["controller"]["pose_min"], dtype=np.float64)
         self.pose_max = np.asarray(cfg["controller"]["pose_max"], dtype=np.float64)
         self.pose_mid = (self.pose_min + self.pose_max) / 2
@@ -67,6 +74,8 @@ class ControlInterface:
         self.proper_ori = np.asarray([[1.0, 0.0, -0.2]])
         self.last_done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._last_done_any = False                  # done is uniform over envs (:360-362), so the host knows it
+        self.obj_saved_num = {}                      # :49-52
+        self.save_path = "saves/third_stage"         # created by the first export (the reference creates it here, empty)
         self.reset_queue()
         self.reset_robot()
 
@@ -85,6 +94,35 @@ class ControlInterface:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.H, self.W = CAMERA_INTRINSIC[-1], CAMERA_INTRINSIC[-2]
         self.lib = _lib.load()
+
+    # ------------------------------------------------------------------ rl_pose.py:56-83
+    def _save_data(self):
+        """Eval-time dataset export (rl_pose.py:56-83): per env one directory `<save_path>/<object name>/<count>/` with
+        `camera_intrinsic / rgb1 / rgb2 / view1_mask / view2_mask / view1_extrinsic / view2_extrinsic / ground_truth` as
+        `<name>.npy.npz` (`np.savez_compressed`, key `arr_0`, float64).  Reference quirks kept: the per-env view indices
+        select a STEP slot of the queues, so every file holds that slot's arrays of ALL envs; the ground truth is the
+        queue's last slot.  Device slots that several envs share are copied to the host once."""
+        current_obj_config = self.env.get_attr("current_obj_config")
+        num = self.available_num.cpu().numpy()
+        first, second = np.clip(num - 1, 0, None), np.clip(num - 2, 0, None)
+        cache = {}
+
+        def host(queue_name, k):
+            if (queue_name, k) not in cache:
+                cache[(queue_name, k)] = getattr(self, queue_name)[k].to(torch.float64).cpu().numpy()
+            return cache[(queue_name, k)]
+
+        for e, obj_config in enumerate(current_obj_config):
+            obj = obj_config["name"]
+            self.obj_saved_num[obj] = self.obj_saved_num.get(obj, 0) + 1
+            root = os.path.join(self.save_path, obj, str(self.obj_saved_num[obj]))
+            os.makedirs(root, exist_ok=True)
+            id1, id2 = int(first[e]), int(second[e])
+            for name, arr in (("camera_intrinsic", host("intrinsic_queue", id1)), ("rgb1", host("image_queue", id1)),
+                              ("rgb2", host("image_queue", id2)), ("view1_mask", host("mask_queue", id1)),
+                              ("view2_mask", host("mask_queue", id2)), ("view1_extrinsic", host("extrinsic_queue", id1)),
+                              ("view2_extrinsic", host("extrinsic_queue", id2)), ("ground_truth", host("gt_bbox", self.max_steps - 1))):
+                np.savez_compressed(os.path.join(root, name + ".npy"), arr)      # numpy appends ".npz": "<name>.npy.npz"
 
     # ------------------------------------------------------------------ rl_pose.py:85-97
     def reset_queue(self):
@@ -291,6 +329,8 @@ class ControlInterface:
             success = self._dev(self.env.get_observation(gt=True)["success"], torch.float64)[:, 0]
         reward, info = self.get_reward(action, move_res, weight, success)
         self.accumulate_steps += 1
+        if self.accumulate_steps == self.max_steps - 1 and eval:         # :446-447
+            self._save_data()
         done = self.get_done()
         self.last_done = done
         self._last_done_any = self.max_steps <= self.accumulate_steps

@@ -344,6 +344,13 @@ class ReplayVecEnv:
         self.resets += 1
         return None
 
+    def get_attr(self, attr_name, indices=None):
+        """`SubprocVecEnv.get_attr` (`env/my_vec_env.py:466`): one entry per env.  Only `current_obj_config` (read by the
+        eval-time dataset export, `rl_pose.py:58`) is known: two object names that change with every reset."""
+        if attr_name != "current_obj_config":
+            raise AttributeError(attr_name)
+        return [{"name": f"obj{(e + self.resets) % 2}"} for e in range(self.num_envs)]
+
 
 # --------------------------------------------------------------------------- similarity alignment cases (SURVEY 8f-4)
 def align_case(case: int, P: int = 1024):

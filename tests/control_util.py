@@ -48,3 +48,27 @@ def drive_steps(make_ci, keys):
         out[task] = {k: np.stack(v) for k, v in rec.items()}
         out[task]["env"], out[task]["manipulation"] = env, man
     return out
+
+
+def check_saved_dataset(make_ci, golden_dir, tmp_path, monkeypatch):
+    """Two eval episodes (+ one step) on `make_ci`, like tools/make_goldens.py::gen_control_save drove the reference class; the
+    files `_save_data` wrote are compared with the golden's summaries: same relative paths, shapes, dtypes, sums and samples."""
+    import os
+    g = np.load(os.path.join(golden_dir, "control_save.npz"))
+    monkeypatch.chdir(tmp_path)
+    env, est, man = synth.ReplayVecEnv(N_ENVS, SEED), StepFakeEstimator("cabinet"), RecordingManipulation()
+    ci = make_ci(env, est, man, synth.control_cfg("cabinet", 0.0))
+    for step in range(9):
+        ci.step(synth.control_actions(N_ENVS, step, SEED), eval=True)
+    paths = []
+    for root, _, files in sorted(os.walk("saves")):
+        paths += [os.path.join(root, f) for f in sorted(files)]
+    assert paths == list(g["paths"])
+    for i, pth in enumerate(paths):
+        z = np.load(pth)
+        assert list(z.keys()) == ["arr_0"], pth
+        a = z["arr_0"]
+        assert a.shape == tuple(g[f"f{i}_shape"]) and str(a.dtype) == str(g[f"f{i}_dtype"]), pth
+        flat = a.reshape(-1).astype(np.float64)
+        np.testing.assert_array_equal(flat[::max(1, flat.size // 2048)], g[f"f{i}_sample"], err_msg=pth)
+        np.testing.assert_allclose(flat.sum(), float(g[f"f{i}_sum"]), rtol=1e-12, err_msg=pth)

@@ -81,6 +81,14 @@ def test_control_step_matches_reference_golden(golden_dir):
             assert [c[2] for c in man.calls] == list(g["pots_manip_eval"])
 
 
+def test_control_save_data_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
+    """The device ControlInterface's eval-time dataset export against the files the reference class wrote
+    (tests/golden/control_save.npz): same paths, shapes, float64 dtype, sums and strided samples."""
+    from control_util import check_saved_dataset
+    from rgbmanip_amd.control_interface import ControlInterface
+    check_saved_dataset(ControlInterface, golden_dir, tmp_path, monkeypatch)
+
+
 def test_control_reward_float32_terms_bit_exact(golden_dir):
     """The float32 terms of the reward (view-norm penalty, xyz-lookat, move success, bbox boundary) follow numpy's float32
     arithmetic exactly; the float64 terms that involve no transcendental function are bit-exact too."""
@@ -253,10 +261,12 @@ def test_rl_manipulation_wrapper_learns_and_plays():
     assert (env.episode > steps_before).all()                      # play() resets and steps the env
 
 
-def test_rl_pose_controller_train_and_run():
+def test_rl_pose_controller_train_and_run(tmp_path, monkeypatch):
     """rl_pose.py:464-516: RLPoseController.train_controller (PPO over the device ControlInterface) and run (deterministic
-    roll-out to the end of the episode, last estimate handed to the manipulation planner)."""
+    roll-out to the end of the episode, last estimate handed to the manipulation planner; its eval steps export the
+    third-stage dataset, rl_pose.py:446-447, here into a scratch directory)."""
     import copy
+    monkeypatch.chdir(tmp_path)
     from test_gpu_ppo import CFG
     from rgbmanip_amd import synthetic_env as se
     from rgbmanip_amd.config import ADAPOSE_CFGS
@@ -279,6 +289,9 @@ def test_rl_pose_controller_train_and_run():
     assert est_box.shape == (4, 8, 3) and len(calls) == 1 and calls[0][2] is True
     assert np.isfinite(calls[0][0]).all() and np.isfinite(calls[0][1]).all()
     assert ctl.control_interface.accumulate_steps == ctl.control_interface.max_steps          # ran to the end of the episode
+    saved = sorted(os.listdir(os.path.join("saves", "third_stage")))
+    assert saved == sorted(c["name"] for c in env.get_attr("current_obj_config"))              # one directory per object, 8 files each
+    assert len(os.listdir(os.path.join("saves", "third_stage", saved[0], "1"))) == 8
 
 
 def test_fp16_estimator_in_the_control_loop():

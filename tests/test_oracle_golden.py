@@ -176,6 +176,14 @@ def test_control_step_oracle_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(cr.canonical_quat(q), cr.canonical_quat(g["lookat_quat"]), rtol=0, atol=1e-12)
 
 
+def test_control_save_data_oracle_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
+    """oracle ControlInterfaceRef._save_data (rl_pose.py:56-83) against the files the reference class wrote over two eval
+    episodes (tests/golden/control_save.npz: paths, shapes, dtypes, sums, strided samples of all 48 files)."""
+    from control_util import check_saved_dataset
+    from oracle import control_ref as cr
+    check_saved_dataset(cr.ControlInterfaceRef, golden_dir, tmp_path, monkeypatch)
+
+
 def test_synth_camera_ref_is_geometrically_consistent():
     """oracle/synth_env_ref.py: the rendered handle mask is the silhouette of the ground-truth corners under the returned
     K and E (so mask, handle_bbox, Intrinsic and Extrinsic of the synthetic env agree with each other)."""

@@ -543,6 +543,66 @@ def gen_control_step(out_dir):
         os.chdir(cwd)
 
 
+def gen_control_save(out_dir):
+    """`ControlInterface._save_data` (rl_pose.py:56-83): the eval-time dataset export the reference runs in the step that
+    brings `accumulate_steps` to `max_steps - 1` when `eval` is set (:446-447; `RLPoseController.run` always steps with
+    eval=True).  The reference class is driven through two eval episodes on the ReplayVecEnv in a scratch directory and the
+    files it wrote are summarised: relative path, shape, dtype, float64 sum and a strided sample (the frames themselves are
+    22 MB per file)."""
+    import tempfile
+    from rgbmanip_amd import synth
+    stub("env.sapien_envs.open_cabinet", CAMERA_INTRINSIC=[0.05, 100, 1, 640, 480])
+    stub("env.sapien_envs", open_cabinet=sys.modules["env.sapien_envs.open_cabinet"])
+    stub("models.manipulation.open_cabinet", OpenCabinetManipulation=object)
+    stub("models.controller.base_controller", BaseController=object)
+    stub("models.pose_estimator.base_estimator", BasePoseEstimator=object)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="rgbm_save_")
+    os.chdir(tmp)
+    try:
+        from models.controller.rl_pose import ControlInterface
+        N, seed = 3, 4
+
+        class FakeEstimator:
+            def __init__(self, task):
+                self.cfg = {"task_name": task}
+
+            def estimate(self, K, rgb1, m1, E1, rgb2, m2, E2):
+                base = np.arange(24, dtype=np.float64).reshape(1, 8, 3) * 0.01
+                return base + (m1.sum((1, 2)) * 1e-5 + rgb2[:, 0, 0, 0])[:, None, None] + np.sin(np.arange(24.0)).reshape(1, 8, 3) * E1[:, 0, 3, None, None]
+
+        class Manip:
+            def plan_pathway(self, center, direction, eval):
+                pass
+
+        cfg = synth.control_cfg("cabinet", 0.0)
+        env = synth.ReplayVecEnv(N, seed)
+        ci = ControlInterface(env, FakeEstimator("cabinet"), Manip(), cfg)
+        for step in range(9):                                   # two full episodes (4 steps each) and one step of a third
+            ci.step(torch.from_numpy(synth.control_actions(N, step, seed)), eval=True)
+        save = {}
+        paths = []
+        for root, _, files in sorted(os.walk("saves")):
+            for f in sorted(files):
+                paths.append(os.path.join(root, f))
+        for i, pth in enumerate(paths):
+            z = np.load(pth)
+            assert list(z.keys()) == ["arr_0"], (pth, list(z.keys()))
+            a = z["arr_0"]
+            flat = a.reshape(-1).astype(np.float64)
+            save[f"f{i}_shape"] = np.array(a.shape)
+            save[f"f{i}_dtype"] = np.array(str(a.dtype))
+            save[f"f{i}_sum"] = np.array(flat.sum())
+            save[f"f{i}_sample"] = flat[::max(1, flat.size // 2048)].copy()
+        save["paths"] = np.array(paths)
+        np.savez_compressed(os.path.join(out_dir, "control_save.npz"), **save)
+        print("control_save golden:", len(paths), "files;", paths[:3], "...")
+    finally:
+        os.chdir(cwd)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_align(out_dir):
     """lib/align.py::estimateSimilarityTransform (the reference function itself, global np.random seeded per case) on the
     seeded cases of rgbmanip_amd.synth.align_case, plus the bbox tail of interface_v5.py:348-374 built from the reference's
@@ -622,7 +682,7 @@ if __name__ == "__main__":
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["adapose", "adapose_trainbn", "postproc", "ppo", "ppo_run", "control", "control_step", "align"]
+    which = sys.argv[1:] or ["adapose", "adapose_trainbn", "postproc", "ppo", "ppo_run", "control", "control_step", "control_save", "align"]
     if "adapose_trainbn" in which:
         gen_adapose_trainbn(out_dir)
     net_out = inp = None
@@ -638,6 +698,8 @@ if __name__ == "__main__":
         gen_control(out_dir)
     if "control_step" in which:
         gen_control_step(out_dir)
+    if "control_save" in which:
+        gen_control_save(out_dir)
     if "align" in which:
         gen_align(out_dir)
     print("done")
