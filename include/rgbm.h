@@ -382,6 +382,9 @@ int rgbm_has_experiments(void);
 int rgbm_prof_rows(void);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);
+/* Restrict the per-launch events to one row of the table (-1 = every row, the default): two events per launch cost ~3.5 us, i.e.
+ * 0.35 ms per 256-pose forward when every launch is bracketed; bench.py brackets only the dominant kernel inside its timed region. */
+int rgbm_prof_select(int row);
 
 #ifdef __cplusplus
 }

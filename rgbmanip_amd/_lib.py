@@ -139,6 +139,7 @@ SIGNATURES = {
     "rgbm_prof_rows": (_i, []),
     "rgbm_has_experiments": (_i, []),
     "rgbm_prof_start": (_i, []),
+    "rgbm_prof_select": (_i, [_i]),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),
 }
 

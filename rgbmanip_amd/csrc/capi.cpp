@@ -357,6 +357,10 @@ int rgbm_has_experiments(void) {
 #endif
 }
 int rgbm_prof_start(void) { return rgbm::prof_start(); }
+int rgbm_prof_select(int row) {
+  RGBM_REQUIRE(row >= -1 && row < rgbm::kProfVariants, "prof_select: row out of range");
+  return rgbm::prof_select(row);
+}
 int rgbm_prof_stop(double* stats) {
   RGBM_REQUIRE(stats != nullptr, "prof_stop arguments");
   return rgbm::prof_stop(stats, rgbm::kProfVariants);

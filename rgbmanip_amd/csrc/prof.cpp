@@ -10,6 +10,8 @@ namespace rgbm {
 
 struct ProfRec { hipEvent_t e0, e1; int variant; double flops, bytes; };
 static bool g_on = false;
+static int g_only = -1;      // >= 0: only launches of this row are bracketed (prof_select)
+static bool g_open = false;    // the last prof_begin_launch recorded its first event
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
@@ -23,17 +25,25 @@ static hipEvent_t get_event() {
 }
 
 void prof_begin_launch(hipStream_t s, int variant, double flops, double bytes) {
-  if (!g_on) return;
+  g_open = false;
+  if (!g_on || (g_only >= 0 && variant != g_only)) return;
   ProfRec r;
   r.e0 = get_event(); r.e1 = get_event(); r.variant = variant; r.flops = flops; r.bytes = bytes;
   if (!r.e0 || !r.e1) return;
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
+  g_open = true;
 }
 
 void prof_end_launch(hipStream_t s) {
-  if (!g_on || g_recs.empty()) return;
+  if (!g_on || !g_open || g_recs.empty()) return;
   (void)hipEventRecord(g_recs.back().e1, s);
+  g_open = false;
+}
+
+int prof_select(int variant) {
+  g_only = variant;
+  return 0;
 }
 
 int prof_start() {

@@ -11,5 +11,6 @@ bool prof_enabled();
 void prof_begin_launch(hipStream_t s, int variant, double flops, double bytes);
 void prof_end_launch(hipStream_t s);
 int prof_start();
+int prof_select(int variant);      // -1: every row (default); >= 0: only that row's launches get events (fewer events in a timed region)
 int prof_stop(double* stats, int n_variants);
 }  // namespace rgbm

@@ -125,6 +125,9 @@ for slot in range(1, 10):                                                      #
 assert fwd_graph(2, 9)[2] == 0 and fwd_graph(1, 0)[2] == 1                     # the newest is cached, the oldest was evicted
 _lib.check(lib.rgbm_adapose_set_option(h, b"sparse_dec", 0), "set_option")     # settings changed: every graph is dropped
 assert fwd_graph(2, 9)[2] == 1
+_lib.check(lib.rgbm_prof_select(31), "prof_select")                            # one row only, then every row again
+_lib.check(lib.rgbm_prof_select(-1), "prof_select")
+assert lib.rgbm_prof_select(4096) != 0                                          # out of range: refused
 _lib.check(lib.rgbm_prof_start(), "prof_start")                                # profiler on: eager, reported as -1
 assert fwd_graph(2, 9)[2] == -1
 stats = (C.c_double * (4 * _lib.PROF_ROWS))()
