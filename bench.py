@@ -293,6 +293,43 @@ def time_steps(fn, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def achievable_peaks(lib, device):
+    """the peaks this box reaches, measured next to the datasheet ones (rgbm_microbench_*: a bare bf16 MFMA stream in the
+    register shape of the implicit GEMM's multiply waves on constant and on pseudo-random operands, and a 16-byte copy).  ~0.3 s."""
+    from rgbmanip_amd import _lib
+    n = C.c_int()
+    _lib.check(lib.rgbm_microbench_mfma_scratch_floats(C.byref(n)), "rgbm_microbench_mfma_scratch_floats")
+    scratch = torch.empty(n.value, dtype=torch.float32, device=device)
+    out = {}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for name, rnd in (("mfma_bf16_constant_operands_TFLOPs", 0), ("mfma_bf16_random_operands_TFLOPs", 1)):
+        fl = C.c_double()
+        run = lambda it: _lib.check(lib.rgbm_microbench_mfma(_lib.ptr(scratch), it, rnd, C.byref(fl), _lib.stream_ptr()), "rgbm_microbench_mfma")
+        run(20000)                                        # warm-up, clocks settle under load
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(3):
+            run(60000)                                    # ~25-35 ms each: long enough for the power limit to act
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(3 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    cp = lambda: _lib.check(lib.rgbm_microbench_copy(_lib.ptr(src), _lib.ptr(dst), nbytes, _lib.stream_ptr()), "rgbm_microbench_copy")
+    cp()
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        cp()
+    e1.record()
+    torch.cuda.synchronize()
+    out["hbm_copy_GBps_read_plus_write"] = round(5 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    out["note"] = ("measured in this run on this GPU; roofline.peak / whole_net_hbm.peak_GBps stay the datasheet figures "
+                   "(2.5 PFLOP/s dense bf16, 8 TB/s), these are additional denominators")
+    return out
+
+
 def prof_table(stats, steps):
     from rgbmanip_amd import _lib
     st = np.array(list(stats)).reshape(_lib.PROF_ROWS, 4)
@@ -331,6 +368,7 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the estimate() plugin-boundary leg (host numpy frames in, H2D included)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / B = 8 latency leg (eager launches and hipGraph replay)")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the achievable-peak probes (bare MFMA stream, copy kernel; ~0.3 s)")
     ap.add_argument("--no-prof", action="store_true", help="timing experiment: no per-launch HIP events in the timed region (the roofline object is then empty)")
     ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel A/B switches (rgbm_debug_flags); a non-zero value is echoed in config")
@@ -631,6 +669,7 @@ def main():
     _mark("boundary leg done")
     # ---- small batches (the deployment path: the reference calls the network per env, num_envs: 8 ships): B = 1 and 8, latency of
     # forward + post-processing, launched one by one and replayed from a hipGraph ----
+    peaks_res = achievable_peaks(lib, device) if rank == 0 and not args.no_peaks else None
     small_res = None
     if rank == 0 and world == 1 and not args.no_small_batch:
         small_res = {"what": "median wall-clock latency of one forward + post-processing call incl. the final device synchronisation, "
@@ -858,6 +897,13 @@ def main():
         res["timed_region_note"] = ("inside the timed region only the dominant kernel's launches sit between two HIP events (rgbm_prof_select); the "
                                     "other rows of conv_kernels come from one untimed step in front of it.  The headline includes "
                                     "that overhead" + ("" if n_unique == B else f"; inputs are {n_unique} unique poses tiled to the batch (no dedupe exists in the library)"))
+        res["frames_per_sec"] = round(2 * value, 1)      # one pose = one stereo pair = two 224 x 224 frames
+        if peaks_res is not None:
+            res["achievable_peaks"] = peaks_res
+            rnd = peaks_res["mfma_bf16_random_operands_TFLOPs"] / (3.0 if dom["dtype"] == "bf16x3" else 1.0)      # split pairs: three MFMAs per product
+            if roofline["unit"] == "TFLOP/s" and dom["dtype"] in ("bf16", "bf16x3") and rnd > 0:
+                roofline["frac_of_achievable"] = round(roofline["achieved"] / rnd, 4)
+                roofline["achievable_peak"] = round(rnd, 1)
         if boundary_res is not None:
             res["plugin_boundary"] = boundary_res
             res["value_plugin_boundary"] = boundary_res["device_prepare"]["poses_per_sec"]

@@ -379,6 +379,13 @@ int rgbm_set_tuning(const char* key, long long value);
 /* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
  * flags are then ignored */
 int rgbm_has_experiments(void);
+/* Achievable-peak probes (the peaks the box reaches, next to the datasheet ones; no reference counterpart).  Asynchronous:
+ * the caller times them with events on `stream`.  rgbm_microbench_mfma: a bare v_mfma_f32_16x16x32_bf16 stream, 8 waves per CU on
+ * every CU, `iters` x 32 MFMAs per wave on constant (random_operands = 0) or pseudo-random operands; `scratch` holds
+ * rgbm_microbench_mfma_scratch_floats floats; *flops = the flops the launch executes.  rgbm_microbench_copy: grid-stride 16-byte copy. */
+int rgbm_microbench_mfma_scratch_floats(int* n);
+int rgbm_microbench_mfma(float* scratch, int iters, int random_operands, double* flops, void* stream);
+int rgbm_microbench_copy(const void* src, void* dst, size_t bytes, void* stream);
 int rgbm_prof_rows(void);
 int rgbm_prof_start(void);
 int rgbm_prof_stop(double* stats);

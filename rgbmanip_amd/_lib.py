@@ -138,6 +138,9 @@ SIGNATURES = {
     "rgbm_set_tuning": (_i, [C.c_char_p, _i64]),
     "rgbm_prof_rows": (_i, []),
     "rgbm_has_experiments": (_i, []),
+    "rgbm_microbench_mfma_scratch_floats": (_i, [C.POINTER(C.c_int)]),
+    "rgbm_microbench_mfma": (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp]),
+    "rgbm_microbench_copy": (_i, [_vp, _vp, C.c_size_t, _vp]),
     "rgbm_prof_start": (_i, []),
     "rgbm_prof_select": (_i, [_i]),
     "rgbm_prof_stop": (_i, [C.POINTER(C.c_double)]),

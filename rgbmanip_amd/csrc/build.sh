@@ -11,7 +11,7 @@ if [ "${RGBM_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DRGBM_EXPERIMENTS"; f
 echo "$FLAGS" > build/.flags.new 2>/dev/null || true
 if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o; cp build/.flags.new build/.flags; fi
 pids=()
-for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip bn_kernels.hip upconv.hip upconv_final.hip stem.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip pnp.hip; do
+for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip bn_kernels.hip upconv.hip upconv_final.hip stem.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip pnp.hip microbench.hip; do
   [ -f "$f" ] || continue
   EXTRA=""
   # files that must round like numpy / torch elementwise ops: no mul+add -> fma contraction

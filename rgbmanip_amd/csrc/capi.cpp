@@ -356,6 +356,16 @@ int rgbm_has_experiments(void) {
   return 0;
 #endif
 }
+int rgbm_microbench_mfma_scratch_floats(int* n) {
+  RGBM_REQUIRE(n, "microbench_mfma_scratch_floats arguments");
+  return rgbm::microbench_mfma_scratch_floats(n);
+}
+int rgbm_microbench_mfma(float* scratch, int iters, int random_operands, double* flops, void* stream) {
+  return rgbm::launch_microbench_mfma(scratch, iters, random_operands, flops, (hipStream_t)stream);
+}
+int rgbm_microbench_copy(const void* src, void* dst, size_t bytes, void* stream) {
+  return rgbm::launch_microbench_copy(src, dst, bytes, (hipStream_t)stream);
+}
 int rgbm_prof_start(void) { return rgbm::prof_start(); }
 int rgbm_prof_select(int row) {
   RGBM_REQUIRE(row >= -1 && row < rgbm::kProfVariants, "prof_select: row out of range");

@@ -125,6 +125,10 @@ int launch_mask_extent(const unsigned char* mask, int N, int H, int W, int* ext,
 int launch_postprocess(const float* nocs, const float* depth, const float* rot, const int* choose, const double* Kc,
                        const double* E1, double* bbox, double* ts_out, int* valid, int B, int P, int img, hipStream_t s,
                        void* scratch = nullptr, size_t scratch_bytes = 0);
+// microbench.hip: achievable-peak probes for bench.py
+int launch_microbench_mfma(float* scratch, int iters, int random_operands, double* flops, hipStream_t s);
+int microbench_mfma_scratch_floats(int* n);
+int launch_microbench_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 size_t postprocess_scratch_bytes(int B);      // device scratch of the split (small-batch) form, per call
 int postprocess_slices(int B);                // workgroups per pose the split form would use (1 = one-kernel form)
 

@@ -6,7 +6,7 @@ for dt in bf16 bf16x3; do
   O=$R/gpurun_out/pq_${tag}_$dt
   mkdir -p $O
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $R/bench.py --dtype $dt --steps 2 --warmup 1 --no-mixed --ppo-envs 0 --no-prepare --no-modes --no-dense-leg --no-accuracy --no-cpu-baseline --no-boundary --no-small-batch > $O/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $R/bench.py --dtype $dt --steps 2 --warmup 1 --no-mixed --ppo-envs 0 --no-prepare --no-modes --no-dense-leg --no-accuracy --no-cpu-baseline --no-boundary --no-small-batch --no-peaks > $O/trace.log 2>&1
   cd $R
   T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
   S=$(find $O/trace -name "*kernel_stats.csv" | head -1)

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --dtype $dt --steps 2 --warmup 1 --no-mixed --ppo-envs 0 --no-prepare --no-modes --no-dense-leg --no-accuracy --no-cpu-baseline --no-boundary --no-small-batch"
+ARGS="$R/bench.py --dtype $dt --steps 2 --warmup 1 --no-mixed --ppo-envs 0 --no-prepare --no-modes --no-dense-leg --no-accuracy --no-cpu-baseline --no-boundary --no-small-batch --no-peaks"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $ARGS > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python3 $ARGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python3 $ARGS > $O/write.log 2>&1
