@@ -571,19 +571,31 @@ def main():
         nets2 = [net, AdaPoseNet(sd0, dtype=args.dtype, device=local_rank, max_chunk_views=args.chunk or None)]
         st2 = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
 
+        last2 = [None, None]
+        ref2 = net(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])      # one stream, nothing else on the device
+        ref2 = {k: v.clone() for k, v in ref2.items()}
+
         def pair():
             for i in range(2):
                 with torch.cuda.stream(st2[i]):
                     o = nets2[i](d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"], stream=st2[i])
                     postprocess(o["view1_nocs"], o["view1_depth"], o["view1_r"], d["choose1"], d["K1"], d["E1"], stream=st2[i])
+                    last2[i] = o
         torch.cuda.synchronize()
         for s_ in st2:
             s_.wait_stream(torch.cuda.current_stream(device))
         t2 = time_steps(pair, 1, max(2, args.steps // 2)) / 2
         torch.cuda.current_stream(device).wait_stream(st2[0])
         torch.cuda.current_stream(device).wait_stream(st2[1])
+        torch.cuda.synchronize()
+        # the overlapped forwards against the one-stream forward of the timed step (same inputs): a throughput figure whose outputs differ
+        # is not a result.  (Round 4: forwards that overlap on the device were seen to differ intermittently in the depth-guided fusion,
+        # tools/check_two_stream_forwards.py)
+        differing = sorted({k for o in last2 for k in ref2 if not torch.equal(o[k].view(torch.int32), ref2[k].view(torch.int32))})
         two_res = {"poses_per_sec": round(B / t2, 1), "ms_per_step": round(t2 * 1e3, 2),
+                   "outputs_bit_identical_to_one_stream": not differing, "differing_outputs": differing,
                    "note": "two steps in flight on two HIP streams (two network instances, two workspaces); `value` is the one-stream figure"}
+        del last2, ref2
         del nets2
         torch.cuda.empty_cache()
 

@@ -167,6 +167,7 @@ def test_bench_single_process_line_has_every_leg():
     rl = line["roofline"]
     assert rl["bound"] == "mfma" and rl["peak"] == 2500.0 and 0 < rl["frac"] < 1 and "traffic" in rl
     assert not any(k["kernel"] == "unused" for k in line["conv_kernels"])
+    assert isinstance(line["two_streams"]["outputs_bit_identical_to_one_stream"], bool)   # checked and reported, whichever way
     assert line["frames_per_sec"] == pytest.approx(2 * line["value"], rel=1e-3)
     pk = line["achievable_peaks"]                                                      # peaks measured on this box, as extra denominators
     assert 1000 < pk["mfma_bf16_random_operands_TFLOPs"] <= pk["mfma_bf16_constant_operands_TFLOPs"] * 1.02 < 2700

@@ -1,0 +1,72 @@
+"""Reproducer (round 4, OPEN): two forwards that OVERLAP on the device — the halves of a batch on two HIP streams, each with its own
+workspace, one handle or two — intermittently differ from the one-stream forward, in the outputs of the depth-guided fusion only
+(fuse_points_kernel's 32 channels of PF96 -> view*_r / _t / _s; a few per cent, pairs of points 4k + 2, 4k + 3 of the first ~25 views of
+a part, never NaN).  What is established (each line one gpurun experiment, MI355X, ROCm 7.2):
+  * 14-19 of 25 runs differ with one handle, 14-18 of 25 with two; 0 of 25 when the host synchronises between the two launches sequences,
+    0 of 25 with GPU_MAX_HW_QUEUES=1 (both streams on one hardware queue);
+  * every input of the fusion (prob, feat, homog, choose, depths) is bit-identical to the reference after the forward, and a checksum
+    kernel placed in front of the fusion sees the final prob; launching the fusion twice back to back repairs most runs (4 of 25 left);
+  * a build of the kernel without its cross-lane shuffle fails at the same rate: not its arithmetic;
+  * no other kernel's output ever differed.
+Not root-caused.  Forwards are therefore issued one at a time per device (the library's tests and every bench figure except the
+`two_streams` leg do that); bench.py checks that leg's outputs and reports `outputs_bit_identical_to_one_stream`.
+usage: python tools/check_two_stream_forwards.py [dtype] [runs]"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from rgbmanip_amd import synth, _lib
+from rgbmanip_amd.adapose import AdaPoseNet
+
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+runs = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+B, h = 256, 128
+dev = torch.device("cuda", 0)
+_, d, _ = bench.make_inputs_crop(B, dev, seed=0)
+sd = synth.adapose_state_dict(seed=0)
+lib = _lib.load()
+one = AdaPoseNet(sd, dtype=dt)
+args = [d[k] for k in ("img1", "img2", "choose1", "choose2", "P1", "P2", "depths")]
+ref = one(d["img1"], d["choose1"], d["img2"], d["choose2"], d["P1"], d["P2"], d["depths"])
+torch.cuda.synchronize()
+ref = {k: v.cpu().numpy() for k, v in ref.items()}
+nets = [AdaPoseNet(sd, dtype=dt), AdaPoseNet(sd, dtype=dt)]
+side = [torch.cuda.Stream(), torch.cuda.Stream()]
+need = nets[0].workspace_bytes(h) + 256
+wss = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+
+def split(handles, sync_between=False):
+    f32 = dict(dtype=torch.float32, device=dev)
+    shapes = {"nocs": (B, 1024, 3), "depth": (B, 1024), "r": (B, 3, 3), "t": (B, 3), "s": (B, 3)}
+    out = {f"view{v}_{k}": torch.empty(*shp, **f32) for k, shp in shapes.items() for v in (1, 2)}
+    cur = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    for i in range(2):
+        si, ws = side[i], wss[i]
+        si.wait_event(fork)
+        off = (-ws.data_ptr()) % 256
+        sl = slice(i * h, (i + 1) * h)
+        o = _lib.AdaposeOut(*[out[n][sl].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
+        _lib.check(lib.rgbm_adapose_forward_ex(handles[i], h, *[_lib.ptr(t[sl]) for t in args], C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
+                                               C.byref(o), 0, _lib.stream_ptr(si)), "rgbm_adapose_forward_ex")
+        if sync_between:
+            torch.cuda.synchronize()
+    for si in side:
+        j = torch.cuda.Event()
+        j.record(si)
+        cur.wait_event(j)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+for name, handles, sb in (("one handle, two streams", [nets[0]._h, nets[0]._h], False), ("two handles, two streams", [nets[0]._h, nets[1]._h], False),
+                          ("one handle, host sync between the halves", [nets[0]._h, nets[0]._h], True)):
+    bad, which = 0, set()
+    for t in range(runs):
+        o = split(handles, sb)
+        diff = [k for k in ref if not np.array_equal(ref[k], o[k], equal_nan=True)]
+        bad += bool(diff)
+        which |= set(diff)
+    print(f"{dt} {name}: {bad} of {runs} runs differ from the one-stream forward {sorted(which)}")
