@@ -7,7 +7,13 @@ a part, never NaN).  What is established (each line one gpurun experiment, MI355
   * every input of the fusion (prob, feat, homog, choose, depths) is bit-identical to the reference after the forward, and a checksum
     kernel placed in front of the fusion sees the final prob; launching the fusion twice back to back repairs most runs (4 of 25 left);
   * a build of the kernel without its cross-lane shuffle fails at the same rate: not its arithmetic;
-  * no other kernel's output ever differed.
+  * no other kernel's output ever differed;
+  * which part of the OTHER forward interferes: its PSPNet alone (three back to back) 0 of 20 runs, through its cost volume 11-19 of 20 in
+    every configuration of that stage (plane-sweep kernel or halo-tile conv0, sparse or dense tail / 3-D stack): nothing specific to one kernel;
+  * a numpy restatement of the fusion reproduces the one-stream values exactly from the tapped inputs; the wrong values match none of: the other
+    part's prob / homography, a neighbouring point's prob, any of the 512 homographies in either workspace — they look like the right computation
+    with some registers of lanes 16-31 / 48-63 disturbed (points 4k + 2, 4k + 3 = those lane rows of a wave) in the blocks resident when the
+    kernel starts, which is what a fault in saving / restoring waves under queue time-slicing would look like; not verified.
 Not root-caused.  Forwards are therefore issued one at a time per device (the library's tests and every bench figure except the
 `two_streams` leg do that); bench.py checks that leg's outputs and reports `outputs_bit_identical_to_one_stream`.
 usage: python tools/check_two_stream_forwards.py [dtype] [runs]"""
