@@ -11,8 +11,8 @@ for dt in bf16 bf16x3; do
   T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
   S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
   cp $S $O/kernel_stats.csv
-  python3 tools/layer_times.py $T 3 > $O/layer_times.txt
-  python3 tools/launch_sequence.py $T 3 > $O/sequence.txt
+  python3 tools/layer_times.py $T 4 > $O/layer_times.txt
+  python3 tools/launch_sequence.py $T 4 > $O/sequence.txt
   find $O -name "*kernel_trace.csv" -delete
   rm -rf $O/trace
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round of profiles for the benchmark command of one storage type (run ON the GPU box, from the repo root, via gpurun):
-#   tools/profile_round.sh <tag> <dtype>
+#   tools/profile_round.sh <tag> <dtype>      (the command runs 4 forwards: 1 warm-up, bench.py's untimed profiled step, 2 timed)
 # writes under gpurun_out/prof_<tag>/ : kernel trace + stats, three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ busy counters;
 # separate passes, program directly after `--`, no trace domains combined with --pmc), and the summaries that get
 # committed to profiles/: <tag>_kernel_stats.csv, <tag>_layer_times.txt, <tag>_hbm_traffic.csv, <tag>_sq_busy.txt and
@@ -23,8 +23,8 @@ F=$(find $O/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/write -name "*counter_collection.csv" | head -1)
 B=$(find $O/busy -name "*counter_collection.csv" | head -1)
 cp $S $O/${tag}_kernel_stats.csv
-python3 tools/layer_times.py $T 3 > $O/${tag}_layer_times.txt
-python3 tools/pmc_traffic.py $F $W $O/${tag}_hbm_traffic.csv $O/hbm_traffic.json $dt 3 > $O/traffic.log 2>&1
+python3 tools/layer_times.py $T 4 > $O/${tag}_layer_times.txt
+python3 tools/pmc_traffic.py $F $W $O/${tag}_hbm_traffic.csv $O/hbm_traffic.json $dt 4 > $O/traffic.log 2>&1
 python3 tools/pmc_busy.py $B $T > $O/${tag}_sq_busy.txt 2>&1
 # raw traces are large: keep only the summaries in gpurun_out
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
