@@ -14,6 +14,8 @@ a part, never NaN).  What is established (each line one gpurun experiment, MI355
     part's prob / homography, a neighbouring point's prob, any of the 512 homographies in either workspace — they look like the right computation
     with some registers of lanes 16-31 / 48-63 disturbed (points 4k + 2, 4k + 3 = those lane rows of a wave) in the blocks resident when the
     kernel starts, which is what a fault in saving / restoring waves under queue time-slicing would look like; not verified.
+  * not leftover register contents: a kernel that leaves a junk pattern in v8-v119 / s20-s89 of every SIMD, launched in front of the fusion on one
+    stream, changes nothing.
 Not root-caused.  Forwards are therefore issued one at a time per device (the library's tests and every bench figure except the
 `two_streams` leg do that); bench.py checks that leg's outputs and reports `outputs_bit_identical_to_one_stream`.
 usage: python tools/check_two_stream_forwards.py [dtype] [runs]"""
