@@ -669,8 +669,9 @@ def main():
                                "view2_heads": "skipped (hip_view2_heads default: the box tail reads view-1 outputs only; all ten outputs stay the "
                                               "network API's default and are what `value` times)",
                                "float32_frames_bool_masks": {"poses_per_sec": round(B / e32_s, 1), "ms_per_call": round(e32_s * 1e3, 1)},
-                               "note": "hip_prepare: device — frames cross PCIe in their own dtype through pinned double-buffered staging (host "
-                                       "thread pool) and are converted on the device; crop / resize / subset / network / post-processing on the GPU"},
+                               "note": "hip_prepare: device — float frames are cast to float32 by the copy into pinned double-buffered staging (host thread pool), "
+                                       "so float64 frames cross PCIe at half their size; uint8 frames cross as bytes; crop / resize / subset / network / "
+                                       "post-processing on the GPU"},
             "host_prepare": {"poses_per_sec": round(nh / h_s, 2), "ms_per_pose": round(h_s / nh * 1e3, 1), "sample_poses": nh,
                              "note": "hip_prepare: host — the reference's per-frame numpy crop / resize on one host core, then one batched forward"},
             "finite": bool(np.isfinite(bb).all())}

@@ -115,6 +115,11 @@ def _host_pool():
     return _POOL
 
 
+def _cast_into(dst, src):
+    """dst[...] = src cast to dst's dtype (float64 / float16 frames -> float32 staging; same dtype: a plain copy).  numpy releases the GIL."""
+    np.copyto(dst, src, casting="same_kind")
+
+
 def _nonzero_into(dst_u8, src):
     np.not_equal(src, 0, out=dst_u8.view(np.bool_))
 
@@ -257,7 +262,10 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 raise TypeError(f"estimate: rgb frames must be float images in [0, 1] or uint8, got {a.dtype}")
         Kd = torch.as_tensor(np.asarray(K)).to(dev)
         E1d, E2d = torch.as_tensor(np.asarray(E1)).to(dev), torch.as_tensor(np.asarray(E2)).to(dev)
-        tdt = [torch.from_numpy(a[:0]).dtype for a in srcs[:2]] + [torch.uint8, torch.uint8]
+        # float frames are converted to float32 WHILE they are copied into the pinned staging buffers (numpy's casting copy is as fast as its
+        # plain copy once a pool of threads runs it: both are bound by host memory, tools/host_convert_bw.py), so float64 frames cross PCIe
+        # at half their size; the value every later stage sees is the same float32(frame) the device-side conversion produced
+        tdt = [torch.uint8 if a.dtype == np.uint8 else torch.float32 for a in srcs[:2]] + [torch.uint8, torch.uint8]
         shp = [tuple(a.shape[1:]) for a in srcs]
         key = ("pipe", chunk, tuple(shp), tuple(tdt))
         if getattr(self, "_pipe_key", None) != key:
@@ -278,7 +286,9 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             for i in range(4):
                 dst, src = self._pipe_np[slot][i], srcs[i]
                 for lo, hi in _split(b - a, max(1, _HOST_THREADS // 2)):
-                    if i < 2 or src.dtype == np.uint8:
+                    if i < 2:
+                        tasks.append((_cast_into, dst[lo:hi], src[a + lo:a + hi]))
+                    elif src.dtype == np.uint8:
                         tasks.append((np.copyto, dst[lo:hi], src[a + lo:a + hi]))
                     elif src.dtype == np.bool_:
                         tasks.append((np.copyto, dst[lo:hi], src[a + lo:a + hi].view(np.uint8)))
@@ -315,19 +325,18 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
 
     def _upload_frames(self, frames):
         """[N,H,W,3] host frames (float64 / float32 in [0,1], or uint8) -> CUDA float32 [N,H,W,3] in [0,1].  Frames that already are
-        CUDA tensors pass through.  The frames cross PCIe in their own dtype and are converted on the device: a pool of host threads
-        copies each chunk into one of two pinned staging buffers (plain memcpy, ~10 GB/s per thread; a dtype-converting numpy copy
-        runs at 0.6-1 GB/s per thread, and 3.8 GB of float64 frames arrive per call at N = 256) while the previous chunk's copy is in
-        flight; the device-side conversion of a chunk is a stream-ordered elementwise kernel."""
+        CUDA tensors pass through.  A pool of host threads copies each chunk into one of two pinned staging buffers while the previous
+        chunk's copy is in flight; float frames are cast to float32 by that copy (3.8 GB of float64 frames arrive per call at N = 256 and
+        cross PCIe as 1.9 GB), uint8 frames cross as bytes and are scaled on the device."""
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
             return frames.to(torch.float32) if frames.dtype != torch.uint8 else (frames.to(torch.float64) / 255.0).to(torch.float32)      # (device-side dtype conversion of an uploaded chunk)
         src = frames.numpy() if isinstance(frames, torch.Tensor) else np.ascontiguousarray(np.asarray(frames))
         dev = self.estimator.device
         if src.dtype != np.uint8 and src.dtype.kind != "f":
             raise TypeError(f"estimate: rgb frames must be float images in [0, 1] or uint8, got {src.dtype}")
-        tdt = torch.from_numpy(src[:0]).dtype
+        tdt = torch.uint8 if src.dtype == np.uint8 else torch.float32      # float frames: converted to float32 by the staging copy itself
         n = src.shape[0]
-        per = max(1, int(np.prod(src.shape[1:]))) * src.dtype.itemsize
+        per = max(1, int(np.prod(src.shape[1:]))) * (1 if src.dtype == np.uint8 else 4)
         rows = max(1, min(n, self._CHUNK_BYTES // per))
         key = (rows, tuple(src.shape[1:]), tdt)
         if getattr(self, "_stage_key", None) != key:
@@ -345,7 +354,7 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             if self._stage_used[k]:
                 self._stage_ev[k].synchronize()                    # the copy that last read this staging buffer has finished
             dst = self._stage_np[k]
-            list(pool.map(lambda p: np.copyto(dst[p[0]:p[1]], src[a + p[0]:a + p[1]]), _split(b - a, _HOST_THREADS)))
+            list(pool.map(lambda p: _cast_into(dst[p[0]:p[1]], src[a + p[0]:a + p[1]]), _split(b - a, _HOST_THREADS)))
             self._stage_dev[k][: b - a].copy_(self._stage[k][: b - a], non_blocking=True)
             self._stage_ev[k].record()
             self._stage_used[k] = True
