@@ -307,20 +307,31 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
             stage(slot, a, b)                              # host threads; overlaps the device's work on the previous chunks
             if trace is not None:
                 trace.append((round((t1 - t0) * 1e3, 2), round((time.perf_counter() - t1) * 1e3, 2)))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if trace is not None else None
             with torch.cuda.stream(self._pipe_stream):
                 if used[slot]:
                     self._pipe_stream.wait_event(self._pipe_done[slot])      # the kernels that read this slot's device buffers are done
+                if ev: ev[0].record(self._pipe_stream)
                 for i in range(4):
                     self._pipe_dev[slot][i][: b - a].copy_(self._pipe_pin[slot][i][: b - a], non_blocking=True)
                 self._pipe_h2d[slot].record(self._pipe_stream)
+                if ev: ev[1].record(self._pipe_stream)
             cur.wait_event(self._pipe_h2d[slot])
+            if ev: ev[2].record(cur)
             d = [t[: b - a] for t in self._pipe_dev[slot]]
             out[a:b] = self.estimate_device(Kd[a:b], self._upload_frames(d[0]), d[2], E1d[a:b], self._upload_frames(d[1]), d[3], E2d[a:b], frame0=a)
             self._pipe_done[slot].record(cur)
+            if ev:
+                ev[3].record(cur)
+                trace[-1] = trace[-1] + (round((time.perf_counter() - t0) * 1e3, 2), ev)
             used[slot] = True
         res = out.cpu().numpy()
         if trace is not None:
-            print("[rgbm upload trace] per chunk (wait for slot ms, stage ms):", trace, file=sys.stderr)
+            e00 = trace[0][3][0]
+            rows = [(w, st, tot, round(e00.elapsed_time(ev[0]), 1), round(e00.elapsed_time(ev[1]), 1), round(e00.elapsed_time(ev[2]), 1), round(e00.elapsed_time(ev[3]), 1))
+                    for (w, st, tot, ev) in trace]
+            print("[rgbm upload trace] per chunk (host: wait for slot ms, stage ms, whole iteration ms | device clock from the first copy's start: copy start, "
+                  "copy end, kernels start, kernels end):", rows, file=sys.stderr)
         return res
 
     def _upload_frames(self, frames):
