@@ -14,6 +14,15 @@ a part, never NaN).  What is established (each line one gpurun experiment, MI355
     part's prob / homography, a neighbouring point's prob, any of the 512 homographies in either workspace — they look like the right computation
     with some registers of lanes 16-31 / 48-63 disturbed (points 4k + 2, 4k + 3 = those lane rows of a wave) in the blocks resident when the
     kernel starts, which is what a fault in saving / restoring waves under queue time-slicing would look like; not verified.
+  * hashes taken INSIDE the kernel (debug build, compared with a one-stream run): for every wrong point the pixel, the prob row, the depth values and
+    the homography as re-read at the end of the kernel are the reference's, and so are the twelve homography words and the depth as first loaded — but the
+    warp coordinates (ix, iy) computed from them at the start of the kernel differ (and with them the sampled features).  The same coordinates evaluated
+    twice in one wave through one `noinline` function, once at the start and once at the end of the kernel, differ from each other in the affected
+    lanes (x, y equal both times; e.g. ix 472.39 early, 477.13 late): what the first instructions of those waves computed or loaded is what is off, and
+    only in lane rows 16-31 / 48-63.  Builds with approximate divisions, without the shuffle, with the kernel at 2 workgroups per CU (one stream): no change
+    / no reproduction.  A stand-alone pair of kernels (`tools/micro/valu_under_mfma.hip`: the same arithmetic re-evaluated next to MFMA / VALU / LDS + MFMA
+    co-tenants on another stream) shows 0 differing evaluations: the co-tenant alone is not it either.  A watcher kernel polling this part's homography
+    through L2 during the overlapped forwards never saw a word change.
   * not leftover register contents: a kernel that leaves a junk pattern in v8-v119 / s20-s89 of every SIMD, launched in front of the fusion on one
     stream, changes nothing.
 Not root-caused.  Forwards are therefore issued one at a time per device (the library's tests and every bench figure except the
