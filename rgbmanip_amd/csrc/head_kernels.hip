@@ -183,11 +183,17 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
     // zero padding): four independent reads per depth instead of four dependent branches.
     const int lane = threadIdx.x & 63, grp = lane & ~7;
     float cix[3], ciy[3];                                   // D <= 24
+    // The 64 lanes of a wave belong to one view (P is a multiple of 8): the view's homography comes through the scalar cache
+    // into SGPRs (one s_load instead of three vector loads per lane).  Round 4: with the per-lane vector loads of this record, forwards that
+    // overlapped on the device (two streams) intermittently computed other warp coordinates in lanes 16-31 / 48-63 of the first
+    // resident blocks from registers that hashed to the right values afterwards; with the scalar form the mismatch is gone
+    // (tools/check_two_stream_forwards.py: 0 of 50 runs against 14-19 of 25).  Cause of the wrong vector loads: not established.
+    const float* hmv = homog + (long long)__builtin_amdgcn_readfirstlane(v) * 12;      // launch_fuse_points requires P % 8 == 0
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int dz = q * 8 + c4;
       cix[q] = ciy[q] = 0.f;
-      if (dz < D) warp_coords_h(homog + (long long)v * 12, (float)x, (float)y, depths[b * D + dz], H, W, cix[q], ciy[q]);
+      if (dz < D) warp_coords_h(hmv, (float)x, (float)y, depths[b * D + dz], H, W, cix[q], ciy[q]);
     }
     for (int dz = 0; dz < D; ++dz) {
       const int q = dz >> 3, srcl = grp + (dz & 7);
@@ -235,6 +241,7 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
   if (Vn < 0) Vn = V;
   const long long total = (long long)Vn * P * 8;
   RGBM_REQUIRE(D >= 1 && D <= 24 && total > 0 && (total + 255) / 256 < (1ll << 31), "fuse_points supports up to 24 depth planes");
+  RGBM_REQUIRE((P & 7) == 0, "fuse_points: the point count must be a multiple of 8 (a wave's 8 points share one view's homography)");
   const unsigned g = (unsigned)((total + 255) / 256);
   if (dtype == BF16)
     hipLaunchKernelGGL((fuse_points_kernel<unsigned short, true>), dim3(g), dim3(256), 0, s, (const unsigned short*)feat,

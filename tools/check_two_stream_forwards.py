@@ -1,32 +1,21 @@
-"""Reproducer (round 4, OPEN): two forwards that OVERLAP on the device — the halves of a batch on two HIP streams, each with its own
-workspace, one handle or two — intermittently differ from the one-stream forward, in the outputs of the depth-guided fusion only
-(fuse_points_kernel's 32 channels of PF96 -> view*_r / _t / _s; a few per cent, pairs of points 4k + 2, 4k + 3 of the first ~25 views of
-a part, never NaN).  What is established (each line one gpurun experiment, MI355X, ROCm 7.2):
-  * 14-19 of 25 runs differ with one handle, 14-18 of 25 with two; 0 of 25 when the host synchronises between the two launches sequences,
-    0 of 25 with GPU_MAX_HW_QUEUES=1 (both streams on one hardware queue);
-  * every input of the fusion (prob, feat, homog, choose, depths) is bit-identical to the reference after the forward, and a checksum
-    kernel placed in front of the fusion sees the final prob; launching the fusion twice back to back repairs most runs (4 of 25 left);
-  * a build of the kernel without its cross-lane shuffle fails at the same rate: not its arithmetic;
-  * no other kernel's output ever differed;
-  * which part of the OTHER forward interferes: its PSPNet alone (three back to back) 0 of 20 runs, through its cost volume 11-19 of 20 in
-    every configuration of that stage (plane-sweep kernel or halo-tile conv0, sparse or dense tail / 3-D stack): nothing specific to one kernel;
-  * a numpy restatement of the fusion reproduces the one-stream values exactly from the tapped inputs; the wrong values match none of: the other
-    part's prob / homography, a neighbouring point's prob, any of the 512 homographies in either workspace — they look like the right computation
-    with some registers of lanes 16-31 / 48-63 disturbed (points 4k + 2, 4k + 3 = those lane rows of a wave) in the blocks resident when the
-    kernel starts, which is what a fault in saving / restoring waves under queue time-slicing would look like; not verified.
-  * hashes taken INSIDE the kernel (debug build, compared with a one-stream run): for every wrong point the pixel, the prob row, the depth values and
-    the homography as re-read at the end of the kernel are the reference's, and so are the twelve homography words and the depth as first loaded — but the
-    warp coordinates (ix, iy) computed from them at the start of the kernel differ (and with them the sampled features).  The same coordinates evaluated
-    twice in one wave through one `noinline` function, once at the start and once at the end of the kernel, differ from each other in the affected
-    lanes (x, y equal both times; e.g. ix 472.39 early, 477.13 late): what the first instructions of those waves computed or loaded is what is off, and
-    only in lane rows 16-31 / 48-63.  Builds with approximate divisions, without the shuffle, with the kernel at 2 workgroups per CU (one stream): no change
-    / no reproduction.  A stand-alone pair of kernels (`tools/micro/valu_under_mfma.hip`: the same arithmetic re-evaluated next to MFMA / VALU / LDS + MFMA
-    co-tenants on another stream) shows 0 differing evaluations: the co-tenant alone is not it either.  A watcher kernel polling this part's homography
-    through L2 during the overlapped forwards never saw a word change.
-  * not leftover register contents: a kernel that leaves a junk pattern in v8-v119 / s20-s89 of every SIMD, launched in front of the fusion on one
-    stream, changes nothing.
-Not root-caused.  Forwards are therefore issued one at a time per device (the library's tests and every bench figure except the
-`two_streams` leg do that); bench.py checks that leg's outputs and reports `outputs_bit_identical_to_one_stream`.
+"""Two forwards that OVERLAP on the device — the halves of a batch on two HIP streams, each with its own workspace, one handle or two —
+against the one-stream forward.  Round 4 history:
+  * with `fuse_points_kernel` loading its view's homography through per-lane vector loads (rounds 1-3), 14-19 of 25 overlapped runs differed from the
+    one-stream forward in view*_r / _t / _s (a few per cent on pairs of points 4k + 2, 4k + 3 = lane rows 16-31 / 48-63 of a wave, in the blocks
+    resident when the kernel starts, never NaN); 0 of 25 with a host synchronisation between the two launch sequences or with GPU_MAX_HW_QUEUES=1;
+  * hashes taken inside the kernel (debug builds): pixel, prob row, depth values and the homography as re-read at the END of the kernel were the
+    reference's, the warp coordinates computed from the homography words loaded at the START were not; the same coordinates evaluated twice in one wave
+    through one `noinline` function (start / end of the kernel) differed from each other in the affected lanes;
+  * not the arithmetic (approximate divisions, no shuffle: same rate), not occupancy (2 workgroups per CU on one stream: no reproduction), not leftover
+    registers (a register-poisoning kernel in front: no change), not one particular co-tenant kernel (every configuration of the other forward's cost
+    volume stage interferes, its PSPNet alone does not), not reproducible stand-alone (`tools/micro/valu_under_mfma.hip`), a watcher polling the
+    homography through L2 never saw a word change;
+  * with the homography loaded through the scalar cache (one wave = one view: `readfirstlane`, the shipped form since) the mismatch is gone in bf16
+    (0 of 60 overlapped runs) and bf16x3 (0 of 30).  fp16 nets still differ when overlapped (9-13 of 15 runs, depth outputs included: another kernel
+    of the fp16 cost volume is affected the same way).  Why per-lane vector loads of a small read-only record return other values in half of the
+    lane rows while another queue's kernels run is not established.
+Forwards are therefore still issued one at a time per device (every test, the plugin and every bench figure but the `two_streams` leg do); bench.py
+checks that leg's outputs and reports `outputs_bit_identical_to_one_stream` (true for bf16 / bf16x3 since the scalar loads).
 usage: python tools/check_two_stream_forwards.py [dtype] [runs]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
