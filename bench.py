@@ -128,7 +128,8 @@ def tree_hash():
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.cpp")) +
-                   glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.inc")))
+                   glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "rgbmanip_amd", "csrc", "*.inc")) +
+                   [os.path.join(ROOT, "rgbmanip_amd", "csrc", "build.sh")])      # the compiler flags are part of what was measured
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

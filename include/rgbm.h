@@ -9,11 +9,8 @@
  * all `*_dev` / device pointers are HIP device memory owned by the caller (e.g. the PyTorch caching allocator);
  * all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) with no hidden
  * synchronisation; handles own only their packed weights; a handle is not thread-safe, distinct handles are.
- * Forwards are to be issued ONE AT A TIME PER DEVICE: two rgbm_adapose_forward calls whose kernels overlap on the GPU (two streams,
- * one handle or two) were seen to differ intermittently from the one-stream result (round 4: gone for bf16 / bf16x3 nets since one
- * kernel loads a small record through the scalar cache, still there for fp16 nets, mechanism not understood:
- * tools/check_two_stream_forwards.py).  Copies, the prepare kernels and the PPO / control entry points on other
- * streams are used concurrently with a forward by the plugin (estimator.py) and are covered by its bit-identity tests.
+ * Forwards on different streams may overlap on the device (round 4: they differed intermittently from the one-stream result until the library was
+ * built without packed fp32 instructions; tools/check_two_stream_forwards.py is the regression check, DESIGN.md section 5d has the finding).
  * dtype: 0 = fp32 (exact-fp32 MFMA, the parity gate), 1 = bf16 storage + fp32 accumulate (throughput mode).
  */
 #ifndef RGBM_H_

@@ -183,11 +183,10 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
     // zero padding): four independent reads per depth instead of four dependent branches.
     const int lane = threadIdx.x & 63, grp = lane & ~7;
     float cix[3], ciy[3];                                   // D <= 24
-    // The 64 lanes of a wave belong to one view (P is a multiple of 8): the view's homography comes through the scalar cache
-    // into SGPRs (one s_load instead of three vector loads per lane).  Round 4: with the per-lane vector loads of this record, forwards that
-    // overlapped on the device (two streams) intermittently computed other warp coordinates in lanes 16-31 / 48-63 of the first
-    // resident blocks from registers that hashed to the right values afterwards; with the scalar form the mismatch is gone
-    // (tools/check_two_stream_forwards.py: 0 of 50 runs against 14-19 of 25).  Cause of the wrong vector loads: not established.
+    // The 64 lanes of a wave belong to one view (P is a multiple of 8): the view's homography comes through the scalar cache into SGPRs
+    // (one s_load instead of three vector loads per lane).  Round 4: with per-lane vector loads of this record hipcc fed the just-loaded
+    // registers into packed fp32 instructions, which computed from other values in lane rows 16-31 / 48-63 whenever another stream's
+    // kernels shared the CU (the library is built without packed fp32 instructions since).
     const float* hmv = homog + (long long)__builtin_amdgcn_readfirstlane(v) * 12;      // launch_fuse_points requires P % 8 == 0
 #pragma unroll
     for (int q = 0; q < 3; ++q) {

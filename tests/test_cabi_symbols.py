@@ -51,3 +51,29 @@ def test_sweep_asm_gathers_keep_their_registers(src):
                         os.path.join(root, "rgbmanip_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "plane loop lines" in r.stdout
+
+
+def test_shipped_kernels_hold_no_packed_fp32_instructions(tmp_path):
+    """Round 4: hipcc's v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 on registers a global_load had just delivered computed from other
+    values in half of the lane rows when two forwards overlapped on the device; the library is built without packed-fp32 instructions
+    (build.sh: -target-feature -packed-fp32-ops).  The code objects inside the built .so must hold none."""
+    import glob
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "rgbmanip_amd", "librgbm_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(so)):
+        pytest.skip("needs llvm-objdump and the built library")
+    work = os.path.join(str(tmp_path), "librgbm_hip.so")
+    shutil.copy(so, work)
+    subprocess.run([objdump, "--offloading", work], check=True, capture_output=True, timeout=600)
+    objs = glob.glob(work + ".*gfx950")
+    assert len(objs) >= 10, objs
+    packed, mfma = 0, 0
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True, timeout=600).stdout
+        packed += sum(1 for line in dis.splitlines() if "v_pk_" in line and "_f32" in line)
+        mfma += dis.count("v_mfma")
+    assert mfma > 1000                         # the disassembly is the real thing
+    assert packed == 0, f"{packed} packed-fp32 instructions in the shipped kernels"

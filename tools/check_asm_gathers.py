@@ -79,7 +79,9 @@ if __name__ == "__main__":
     src = sys.argv[1]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-S",
+        # the flags of rgbmanip_amd/csrc/build.sh (incl. no packed-fp32 instructions): the ISA that is checked is the ISA that ships
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Xclang", "-target-feature",
+                               "-Xclang", "-packed-fp32-ops", "-S",
                                "--cuda-device-only", os.path.abspath(src), "-o", out] + sys.argv[2:], cwd=os.path.dirname(os.path.abspath(src)))
         f = check(open(out).read())
     for x in f:

@@ -1,21 +1,26 @@
 """Two forwards that OVERLAP on the device — the halves of a batch on two HIP streams, each with its own workspace, one handle or two —
-against the one-stream forward.  Round 4 history:
-  * with `fuse_points_kernel` loading its view's homography through per-lane vector loads (rounds 1-3), 14-19 of 25 overlapped runs differed from the
-    one-stream forward in view*_r / _t / _s (a few per cent on pairs of points 4k + 2, 4k + 3 = lane rows 16-31 / 48-63 of a wave, in the blocks
-    resident when the kernel starts, never NaN); 0 of 25 with a host synchronisation between the two launch sequences or with GPU_MAX_HW_QUEUES=1;
-  * hashes taken inside the kernel (debug builds): pixel, prob row, depth values and the homography as re-read at the END of the kernel were the
-    reference's, the warp coordinates computed from the homography words loaded at the START were not; the same coordinates evaluated twice in one wave
-    through one `noinline` function (start / end of the kernel) differed from each other in the affected lanes;
-  * not the arithmetic (approximate divisions, no shuffle: same rate), not occupancy (2 workgroups per CU on one stream: no reproduction), not leftover
-    registers (a register-poisoning kernel in front: no change), not one particular co-tenant kernel (every configuration of the other forward's cost
-    volume stage interferes, its PSPNet alone does not), not reproducible stand-alone (`tools/micro/valu_under_mfma.hip`), a watcher polling the
-    homography through L2 never saw a word change;
-  * with the homography loaded through the scalar cache (one wave = one view: `readfirstlane`, the shipped form since) the mismatch is gone in bf16
-    (0 of 60 overlapped runs) and bf16x3 (0 of 30).  fp16 nets still differ when overlapped (9-13 of 15 runs, depth outputs included: another kernel
-    of the fp16 cost volume is affected the same way).  Why per-lane vector loads of a small read-only record return other values in half of the
-    lane rows while another queue's kernels run is not established.
-Forwards are therefore still issued one at a time per device (every test, the plugin and every bench figure but the `two_streams` leg do); bench.py
-checks that leg's outputs and reports `outputs_bit_identical_to_one_stream` (true for bf16 / bf16x3 since the scalar loads).
+against the one-stream forward: a regression check since round 4, when they differed.  What was found (each line one or more gpurun experiments):
+  * symptom (library built with hipcc's defaults): 14-19 of 25 overlapped runs differed from the one-stream forward in view*_r / _t / _s (fp16 nets:
+    depth outputs too) — a few per cent on pairs of points 4k + 2, 4k + 3 = lane rows 16-31 / 48-63 of a wave, in the blocks resident when a kernel
+    starts, never NaN; 0 of 25 with a host synchronisation between the two launch sequences or with GPU_MAX_HW_QUEUES=1; one-stream forwards always
+    bit-stable (510 repeated runs);
+  * localisation: hashes taken inside `fuse_points_kernel` (debug builds) showed pixel, prob row, depth values and the homography as re-read at the END
+    of the kernel to be the reference's, while the warp coordinates computed from the homography words loaded at the START were not; the same coordinates
+    evaluated twice in one wave through one `noinline` function (start / end of the kernel) differed from each other in the affected lanes;
+  * ruled out: the divisions (approximate ones: same rate), the cross-lane shuffle, occupancy (2 workgroups per CU on one stream: no reproduction),
+    leftover register contents (register-poisoning kernel in front), one particular co-tenant kernel (every configuration of the other forward's cost
+    volume stage interferes, its PSPNet alone does not), memory contents (a watcher polling the homography through L2 never saw a word change), a
+    stand-alone pair of kernels (`tools/micro/valu_under_mfma.hip`);
+  * the instruction: in that kernel hipcc feeds the just-loaded homography registers (`global_load_dwordx4`, the correct `s_waitcnt vmcnt(n)` in front)
+    into PACKED fp32 instructions (`v_pk_mul_f32` / `v_pk_fma_f32` / `v_pk_add_f32`).  The same source with the per-lane vector loads kept and packed
+    fp32 instructions disabled (`-Xclang -target-feature -Xclang -packed-fp32-ops`): 0 of 60 overlapped runs; with them: 16 of 20.  Loading the record
+    through the scalar cache (SGPR operands) also removed it in that kernel, but fp16 nets kept differing until the WHOLE library was built without
+    packed fp32 instructions: then bf16 0 of 40, bf16x3 0 of 24, fp16 0 of 40 overlapped runs.
+So: on this part and toolchain (MI355X, ROCm 7.2 hipcc) a packed-fp32 VALU instruction that consumes registers a vector memory load has just delivered can
+compute from other values in half of the lane rows while kernels of another hardware queue share the CU.  The library is built without packed fp32
+instructions (build.sh; they bought nothing: same-box A/B within 0.3 %), tests/test_cabi_symbols.py asserts the shipped code objects hold none, and
+`fuse_points_kernel` keeps the scalar load (one instruction instead of three per lane).  bench.py's `two_streams` leg compares its outputs with the
+one-stream forward (`outputs_bit_identical_to_one_stream`).
 usage: python tools/check_two_stream_forwards.py [dtype] [runs]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
