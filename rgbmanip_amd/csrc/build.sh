@@ -15,7 +15,7 @@ FLAGS="$FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops"
 # 256 x 128 tile, register-staged implicit GEMM: all measured slower than what ships; debug flags 8192 / 131072 / 4 select them)
 if [ "${RGBM_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DRGBM_EXPERIMENTS"; fi
 echo "$FLAGS" > build/.flags.new 2>/dev/null || true
-if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o; cp build/.flags.new build/.flags; fi
+if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o build/*.asm_ok; cp build/.flags.new build/.flags; fi      # new flags: everything is rebuilt AND the sweep kernels' ISA is re-checked
 pids=()
 for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv0_sweep_x3.hip prob_sparse.hip misc_kernels.hip bn_kernels.hip upconv.hip upconv_final.hip stem.hip head_kernels.hip postproc.hip prepare.hip ppo_kernels.hip policy_kernels.hip control.hip synth_env.hip align.hip pnp.hip microbench.hip; do
   [ -f "$f" ] || continue
@@ -36,7 +36,7 @@ done
 # was recompiled; a finding fails the build.
 chk=()
 for f in conv0_sweep.hip conv0_sweep_x3.hip; do
-  if [ ! -f build/${f%.hip}.asm_ok ] || [ "$f" -nt build/${f%.hip}.asm_ok ] || [ common.h -nt build/${f%.hip}.asm_ok ]; then
+  if [ ! -f build/${f%.hip}.asm_ok ] || [ "$f" -nt build/${f%.hip}.asm_ok ] || [ common.h -nt build/${f%.hip}.asm_ok ] || [ ../../tools/check_asm_gathers.py -nt build/${f%.hip}.asm_ok ] || [ build.sh -nt build/${f%.hip}.asm_ok ]; then
     ( python3 ../../tools/check_asm_gathers.py "$f" > build/${f%.hip}.asm_log 2>&1 && touch build/${f%.hip}.asm_ok ) &
     chk+=("$!:$f")
   fi

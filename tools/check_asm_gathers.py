@@ -45,7 +45,16 @@ def check(asm_text):
         cands = [(y - x, x, y) for x, y in loops if sum(is_gather(l) for l in body[x:y + 1]) >= 16]
         if not cands:
             continue
-        _, x, y = min(cands)                     # the innermost such loop: the producers' plane loop
+        # the innermost such loop is the producers' plane loop.  "Innermost" by LLVM's own loop-depth comment on the header label (hipcc may lay
+        # the body of an inner loop out BEHIND the back edge of its parent, so that the two line ranges are disjoint and the shorter one is the
+        # parent's prologue); ties: the shorter range
+        def depth(x):
+            for l in body[x:x + 3]:              # "=>This Inner Loop Header: Depth=2" or "in Loop: Header=BB0_37 Depth=1", on or right under the label
+                m = re.search(r'Depth=(\d+)', l)
+                if m:
+                    return int(m.group(1))
+            return 0
+        _, _, x, y = min((-depth(x), span, x, y) for span, x, y in cands)
         inside = [l.split()[1].rstrip(',') for l in body[x:y + 1] if is_gather(l)]
         dest = set()
         for t in inside:
