@@ -23,7 +23,8 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, "bf16": _lib.
 class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
                  cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None,
-                 norm_mode: int | str = 0, poison_workspace: bool = False, graph: bool = False, graph_max_batch: int = 32):
+                 norm_mode: int | str = 0, poison_workspace: bool = False, graph: bool = False, graph_max_batch: int = 32,
+                 split_streams: bool = False, split_min_batch: int = 128):
         self.lib = _lib.load()
         # graph: forwards of at most `graph_max_batch` poses are replayed from a hipGraph captured per batch size
         # (rgbm_adapose_forward_graph): static input / output / workspace buffers per batch size, one hipGraphLaunch instead of ~150
@@ -38,6 +39,15 @@ class AdaPoseNet:
         # that a kernel reading a tile the sparse cost regularisation skipped — or anything else a forward did not write itself —
         # cannot find a previous run's (correct) values there (tests/test_gpu_at_batch.py, bench.py's at-batch check)
         self.poison_workspace = bool(poison_workspace)
+        # split_streams (opt-in): a forward of at least `split_min_batch` (even) poses runs as two half batches on two side streams, each with
+        # its own workspace: the tail of every launch of one half (partial last round of workgroups, the drain of a persistent kernel) is
+        # filled by the other half's kernels (-0.7 % bf16, -2.6 % bf16x3 at batch 256).  Same kernels, same per-pose arithmetic:
+        # outputs bit-identical to the one-stream forward (tests/test_gpu_at_batch.py) — which needs a library without packed fp32
+        # instructions (build.sh).  Intermediate taps (fetch) refer to the one-stream workspace and are refused after a split forward.
+        self.split_streams = bool(split_streams)
+        self.split_min_batch = int(split_min_batch)
+        self._split = None                           # ([two side streams], [two workspaces], batch)
+        self._last_split = False
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -169,6 +179,10 @@ class AdaPoseNet:
             "view1_t": torch.empty(B, 3, **f32), "view2_t": torch.empty(B, 3, **f32),
             "view1_s": torch.empty(B, 3, **f32), "view2_s": torch.empty(B, 3, **f32),
         }
+        if self.split_streams and stop_after == 0 and B >= self.split_min_batch and B % 2 == 0:
+            self._forward_split(B, (img1, img2, ch1, ch2, P1, P2, dep), out, stream)
+            return out
+        self._last_split = False
         o = _lib.AdaposeOut(*[out[n].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
         ws_ptr, ws_bytes = self._workspace(B)
         if self.poison_workspace:
@@ -180,10 +194,42 @@ class AdaPoseNet:
         self._last = (img1, img2, ch1, ch2, P1, P2, dep)     # keep inputs alive until the stream has consumed them
         return out
 
+    def _forward_split(self, B, args, out, stream):
+        h = B // 2
+        if self._split is None or self._split[2] != B:
+            self._split = None
+            need = self.workspace_bytes(h) + 256
+            self._split = ([torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)],
+                           [torch.empty(need, dtype=torch.uint8, device=self.device) for _ in range(2)], B)
+        side, wss, _ = self._split
+        cur = stream if stream is not None else torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        for i in (0, 1):
+            si, ws = side[i], wss[i]
+            si.wait_event(fork)                       # inputs (and the previous use of the outputs) are ordered on `cur`
+            off = (-ws.data_ptr()) % 256
+            if self.poison_workspace:
+                with torch.cuda.stream(si):
+                    ws.fill_(0xFF)
+            sl = slice(i * h, (i + 1) * h)
+            o = _lib.AdaposeOut(*[out[n][sl].data_ptr() for n, _ in _lib.AdaposeOut._fields_])
+            a = [t[sl] for t in args]                  # leading-dimension slices of contiguous tensors: contiguous views
+            _lib.check(self.lib.rgbm_adapose_forward_ex(self._h, h, *[_lib.ptr(t) for t in a], C.c_void_p(ws.data_ptr() + off),
+                                                        ws.numel() - off, C.byref(o), 0, _lib.stream_ptr(si)), "rgbm_adapose_forward")
+        for si in side:
+            join = torch.cuda.Event()
+            join.record(si)
+            cur.wait_event(join)
+        self._last = args
+        self._last_split = True
+
     __call__ = forward
 
     def fetch(self, B: int, name: str, max_elems: int) -> torch.Tensor:
         """Debug/test access to a named intermediate of the last forward (fp32, flat)."""
+        if self._last_split:
+            raise _lib.RgbmError("fetch: the last forward ran as two half batches (split_streams); run it with split_streams=False for taps")
         buf = torch.empty(max_elems, dtype=torch.float32, device=self.device)
         n = C.c_size_t()
         ws_ptr, _ = self._workspace(B)

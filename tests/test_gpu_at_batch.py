@@ -218,6 +218,24 @@ def test_forward_is_bit_stable_at_bench_shape(inputs256, dtype, B, reps):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "fp16"])
+def test_overlapping_half_batches_equal_the_one_stream_forward(inputs256, dtype):
+    """AdaPoseNet(split_streams=True) runs a batch as two half batches on two HIP streams (their kernels overlap on the device).  All ten
+    outputs must equal the one-stream forward bit for bit, run after run (poisoned workspaces): with hipcc's packed fp32 instructions in
+    the library they intermittently did not (14-19 of 25 runs; the library is built without them, tests/test_cabi_symbols.py
+    checks the shipped code objects).  12 overlapped forwards per storage type."""
+    args = _dev_inputs(inputs256, B_FULL)
+    ref = {k: v.clone() for k, v in _forward(_net(dtype), args).items()}
+    net = _net(dtype, poison_workspace=True, split_streams=True)
+    bad = []
+    for r in range(12):
+        cur = _forward(net, args)
+        bad += [(r, k, float((ref[k] - cur[k]).abs().max())) for k in OUT_KEYS if not torch.equal(ref[k].view(torch.int32), cur[k].view(torch.int32))]
+    assert net._last_split and not bad, bad[:10]
+    with pytest.raises(Exception, match="split_streams"):
+        net.fetch(B_FULL, "prob", 16)
+
+
 def test_mixed_object_rank_workload_of_2048_pose_batch():
     """BASELINE configs[4] as one of its 8 ranks sees it: a 2048-pose batch with interleaved heads, sorted by head and cut into
     8 contiguous shards -> rank 5 owns 256 poses of ONE head; its `MixedObjectNet` result in fp16 must be bit-identical to that
