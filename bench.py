@@ -590,8 +590,8 @@ def main():
         torch.cuda.current_stream(device).wait_stream(st2[1])
         torch.cuda.synchronize()
         # the overlapped forwards against the one-stream forward of the timed step (same inputs): a throughput figure whose outputs differ
-        # is not a result.  (Round 4: forwards that overlap on the device were seen to differ intermittently in the depth-guided fusion,
-        # tools/check_two_stream_forwards.py)
+        # is not a result.  (Round 4: with hipcc's packed fp32 instructions in the library, forwards that overlapped on the device differed
+        # intermittently; it is built without them since — tools/check_two_stream_forwards.py)
         differing = sorted({k for o in last2 for k in ref2 if not torch.equal(o[k].view(torch.int32), ref2[k].view(torch.int32))})
         two_res = {"poses_per_sec": round(B / t2, 1), "ms_per_step": round(t2 * 1e3, 2),
                    "outputs_bit_identical_to_one_stream": not differing, "differing_outputs": differing,
