@@ -10,7 +10,8 @@ against the one-stream forward: a regression check since round 4, when they diff
   * ruled out: the divisions (approximate ones: same rate), the cross-lane shuffle, occupancy (2 workgroups per CU on one stream: no reproduction),
     leftover register contents (register-poisoning kernel in front), one particular co-tenant kernel (every configuration of the other forward's cost
     volume stage interferes, its PSPNet alone does not), memory contents (a watcher polling the homography through L2 never saw a word change), a
-    stand-alone pair of kernels (`tools/micro/valu_under_mfma.hip`);
+    stand-alone pair of kernels (`tools/micro/valu_under_mfma.hip`; later also `tools/micro/pk_after_load.hip`: a hand-written `v_pk_mul_f32` right behind the
+    counted wait of cache-cold loads, 0 of 335 M lanes off next to MFMA / copy co-tenants — the minimal pattern alone does not reproduce it);
   * the instruction: in that kernel hipcc feeds the just-loaded homography registers (`global_load_dwordx4`, the correct `s_waitcnt vmcnt(n)` in front)
     into PACKED fp32 instructions (`v_pk_mul_f32` / `v_pk_fma_f32` / `v_pk_add_f32`).  The same source with the per-lane vector loads kept and packed
     fp32 instructions disabled (`-Xclang -target-feature -Xclang -packed-fp32-ops`): 0 of 60 overlapped runs; with them: 16 of 20.  Loading the record
