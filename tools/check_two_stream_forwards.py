@@ -17,6 +17,7 @@ against the one-stream forward: a regression check since round 4, when they diff
     fp32 instructions disabled (`-Xclang -target-feature -Xclang -packed-fp32-ops`): 0 of 60 overlapped runs; with them: 16 of 20.  Loading the record
     through the scalar cache (SGPR operands) also removed it in that kernel, but fp16 nets kept differing until the WHOLE library was built without
     packed fp32 instructions: then bf16 0 of 40, bf16x3 0 of 24, fp16 0 of 40 overlapped runs.
+To bring the failure back on demand: tools/patches/README.md (a patch with the vector loads + a build with packed instructions: 13 of 20 runs differ).
 So: on this part and toolchain (MI355X, ROCm 7.2 hipcc) a packed-fp32 VALU instruction that consumes registers a vector memory load has just delivered can
 compute from other values in half of the lane rows while kernels of another hardware queue share the CU.  The library is built without packed fp32
 instructions (build.sh; they bought nothing: same-box A/B within 0.3 %), tests/test_cabi_symbols.py asserts the shipped code objects hold none, and
