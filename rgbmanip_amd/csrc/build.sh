@@ -22,7 +22,7 @@ for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv
   EXTRA=""
   # files that must round like numpy / torch elementwise ops: no mul+add -> fma contraction
   case "$f" in postproc.hip|ppo_kernels.hip|prepare.hip|control.hip|synth_env.hip|align.hip|pnp.hip|misc_kernels.hip|bn_kernels.hip) EXTRA="-ffp-contract=off";; esac
-  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ] || [ conv_igemm_experiments.inc -nt build/${f%.hip}.o ] || [ conv3d_tile_table.h -nt build/${f%.hip}.o ] || [ control.h -nt build/${f%.hip}.o ] || [ bbox_emit.h -nt build/${f%.hip}.o ] || [ build.sh -nt build/${f%.hip}.o ]; then
+  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ] || [ conv_igemm_experiments.inc -nt build/${f%.hip}.o ] || [ conv_igemm_m32.inc -nt build/${f%.hip}.o ] || [ conv3d_tile_table.h -nt build/${f%.hip}.o ] || [ control.h -nt build/${f%.hip}.o ] || [ bbox_emit.h -nt build/${f%.hip}.o ] || [ build.sh -nt build/${f%.hip}.o ]; then
     hipcc $FLAGS $EXTRA -c "$f" -o build/${f%.hip}.o &
     pids+=($!)
   fi

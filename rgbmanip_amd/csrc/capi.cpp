@@ -520,6 +520,7 @@ extern "C" int rgbm_set_tuning(const char* key, long long value) {
   RGBM_REQUIRE(key != nullptr, "set_tuning arguments");
   const std::string k = key;
   if (k == "ws_min_rows") { RGBM_REQUIRE(value >= 0, "ws_min_rows"); rgbm::g_ws_min_rows = value; }
+  else if (k == "gemm_kernel") { RGBM_REQUIRE(value >= 0 && value <= 2, "gemm_kernel"); rgbm::g_gemm_kernel = (int)value; }
   else { set_error("unknown tuning key " + k); return -1; }
   ++rgbm::g_tuning_version;
   return 0;

@@ -238,6 +238,9 @@ struct ConvDesc {
   // persistent kernel only (filled by its launcher): tiles in total, and exact-division magics for Wq, Hq, Dq
   int n_tiles; unsigned fd_m[3]; int fd_s[3];
   int korder;                             // K-tile walk of the request waves: 1 = channel block outer, taps inner; 0 = taps outer
+  int buf_ok;                             // request waves may use 32-bit buffer offsets for both operands (set by the launcher)
+  const void* ident;                      // conv_igemm_m32_kernel<256 pixels>: 256 x 256 identity in the storage type (residual steps), set by the launcher
+  long long m0;                           // first GEMM row of this launch (conv_igemm_m32_kernel: a layer split into a main and a tail launch)
   // optional 1x1 conv fused behind the activation (conv_igemm_ws64_kernel only): y2 = act2(W2 . act(y) + bias2); when set,
   // `out` is not written.  w2: [cout2_pad][kpad2] K-major bf16 rows of 64 input channels.
   const void* w2; const float* bias2; void* out2; int ldo2, cout2, kpad2, act2; float slope2;

@@ -4,7 +4,10 @@
 // is needed.  The LDS image of a tile is lane-linear (wave-uniform base + lane*16 bytes), therefore the bank-conflict
 // swizzle is applied on the SOURCE side: the lane that fills LDS slot (row, j) fetches global chunk j ^ ((row>>1)&7),
 // and readers XOR the same value (an involution).  Out-of-image / padded-K lanes fetch from a 16-byte zero page.
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "prof.h"
 
@@ -13,6 +16,9 @@
 #endif
 #ifndef W256_ABL
 #define W256_ABL 0    // experiment builds of the 256 x 256 kernel: 1 = no MFMA, 2 = no LDS-DMA, 4 = no fragment reads, 8 = no setprio
+#endif
+#ifndef WS_BUF
+#define WS_BUF 1      // request waves of the persistent kernels: LDS-DMA through buffer descriptors (blds16) where the operands fit 32-bit offsets
 #endif
 #ifndef IG_ABL
 #define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too,
@@ -23,6 +29,9 @@ namespace rgbm {
 
 extern int g_debug_flags;
 extern long long g_ws_min_rows;
+// kernel of the 256-channel x 128-pixel launches (layer3 / layer4 / up_1), rgbm_set_tuning("gemm_kernel"): 0 = conv_igemm_ws_kernel
+// (16x16x32 MFMAs, 8 multiply waves, 256 x 128 tile), 1 = conv_igemm_m32_kernel<256 x 128>, 2 = conv_igemm_m32_kernel<256 x 256> (default)
+int g_gemm_kernel = 2;
 __device__ uint4 g_zero_page[4];     // zero-initialised device memory: the source of every padded chunk
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -40,6 +49,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
   return;
 #endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_off) : "memory");
+}
+// one LDS-DMA piece through a buffer descriptor: lane address = base + voff + soff (soff is not part of the range check: a lane whose
+// voff is >= num_records reads nothing and delivers zeros).  tools/micro/cu_fill_rate.hip: one wave sustains 37-43 GB/s of 1 KiB pieces
+// this way against 27-32 GB/s with 64-bit global addresses, four waves 120-144 against 104-114
+__device__ __forceinline__ void blds16(unsigned voff, const __amdgpu_buffer_rsrc_t& rsrc, unsigned soff, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_off) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
@@ -816,6 +831,16 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     int tkd = 0, tkh = 0, tkw = 0, tc = 0;   // wave-uniform tap walker
     long long wko = 0;                       // byte offset of the walker's K index in a weight row
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds3 + pw * 64));      // this wave's first piece, stage 0
+    // buffer form of the requests (d.buf_ok, set by the launcher when both operands fit 32-bit offsets): X offsets are taken from
+    // (input base - xbias) so that a row whose tap (0,0,0) lies in the padding still has a non-negative offset
+    const bool use_buf = WS_BUF && d.buf_ok;
+    const long long xbias = ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.Cin * (long long)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(d.in)) - xbias, 0,
+        (int)(unsigned)((long long)d.N * d.Di * d.Hi * d.Wi * d.Cin * (long long)sizeof(T) + xbias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(d.wgt)), 0, (int)(unsigned)((long long)d.n_ch_tiles * BCH * d.Kpad * (long long)sizeof(T)), 0x00020000);
+    unsigned xoff[XR], woff[WL];
 
     // The eight lanes (r0, j = 0..7) of a row group need the same XR row descriptors (GEMM rows r0 + 32*i): lane j decodes
     // row i = j once and the group exchanges them, instead of every lane decoding all XR rows (3 divisions, 7 bound tests and
@@ -857,11 +882,13 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
         const long long b = __shfl(mybase, grp | i, 64);
         rmask[i] = (unsigned)__shfl((int)mymask, grp | i, 64);
         rowp[i] = reinterpret_cast<const char*>(in) + b + (long long)(js * E) * (long long)sizeof(T);
+        xoff[i] = (unsigned)(b + xbias + (long long)(js * E) * (long long)sizeof(T));
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
         const int row = r0 + 32 * i;
         wrow[i] = reinterpret_cast<const char*>(wgt + (long long)(my_ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E);
+        woff[i] = (unsigned)(((long long)(my_ch_tile * BCH + row) * d.Kpad + (j ^ swz_w(row)) * E) * (long long)sizeof(T));
       }
       tkd = tkh = tkw = tc = 0;
       wko = 0;
@@ -876,6 +903,15 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
       const long long soff =
           ((long long)((tkd * d.dild * d.Hi + tkh * d.dilh) * d.Wi + tkw * d.dilw) * d.Cin + tc) * (long long)sizeof(T);
       const bool cok = tkd < d.KD && tc + js * E < d.Cin;
+      if (use_buf) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+          const bool ok = cok && (rmask[i] & sel) == sel;
+          blds16(ok ? xoff[i] : 0xffffffffu, rsrc_x, (unsigned)soff, sbase + (BCH * 8 + i * 256) * 16);      // X rows 32*i + 8*pw .. +7
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) blds16(woff[i], rsrc_w, (unsigned)wko, sbase + (i * 256) * 16);       // W rows 32*i + 8*pw .. +7
+      } else {
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
@@ -884,6 +920,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) glds16((IG_ABL & 4) ? zero : wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
+      }
       if (d.korder && d.lcin >= 0) {
         // channel block outer, taps inner: the taps of one channel block read the same pixel rows shifted by a few rows / columns,
         // so between two uses of a cache line the XCD touches one channel block of its 32 tiles (~0.6 MB) instead of every channel
@@ -1317,6 +1354,13 @@ static void make_fastdiv(int dvs, unsigned& m, int& sh) {
   m = (unsigned)(((1ull << sh) + (unsigned long long)dvs - 1ull) / (unsigned long long)dvs);
 }
 
+// both operands addressable with 32-bit byte offsets from one buffer descriptor each (the request waves' blds16 form)
+static bool conv_buffer_offsets_ok(const ConvDesc& d, int bch, size_t esz) {
+  const long long xbytes = ((long long)d.N * d.Di * d.Hi * d.Wi + (long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.Cin * (long long)esz;
+  const long long wbytes = (long long)((d.Cout + bch - 1) / bch) * bch * d.Kpad * (long long)esz;
+  return xbytes < (1ll << 32) - 65536 && wbytes < (1ll << 32) - 65536 && d.pd >= 0 && d.ph >= 0 && d.pw >= 0;
+}
+
 template <typename T, bool WIDE, bool RH, bool SLIM = false>
 static int launch_ws(ConvDesc d, hipStream_t s) {
   constexpr int BCH = SLIM ? 64 : WIDE ? 256 : 128, BPIX = (WIDE && !SLIM) ? 128 : 256;
@@ -1330,6 +1374,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   d.korder = (g_debug_flags & (1 << 20)) ? 0 : 1;          // debug flag 1048576: taps outer, channels inner (the order before round 3) for A/B
+  d.buf_ok = conv_buffer_offsets_ok(d, BCH, sizeof(T)) && !(g_debug_flags & (1 << 25));      // debug flag 33554432: 64-bit global addresses + zero page (A/B)
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), (int)LDS)) return rc;
   int n_cu = 0;
   if (int rc = persistent_grid_cus(&n_cu)) return rc;
@@ -1340,6 +1385,8 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+#include "conv_igemm_m32.inc"      // 256 x 128 tile on 32x32x16 MFMAs, one multiply wave per SIMD (tuning key gemm_kernel)
 
 #ifdef RGBM_EXPERIMENTS      // experiment kernels (slower than the shipped ones; kept with their parity tests): build with RGBM_EXPERIMENTS=1 build.sh
 #include "conv_igemm_experiments.inc"
@@ -1926,6 +1973,11 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
           if ((g_debug_flags & 131072) && conv_rowhalo_ok(d) && d.Kpad == 9 * d.Cin && d.KT == 9 * (d.Cin >> 6)) return launch_ws<T, true, true>(d, s);
         }
 #endif
+        if constexpr (sizeof(T) == 2) {
+          if (conv_buffer_offsets_ok(d, 256, sizeof(T))) {      // its request waves address both operands through 32-bit buffer offsets
+            if (g_gemm_kernel >= 1) return launch_m32<T>(d, s, g_gemm_kernel);
+          }
+        }
         return launch_ws<T, true, false>(d, s);
       }
       return launch_ws<T, false, false>(d, s);

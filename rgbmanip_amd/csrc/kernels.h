@@ -80,6 +80,7 @@ struct Conv3dTileDesc {
 extern int g_debug_flags;
 extern long long g_ws_min_rows;
 extern int g_tuning_version;
+extern int g_gemm_kernel;
 void conv3d_tile_pack(const float* w, const float* scale, int Cin, int Cout, int coutp, bool transposed, int dtype,
                       std::vector<float>& packed);
 int launch_conv3d_tile(int layer, int dtype, const Conv3dTileDesc& d, hipStream_t s);

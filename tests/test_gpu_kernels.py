@@ -127,8 +127,70 @@ def test_conv2d_switchable_igemm_variants(flags, dtype):
         lib.rgbm_debug_flags(0)
     y0 = conv_nd(dtype, x, w, stride=1, pad=dil, dil=dil, bias=b, res=res, res_mode=1, act=1)
     assert rel_err(y, ref) < TOL[dtype] and rel_err(y0, ref) < TOL[dtype]
-    if flags == 65536:       # same K order as the default kernel: identical sums
-        assert torch.equal(y, y0)
+    if flags == 65536:       # same K order and MFMA shape as the 16x16x32 wide kernel: identical sums
+        try:
+            lib.rgbm_set_tuning(b"gemm_kernel", 0)
+            y16 = conv_nd(dtype, x, w, stride=1, pad=dil, dil=dil, bias=b, res=res, res_mode=1, act=1)
+        finally:
+            lib.rgbm_set_tuning(b"gemm_kernel", 2)
+        assert torch.equal(y, y16)
+
+
+WIDE_CASES = [c for c in CONV2D_CASES if c[0].startswith("wide_") or c[0] == "ws128_dil2_bias_prelu"] + [
+    # the backbone's own shapes at a small batch: layer3 (dilation 2, residual + ReLU, lib/pspnet.py:42), layer4 (dilation 4, :43), and a
+    # launch with fewer tiles than CUs and one with K tiles < ring depth
+    ("m32_layer3", 6, 256, 28, 28, 256, 3, 1, 2, 2, False, 1, 1),
+    ("m32_layer4", 5, 256, 28, 28, 512, 3, 1, 4, 4, False, 1, 1),
+    ("m32_one_ktile", 9, 64, 28, 28, 256, 1, 1, 0, 1, True, 2, 0),
+    ("m32_two_ktiles_ragged", 7, 128, 27, 29, 768, 1, 1, 0, 1, True, 1, 2),
+    # enough rows for whole rounds of 256 x 256 tiles on 256 CUs plus a tail launch (M = 66 * 1568: 404.25 pixel tiles), with and
+    # without the residual that rides the matrix pipe as four identity K steps
+    ("m32_big_res", 66, 64, 28, 56, 256, 3, 1, 2, 2, True, 1, 1),
+    ("m32_big_nores_512", 34, 128, 56, 28, 512, 1, 1, 0, 1, False, 2, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16, _lib.BF16X3], ids=["bf16", "fp16", "bf16x3"])
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_conv2d_gemm_kernel_variants(case, dtype):
+    """The three kernels of the 256-channel x 128-pixel launches (rgbm_set_tuning("gemm_kernel"): 0 = 16x16x32 MFMAs with a barrier per
+    K tile, 1 = 32x32x16 MFMAs on 256 x 128 tiles, 2 = whole rounds of 256 x 256 tiles + a 256 x 128 tail launch, the default) against
+    F.conv2d on the same rounded operands; 1 and 2 run the same arithmetic in the same order (a residual added by identity K steps is
+    exact) and must agree bit for bit, three runs of 2 must too (a stage refilled under a reader, or read before it landed, shows up
+    here)."""
+    from gpu_util import conv_nd, rel_err
+    lib = _lib.load()
+    name, N, Cin, H, W, Cout, k, stride, pad, dil, has_bias, act, res_mode = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    res = _q(torch.randn(ref.shape, generator=g), dtype) if res_mode else None
+    if res_mode == 1:
+        ref = ref + res
+    ref = _act(ref, act, 0.25)
+    if res_mode == 2:
+        ref = ref + res
+    ys = {}
+    try:
+        for kern in (0, 1, 2, 2, 2):
+            _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kern), "gemm_kernel")
+            y = conv_nd(dtype, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25)
+            assert torch.isfinite(y).all()
+            assert rel_err(y, ref) < TOL[dtype], (name, kern)
+            if kern in ys:
+                assert torch.equal(y, ys[kern]), (name, kern, "run-to-run")
+            ys[kern] = y
+    finally:
+        lib.rgbm_set_tuning(b"gemm_kernel", 2)
+    if res_mode == 1:
+        # the 256 x 256 tiles add a pre-activation residual on the matrix pipe (identity K steps): the pipe's adder is not the IEEE fp32
+        # add of the epilogue, so a few results per million round the other way by one unit of the storage type
+        d = (ys[1] - ys[2]).abs()
+        assert float((d > 0).float().mean()) < 1e-5 and float(d.max()) <= float(ys[1].abs().max()) * 2.0 ** -7, name
+    else:
+        assert torch.equal(ys[1], ys[2]), name
 
 
 @pytest.mark.parametrize("name", ["l2_3x3_s2", "up_prelu", "ws128_res_pre", "ws128_1x1_s1", "ws64_prelu_bias", "ws64_rowhalo_dil2",

@@ -1,5 +1,6 @@
 """Same-box A/B of one rgbm_adapose_set_option key at batch 256: ms per forward for each value, interleaved.
-usage: ab_option.py <dtype> <key> <v0> <v1> [...]      key "debug": the values are rgbm_debug_flags words (read at launch time) on one net"""
+usage: ab_option.py <dtype> <key> <v0> <v1> [...]      key "debug": the values are rgbm_debug_flags words (read at launch time) on one net;
+key "tuning:<name>": the values go to rgbm_set_tuning(<name>, v) on one net (e.g. tuning:gemm_kernel 0 1 2)"""
 import os
 import sys
 import numpy as np
@@ -13,7 +14,7 @@ B = 256
 inp = synth.adapose_inputs(16, seed=0)
 inp = {k: torch.from_numpy(np.concatenate([v] * (B // 16), 0)).cuda() for k, v in inp.items()}
 sd = synth.adapose_state_dict(seed=0)
-if key == "debug":
+if key == "debug" or key.startswith("tuning:"):
     from rgbmanip_amd import _lib
     one = AdaPoseNet(sd, dtype=dtype)
     nets = {v: (one, v) for v in vals}
@@ -21,7 +22,10 @@ else:
     nets = {v: AdaPoseNet(sd, dtype=dtype, options={key: v}) for v in vals}
 def run(net):
     if isinstance(net, tuple):
-        _lib.load().rgbm_debug_flags(net[1])
+        if key == "debug":
+            _lib.load().rgbm_debug_flags(net[1])
+        else:
+            _lib.check(_lib.load().rgbm_set_tuning(key.split(":", 1)[1].encode(), net[1]), "set_tuning")
         net = net[0]
     return net(inp["img1"], inp["choose1"], inp["img2"], inp["choose2"], inp["P1"], inp["P2"], inp["depths"])
 for net in nets.values():
