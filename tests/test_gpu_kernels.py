@@ -184,13 +184,7 @@ def test_conv2d_gemm_kernel_variants(case, dtype):
             ys[kern] = y
     finally:
         lib.rgbm_set_tuning(b"gemm_kernel", 2)
-    if res_mode == 1:
-        # the 256 x 256 tiles add a pre-activation residual on the matrix pipe (identity K steps): the pipe's adder is not the IEEE fp32
-        # add of the epilogue, so a few results per million round the other way by one unit of the storage type
-        d = (ys[1] - ys[2]).abs()
-        assert float((d > 0).float().mean()) < 1e-5 and float(d.max()) <= float(ys[1].abs().max()) * 2.0 ** -7, name
-    else:
-        assert torch.equal(ys[1], ys[2]), name
+    assert torch.equal(ys[1], ys[2]), name      # incl. the residual: both tile sizes add it on the matrix pipe (identity K steps)
 
 
 @pytest.mark.parametrize("name", ["l2_3x3_s2", "up_prelu", "ws128_res_pre", "ws128_1x1_s1", "ws64_prelu_bias", "ws64_rowhalo_dil2",
