@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense / worst-case / survey-mask legs of the headline dtype")
     ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 throughput + accuracy legs (the modes inside the 1e-4 gate)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the estimate() plugin-boundary leg (host numpy frames in, H2D included)")
+    ap.add_argument("--no-ppo-default", action="store_true", help="skip the PPO leg's second run with the estimator's default cfg (bf16x3)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / B = 8 latency leg (eager launches and hipGraph replay)")
     ap.add_argument("--no-peaks", action="store_true", help="skip the achievable-peak probes (bare MFMA stream, copy kernel; ~0.3 s)")
     ap.add_argument("--no-prof", action="store_true", help="timing experiment: no per-launch HIP events in the timed region (the roofline object is then empty)")
@@ -653,6 +654,24 @@ def main():
         t1 = time.perf_counter()
         est_h.estimate(Kh[:nh], r1[:nh], m1[:nh], E1h[:nh], r2[:nh], m2[:nh], E2h[:nh])
         h_s = time.perf_counter() - t1
+        # what `python train.py ... pose_estimator=adapose_cabinet` gets with the yaml files unchanged: NO hip_* key, no dtype argument
+        # (storage type bf16x3, the mode inside north_star's 1e-4; hip_prepare: device since round 5)
+        del est_h
+        torch.cuda.empty_cache()
+        est_def = AdaPoseEstimator_v5(None, dict(ecfg), None, state_dict=sd0)
+        est_def.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            bb_def = est_def.estimate(Kh, r1, m1, E1h, r2, m2, E2h)
+        def_s = (time.perf_counter() - t1) / 2
+        def_res = {"poses_per_sec": round(B / def_s, 1), "ms_per_call": round(def_s * 1e3, 1), "dtype": est_def.dtype,
+                   "hip_prepare": est_def.prepare_mode, "view2_heads": bool(est_def.view2_heads), "finite": bool(np.isfinite(bb_def).all()),
+                   "max_abs_box_difference_to_the_bf16_leg_m": float(np.abs(bb_def - bb).max()),
+                   "note": "AdaPoseEstimator_v5(env, ADAPOSE_CFGS['adapose_cabinet'], logger) with no hip_* override: the estimate() a "
+                           "train.py user gets with the reference's yaml files unchanged"}
+        del est_def
+        torch.cuda.empty_cache()
         gb = (r1.nbytes + r2.nbytes + m1.nbytes + m2.nbytes) / 1e9
         boundary_res = {
             "call": "AdaPoseEstimator_v5.estimate(K, rgb1, mask1, E1, rgb2, mask2, E2) -> [N,8,3] world boxes, numpy in, numpy out "
@@ -673,10 +692,11 @@ def main():
                                "note": "hip_prepare: device — float frames are cast to float32 by the copy into pinned double-buffered staging (host thread pool), "
                                        "so float64 frames cross PCIe at half their size; uint8 frames cross as bytes; crop / resize / subset / network / "
                                        "post-processing on the GPU"},
+            "default_cfg": def_res,
             "host_prepare": {"poses_per_sec": round(nh / h_s, 2), "ms_per_pose": round(h_s / nh * 1e3, 1), "sample_poses": nh,
                              "note": "hip_prepare: host — the reference's per-frame numpy crop / resize on one host core, then one batched forward"},
             "finite": bool(np.isfinite(bb).all())}
-        del r1, r2, m1, m2, r1f, r2f, est_d, est_h, est_full
+        del r1, r2, m1, m2, r1f, r2f, est_d, est_full
     frames = None
     torch.cuda.empty_cache()
 
@@ -815,12 +835,33 @@ def main():
                    "optimizer_steps": 32, "env": env_name,
                    "estimator_view2_heads": (bool(est.view2_heads) if args.ppo_env == "full" else True),
                    "lr_after": ppo.step_size}
+        prim = (ppo.last_collection_time, ppo.last_learn_time, ppo.last_fps)
+        dflt = None
+        if args.ppo_env == "full" and not args.no_ppo_default:
+            # the same loop with the estimator a train.py user gets from the unchanged yaml files: no hip_* key, no dtype argument
+            # (bf16x3 storage, device-side prepare_model_input)
+            del ppo, env, est
+            torch.cuda.empty_cache()
+            est = AdaPoseEstimator_v5(None, dict(ADAPOSE_CFGS["adapose_cabinet"], load=False), None, state_dict=sd0, device=local_rank)
+            venv = SyntheticMultiVecEnv(args.ppo_envs, device, seed=0, env_id_offset=rank * args.ppo_envs)
+            env = ControlInterface(venv, est, SyntheticManipulation(venv), cfg, device=device)
+            ppo = PPO(env, cfg)
+            ppo.run(args.ppo_iters, log_interval=1, save_interval=10 ** 9)
+            barrier()
+            ppo_res["default_cfg"] = {"env_steps_per_sec": round(ppo.last_fps, 1), "collection_s": round(ppo.last_collection_time, 3),
+                                      "learn_s": round(ppo.last_learn_time, 4), "estimator_dtype": est.dtype, "hip_prepare": est.prepare_mode,
+                                      "estimator_view2_heads": bool(est.view2_heads),
+                                      "note": "pose_estimator=adapose_cabinet controller=rl with no hip_* key in the yaml files"}
+            dflt = (ppo.last_collection_time, ppo.last_learn_time, ppo.last_fps)
         if dist is not None:      # per-rank collection / learn times: a straggler of the PPO loop is visible the day SCALE runs
-            allr = torch.zeros(world, 3, dtype=torch.float64, device=device)
-            allr[rank] = torch.tensor([ppo.last_collection_time, ppo.last_learn_time, ppo.last_fps], dtype=torch.float64, device=device)
+            allr = torch.zeros(world, 6, dtype=torch.float64, device=device)
+            allr[rank] = torch.tensor(list(prim) + list(dflt or (0.0, 0.0, 0.0)), dtype=torch.float64, device=device)
             dist.all_reduce(allr)
             ppo_res["per_rank"] = {"collection_s": [round(float(a[0]), 3) for a in allr], "learn_s": [round(float(a[1]), 4) for a in allr]}
             ppo_res["env_steps_per_sec_all_ranks"] = round(world * args.ppo_envs * 16 / max(float(a[0] + a[1]) for a in allr), 1)
+            if dflt is not None:
+                ppo_res["default_cfg"]["per_rank"] = {"collection_s": [round(float(a[3]), 3) for a in allr], "learn_s": [round(float(a[4]), 4) for a in allr]}
+                ppo_res["default_cfg"]["env_steps_per_sec_all_ranks"] = round(world * args.ppo_envs * 16 / max(float(a[3] + a[4]) for a in allr), 1)
 
     _mark("ppo leg done")
     if rank == 0:

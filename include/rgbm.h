@@ -371,12 +371,19 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * 2097152  bf16 plane sweep: blend on scalar fp32 FMAs                    4194304  ... on packed fp32 (rounds 1-3; default: v_perm + v_dot2_f32_bf16)
  * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches
  * 33554432 post-processing: generic fp64 radix selection of the median only (the fall-back of the default selection on fp32
- *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose */
+ *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose
+ * 134217728 implicit-GEMM request waves: 64-bit global addresses + zero page instead of buffer descriptors (the form before round 5) */
 int rgbm_debug_flags(int flags);
 /* dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
  * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = 1024 (measured at
  * B = 1 .. 8 in every storage type; rounds 1-3 used 65536).  Launches whose 64-channel x 256-pixel tiles fit one round of the
- * persistent grid take that tile shape (debug flag 16777216 disables it). */
+ * persistent grid take that tile shape (debug flag 16777216 disables it).
+ * "gemm_kernel": kernel of the launches whose output channels are a multiple of 256 (layer3 / layer4 / up_1) in the 16-bit storage
+ * types: 0 = conv_igemm_ws_kernel (16x16x32 MFMAs, 256 x 128 tile), 1 = conv_igemm_m32_kernel on 256 x 128 tiles (32x32x16 MFMAs,
+ * one multiply wave per SIMD), 2 (default) = whole rounds of 256 x 256 tiles + a 256 x 128 tail launch.  1 and 2 add a pre-activation
+ * residual on the matrix pipe (identity K steps) and give bit-identical results; 0 differs from them in the last bit of a few
+ * residual sums per million.  Debug flag 134217728: the persistent kernels' request waves use 64-bit global addresses and a zero page
+ * instead of buffer descriptors (A/B). */
 int rgbm_set_tuning(const char* key, long long value);
 /* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
  * flags are then ignored */

@@ -1374,7 +1374,7 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
   make_fastdiv(d.Hq, d.fd_m[1], d.fd_s[1]);
   make_fastdiv(d.Dq, d.fd_m[2], d.fd_s[2]);
   d.korder = (g_debug_flags & (1 << 20)) ? 0 : 1;          // debug flag 1048576: taps outer, channels inner (the order before round 3) for A/B
-  d.buf_ok = conv_buffer_offsets_ok(d, BCH, sizeof(T)) && !(g_debug_flags & (1 << 25));      // debug flag 33554432: 64-bit global addresses + zero page (A/B)
+  d.buf_ok = conv_buffer_offsets_ok(d, BCH, sizeof(T)) && !(g_debug_flags & (1 << 27));      // debug flag 134217728: 64-bit global addresses + zero page (A/B)
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, WIDE, RH, SLIM>), (int)LDS)) return rc;
   int n_cu = 0;
   if (int rc = persistent_grid_cus(&n_cu)) return rc;

@@ -157,7 +157,11 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                                                                 graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)),
                                                                 options={"view2_heads": int(self.view2_heads)})
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
-        self.prepare_mode = cfg.get("hip_prepare", "host")          # "host" (numpy, reference RNG) | "device" (rgbm_prepare_inputs)
+        # "device" (default since round 5): frames are uploaded once and cropped / resized / sub-sampled on the GPU (rgbm_prepare_inputs);
+        # a mask with more than 1024 pixels keeps the 1024 smallest hash keys (hip_prepare_seed) instead of the pixels np.random.shuffle
+        # would pick (interface_v5.py:126-130) — same distribution, another stream.  "host": the reference's per-frame numpy path on the
+        # global numpy RNG (one host core: 46 ms per pose), for RNG-stream parity with the reference.
+        self.prepare_mode = cfg.get("hip_prepare", "device")
         self.prepare_seed = int(cfg.get("hip_prepare_seed", 0))
         self._frame = 0               # hash-subset mode of the host path: index of the sample being prepared
 

@@ -463,7 +463,7 @@ def test_estimator_plugin_estimate_vs_oracle_pipeline():
     from rgbmanip_amd.config import ADAPOSE_CFGS
     from rgbmanip_amd.estimator import AdaPoseEstimator_v5, DEFAULT_BBOX
     g = np.random.default_rng(3)
-    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False)
+    cfg = dict(ADAPOSE_CFGS["adapose_cabinet"], load=False, hip_prepare="host")      # the mode that consumes the reference's RNG stream
     sd = synth.adapose_state_dict(seed=0)
     est = AdaPoseEstimator_v5(None, cfg, None, state_dict=sd, dtype="fp32")
     n = 3
