@@ -1973,7 +1973,7 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
           if ((g_debug_flags & 131072) && conv_rowhalo_ok(d) && d.Kpad == 9 * d.Cin && d.KT == 9 * (d.Cin >> 6)) return launch_ws<T, true, true>(d, s);
         }
 #endif
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 || std::is_same<T, bx3_t>::value) {
           if (conv_buffer_offsets_ok(d, 256, sizeof(T))) {      // its request waves address both operands through 32-bit buffer offsets
             if (g_gemm_kernel >= 1) return launch_m32<T>(d, s, g_gemm_kernel);
           }

@@ -3,6 +3,7 @@ at batch 256, through rgbm_conv_nd, timed by the in-library event profiler.  usa
 Prints per shape: ms per launch and TFLOP/s per kernel (median over rounds), and max |out_k - out_0|."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from rgbmanip_amd import _lib
 lib = _lib.load()
@@ -21,7 +22,8 @@ fp = lambda t: t.numpy().ctypes.data_as(C.c_void_p)
 def to_store(t):
     if DT == _lib.BF16: return t.bfloat16().cuda()
     if DT == _lib.F16: return t.half().cuda()
-    x = t.float().cuda().contiguous(); _lib.check(lib.rgbm_f32_to_bx3(_lib.ptr(x), _lib.ptr(x), x.numel(), _lib.stream_ptr()), "bx3"); return x
+    from gpu_util import bx3_pack
+    return torch.cat([bx3_pack(c.cuda()) for c in t.float().chunk(16)]).contiguous()
 for name, H, W, Cin, Cout, k, dil, res in shapes:
     x = to_store(torch.randn(N, H, W, Cin, generator=g))
     w = (torch.randn(Cout, Cin, 1, k, k, generator=g) / np.sqrt(Cin * k * k)).contiguous()
@@ -39,7 +41,7 @@ for name, H, W, Cin, Cout, k, dil, res in shapes:
     for kk in kernels:
         _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kk % 10), "tuning"); lib.rgbm_debug_flags(8192 if kk == 20 else (8192 | (1 << 27)) if kk == 30 else (1 << 27) if kk >= 10 else 0)
         out.zero_(); run(); torch.cuda.synchronize()
-        o = out.view(torch.int32 if x.dtype == torch.float32 else torch.int16).clone()
+        o = out.view(torch.int32 if x.dtype in (torch.float32, torch.int32) else torch.int16).clone()
         if ref is None: ref = o
         else: diffs[kk] = int((o != ref).sum())
     for rd in range(rounds):
