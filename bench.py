@@ -680,7 +680,8 @@ def main():
             "device_prepare": {"poses_per_sec": round(B / e_s, 1), "ms_per_call": round(e_s * 1e3, 1),
                                "pipeline": "chunks of 32 poses: host threads stage chunk c+1 into pinned memory | copy engine moves chunk c | kernels run chunk c-1",
                                "unpipelined_ms_per_call": round(e1_s * 1e3, 1), "unpipelined_poses_per_sec": round(B / e1_s, 1),
-                               "pipelined_equals_unpipelined": bool(np.allclose(bb, bb1, rtol=2e-2, atol=1e-3)),
+                               "pipelined_close_to_unpipelined": bool(np.allclose(bb, bb1, rtol=2e-2, atol=1e-3)),
+                               "pipelined_vs_unpipelined_max_abs_m": float(np.abs(bb - bb1).max()),
                                "upload_alone_ms": round(up_s * 1e3, 1), "upload_alone_host_GBps": round(gb / up_s, 1),
                                "upload_share_of_unpipelined_call": round(up_s / e1_s, 3),
                                "device_resident_ms": round(dev_s * 1e3, 1), "device_resident_poses_per_sec": round(B / dev_s, 1),

@@ -368,13 +368,17 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
  *                                                                                  (default since round 3: channel block outer, taps inner)
- * 2097152  bf16 plane sweep: blend on scalar fp32 FMAs                    4194304  ... on packed fp32 (rounds 1-3; default: v_perm + v_dot2_f32_bf16)
+ * 2097152  bf16 plane sweep: blend on fp32 FMAs from inline asm           4194304  ... on v_perm + v_dot2_f32_bf16 (8-bit bilinear weights; the
+ *                                                                                  round-4 default; default since round 5: plain fp32 blend)
  * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches
  * 33554432 post-processing: generic fp64 radix selection of the median only (the fall-back of the default selection on fp32
  *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose
  * 134217728 implicit-GEMM request waves: 64-bit global addresses + zero page instead of buffer descriptors (the form before round 5) */
 int rgbm_debug_flags(int flags);
-/* dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
+/* Kernel choice - tile shape, and with it the order of the fp32 sums - depends on a launch's GEMM rows, i.e. on the batch size: the
+ * same pose in batches of different sizes agrees to the storage type's rounding (1e-6 .. 1e-5 relative in fp32 / bf16x3), not bit for
+ * bit.  Equal-sized batches (and the two half batches of split_streams) are bit-identical.
+ * dispatch thresholds (process-wide, like the debug flags).  "ws_min_rows": GEMM rows (output pixels of a conv launch) from which
  * the persistent role-specialised implicit-GEMM kernels are used instead of the generic tiles; 0 (default) = 1024 (measured at
  * B = 1 .. 8 in every storage type; rounds 1-3 used 65536).  Launches whose 64-channel x 256-pixel tiles fit one round of the
  * persistent grid take that tile shape (debug flag 16777216 disables it).

@@ -78,8 +78,10 @@ class AdaPoseNet:
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"cost_impl", int(cost_impl)), "rgbm_adapose_set_option")
         if sparse_tail is not None:
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, b"sparse_tail", int(sparse_tail)), "rgbm_adapose_set_option")
+        self.options = {}                                 # what was set through this object (a sharing estimator reads view2_heads back)
         for key, val in (options or {}).items():          # any rgbm_adapose_set_option key (include/rgbm.h), e.g. fuse_final
             _lib.check(self.lib.rgbm_adapose_set_option(self._h, key.encode(), int(val)), "rgbm_adapose_set_option")
+            self.options[key] = int(val)
         self._ws = None
         self._ws_B = None
 
@@ -159,7 +161,9 @@ class AdaPoseNet:
     def forward(self, view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values,
                 stop_after: int = 0, stream=None):
         if self.graph and stop_after == 0 and stream is None and len(view1_img) <= self.graph_max_batch:
+            self._last_graph = True
             return self._forward_graph((view1_img, view1_choose, view2_img, view2_choose, view1_proj, view2_proj, depth_values))
+        self._last_graph = False
         img1 = self._prep(view1_img, torch.float32)
         img2 = self._prep(view2_img, torch.float32)
         ch1 = self._prep(view1_choose, torch.int32)
@@ -230,6 +234,9 @@ class AdaPoseNet:
         """Debug/test access to a named intermediate of the last forward (fp32, flat)."""
         if self._last_split:
             raise _lib.RgbmError("fetch: the last forward ran as two half batches (split_streams); run it with split_streams=False for taps")
+        if getattr(self, "_last_graph", False):
+            raise _lib.RgbmError("fetch: the last forward replayed a captured graph (its intermediates live in the graph's own workspace); "
+                                 "run it with graph=False for taps")
         buf = torch.empty(max_elems, dtype=torch.float32, device=self.device)
         n = C.c_size_t()
         ws_ptr, _ = self._workspace(B)
@@ -258,6 +265,8 @@ def postprocess(view1_nocs, view1_depth, view1_r, view1_choose, K_crop, E1, img_
     nb = C.c_size_t()
     _lib.check(lib.rgbm_adapose_postprocess_scratch_bytes(B, C.byref(nb)), "rgbm_adapose_postprocess_scratch_bytes")
     scratch = torch.empty(nb.value // 8, dtype=torch.int64, device=dev) if nb.value else None
+    if scratch is not None and stream is not None:
+        scratch.record_stream(stream)      # allocated on the current stream, used (and dropped on return) on `stream`: the caching allocator must not reuse it early
     _lib.check(lib.rgbm_adapose_postprocess_ws(B, P, img_size, _lib.ptr(nocs), _lib.ptr(depth), _lib.ptr(r), _lib.ptr(ch),
                                                _lib.ptr(K), _lib.ptr(E), _lib.ptr(bbox), _lib.ptr(ts), _lib.ptr(valid),
                                                _lib.ptr(scratch), nb.value, _lib.stream_ptr(stream)), "rgbm_adapose_postprocess_ws")

@@ -135,13 +135,14 @@ template <> struct Sw16<f16_t> {
 };
 
 // Blend modes of the bf16 producers (template parameter BL of the kernel; rgbm_debug_flags 2097152 / 4194304 select 1 / 0 for A/B):
-//   0  packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add_f32 on unpacked channel pairs): 8 unpack + 5 packed + 1 convert per
+//   0  [default since round 5] fp32 arithmetic on unpacked channel pairs (written for v_pk_mul / v_pk_fma / v_pk_add_f32; the library is
+//      built without packed fp32 instructions since round 4, so these are plain fp32 FMAs): 8 unpack + 5 packed + 1 convert per
 //      dword.  Packed fp32 instructions next to another wave's MFMA stream on the same SIMD cost far more than their issue slot
 //      (MI355X_MICROARCH.md: one v_pk_fma_f32 instead of two v_fma_f32 = +22 cycles) — and three of the four producers share
 //      their SIMD with a consumer.
 //   1  the same sum on scalar v_fma_f32 (inline asm: the SLP vectoriser would re-pack plain C): 8 unpack + 10 + 1 per dword,
 //      bit-identical to mode 0.
-//   2  [default] channel pairs stay packed: v_perm_b32 puts the low (high) halves of two corners' dwords side by side and
+//   2  [round-4 default; debug flag 4194304 since round 5] channel pairs stay packed: v_perm_b32 puts the low (high) halves of two corners' dwords side by side and
 //      v_dot2_f32_bf16 multiplies them by the corner weights as a bf16 pair, accumulating in fp32 on top of the reference feature:
 //      4 perm + 4 dot2 + 1 convert per dword, no packed-fp32 instruction.  The products are exact (bf16 x bf16 in fp32), the weights
 //      carry 8 significant bits — the rounding the gathered features already have; a corner outside the image keeps weight 0 exactly,
@@ -588,10 +589,13 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 2>), SW_LDS)) return rc;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t, 0>), SW_LDS)) return rc;
   prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
-  // bf16 blend mode (see blend_chunk): debug flag 4194304 = packed fp32 (rounds 1-3), 2097152 = scalar fp32, default = perm + dot2
-  if (dtype == BF16 && (g_debug_flags & (1 << 22))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  // bf16 blend mode (see blend_chunk).  Default since round 5: the plain fp32 blend (mode 0; the library is built without packed fp32
+  // instructions, so it is scalar v_fma_f32 code) — on this build the three modes are level (44.11 / 44.15 / 44.09 ms per forward, same-box
+  // interleaved) and the dot2 form rounds the four bilinear weights to 8 bits (c0 mean error 1.9e-3 against < 1e-3).  Debug flag
+  // 4194304 = v_perm + v_dot2_f32_bf16 (the round-4 default), 2097152 = fp32 FMAs from inline asm.
+  if (dtype == BF16 && (g_debug_flags & (1 << 22))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 2>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   else if (dtype == BF16 && (g_debug_flags & (1 << 21))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 1>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
-  else if (dtype == BF16) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 2>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  else if (dtype == BF16) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   else hipLaunchKernelGGL((conv0_sweep_kernel<f16_t, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());

@@ -64,7 +64,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
   const int lr = lane & 15, lg = lane >> 4;
   for (int i = tid; i < 27 * 8; i += 256) wp[i] = d.wprob[i];
   const int D = d.D, H = d.H, W = d.W, Dq = D >> 1, Hq = H >> 1, Wq = W >> 1;
-  const long long pidx = (long long)blockIdx.x * 4 + wave;              // point index within the chunk (wave-uniform)
+  // XCD-aware block order (round 5): hardware block b runs on XCD b % 8, and the 256 blocks of a view share its c0 / u9 lines.  In
+  // launch order every XCD touched every view (c0 crossed the fabric into up to eight L2s: 11.9 GB of fetches per step for a tensor
+  // whose needed part is a fraction of its 9.9 GB); XCD x now owns a contiguous run of blocks, i.e. whole views.
+  const long long nb = gridDim.x, bq = nb >> 3, br = nb & 7;
+  const long long xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const long long vblk = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+  const long long pidx = vblk * 4 + wave;                                // point index within the chunk (wave-uniform)
   const bool active = pidx < (long long)d.Vc * d.P;
   const int vl = active ? (int)(pidx / d.P) : 0;
   const int v = d.v0 + vl;

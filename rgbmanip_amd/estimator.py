@@ -156,6 +156,14 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                                                                 graph=bool(cfg.get("hip_graph", False)),
                                                                 graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)),
                                                                 options={"view2_heads": int(self.view2_heads)})
+        if net is not None:
+            # a shared network keeps ITS setting (changing it on the shared handle would drop every captured graph and change the other
+            # users' outputs): report what it computes, and refuse the combination that would feed never-written view-2 outputs to the PnP tail
+            net_v2 = bool(net.options.get("view2_heads", 1))
+            if self.view2_heads and not net_v2:
+                raise ValueError("AdaPoseEstimator_v5: this cfg needs the view-2 heads (hip_view2_heads, or the PnP tail of "
+                                 "direct_regression=False / use_depth=False), but the shared net was built with view2_heads=0")
+            self.view2_heads = net_v2
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         # "device" (default since round 5): frames are uploaded once and cropped / resized / sub-sampled on the GPU (rgbm_prepare_inputs);
         # a mask with more than 1024 pixels keeps the 1024 smallest hash keys (hip_prepare_seed) instead of the pixels np.random.shuffle
@@ -252,7 +260,9 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
         float32 frames in bf16 and bf16x3, tools/boundary_chunks.py; 1 GB of pinned staging for float64 frames) run as a three-stage pipeline over
         chunks of poses: host threads copy chunk c + 1 into pinned staging buffers while the copy engine moves chunk c to the device
         on its own stream and the kernels (dtype conversion, crop / resize / subset, network, post-processing) work on chunk c - 1.
-        Every pose's box equals the unchunked call's (poses are independent; a chunk is a smaller batch of the same kernels)."""
+        Poses are independent, but a chunk is a smaller batch: below ~1000 GEMM rows per launch and at launches that fit one round of the
+        persistent grid the dispatcher picks other tiles (summation order), so a pose's box agrees with the unchunked call's to the
+        storage type's rounding (1e-6 .. 1e-5 relative in fp32 / bf16x3), not bit for bit (include/rgbm.h, rgbm_set_tuning)."""
         n = len(rgb1)
         chunk = int(self.cfg.get("hip_upload_chunk", 32))
         on_dev = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (rgb1, rgb2))

@@ -45,7 +45,7 @@ def _net(dtype, **kw):
 
 class _generic_kernels_only:
     """Within the block every conv launch takes the generic tiles (rgbm_set_tuning ws_min_rows = 2^30): since round 4 the persistent
-    kernels start at 1024 (16-bit) / 8192 (4-byte) GEMM rows, so two batch sizes on either side of a threshold sum in different
+    kernels start at 1024 GEMM rows in every storage type, so two batch sizes on either side of a threshold sum in different
     orders (1e-6 .. 1e-5 apart) — tests that compare batches of different sizes BIT FOR BIT (or to 1e-6) pin the selection."""
     def __enter__(self):
         from rgbmanip_amd import _lib
@@ -323,16 +323,17 @@ def test_fp16_close_to_golden(inputs, golden_dir, cost_impl):
         assert errs[k] < gate[k.split("_")[1]], (k, errs)
 
 
-@pytest.mark.parametrize("blend", ["dot2", "packed_f32", "scalar_f32"])
+@pytest.mark.parametrize("blend", ["dot2", "default_f32", "scalar_f32"])
 def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps, blend):
     """cost_impl 3 (depth-sweeping conv0, conv0_sweep.hip) vs 2 (halo-tile conv0): same bf16 features and conv weights, fp32
-    accumulation in a different order.  With the fp32 blends (debug flags 4194304 / 2097152: the round 1-3 arithmetic) c0 may differ
-    by one bf16 rounding at most; the default blend (v_perm + v_dot2_f32_bf16) also rounds the four bilinear weights of a voxel to
-    bf16 — measured 1.5 bf16 steps at most, the mean difference 1.9e-3; every variant stays close to the oracle."""
+    accumulation in a different order.  With the fp32 blends (the default since round 5, and debug flag 2097152) c0 may differ
+    by one bf16 rounding at most; the dot2 blend (v_perm + v_dot2_f32_bf16, debug flag 4194304: the round-4 default) also rounds the
+    four bilinear weights of a voxel to bf16 — measured 1.5 bf16 steps at most, the mean difference 1.9e-3; every variant stays close
+    to the oracle."""
     from rgbmanip_amd import _lib
     _, taps = oracle_taps
     c0 = {}
-    _lib.check(_lib.load().rgbm_debug_flags({"dot2": 0, "packed_f32": 1 << 22, "scalar_f32": 1 << 21}[blend]))
+    _lib.check(_lib.load().rgbm_debug_flags({"dot2": 1 << 22, "default_f32": 0, "scalar_f32": 1 << 21}[blend]))
     try:
         for ci in (2, 3):
             net = _net("bf16", cost_impl=ci, options={"sparse_dec": 0})      # the whole c0 volume is compared: no tile skipping
