@@ -5,11 +5,14 @@ cd "$(dirname "$0")"
 OUT=${1:-..}
 mkdir -p build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-# No packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in any kernel.  Round 4: with two forwards overlapping on the
-# device, hipcc's v_pk_* instructions that consume registers a global_load has just delivered (behind the right s_waitcnt vmcnt) computed
-# from other values in lane rows 16-31 / 48-63 of the first resident blocks — fuse_points_kernel's warp coordinates, 16 of 20 overlapped
-# runs; the same source without packed ops: 0 of 60 (tools/check_two_stream_forwards.py).  The packed forms buy
-# nothing here (same-box A/B of every kernel file with and without them: within 0.3 %), so they are off everywhere.
+# No packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in any kernel.  Round 4: forwards that overlap on the device
+# (two streams) differed intermittently from the one-stream forward, and the difference CORRELATES with this code-generation switch: same
+# source with packed ops 16 of 20 overlapped runs differ, without them 0 of 60 (tools/check_two_stream_forwards.py).
+# The mechanism is NOT isolated: the stand-alone reproducers (tools/micro/pk_after_load.hip, valu_under_mfma.hip) are negative, and a
+# library-wide flag also moves register allocation and scheduling in every kernel, so a latent ordering bug elsewhere is not excluded.
+# What holds is the gate: 12 overlapped forwards x 3 storage types bit for bit (tests/test_gpu_at_batch.py) and the check that the shipped
+# code objects hold no v_pk_*_f32 (tests/test_cabi_symbols.py).  The packed forms buy nothing here (same-box A/B of every kernel file with
+# and without them: within 0.3 %), so they are off everywhere.
 FLAGS="$FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops"
 # RGBM_EXPERIMENTS=1 build.sh also compiles the experiment kernels (256 x 256 two-group implicit GEMM, row-halo variant of the
 # 256 x 128 tile, register-staged implicit GEMM: all measured slower than what ships; debug flags 8192 / 131072 / 4 select them)

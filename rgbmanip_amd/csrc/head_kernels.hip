@@ -184,9 +184,10 @@ __global__ void fuse_points_kernel(const T* __restrict__ feat, const float* __re
     const int lane = threadIdx.x & 63, grp = lane & ~7;
     float cix[3], ciy[3];                                   // D <= 24
     // The 64 lanes of a wave belong to one view (P is a multiple of 8): the view's homography comes through the scalar cache into SGPRs
-    // (one s_load instead of three vector loads per lane).  Round 4: with per-lane vector loads of this record hipcc fed the just-loaded
-    // registers into packed fp32 instructions, which computed from other values in lane rows 16-31 / 48-63 whenever another stream's
-    // kernels shared the CU (the library is built without packed fp32 instructions since).
+    // (one s_load instead of three vector loads per lane).  Round 4: with per-lane vector loads of this record feeding hipcc's packed
+    // fp32 instructions, this kernel's warp coordinates differed in lane rows 16-31 / 48-63 whenever another stream's kernels shared
+    // the CU — a correlation with the packed-fp32 code-generation switch (16 of 20 runs against 0 of 60), mechanism not isolated,
+    // stand-alone reproducers negative (the library is built without packed fp32 instructions since).
     const float* hmv = homog + (long long)__builtin_amdgcn_readfirstlane(v) * 12;      // launch_fuse_points requires P % 8 == 0
 #pragma unroll
     for (int q = 0; q < 3; ++q) {

@@ -650,16 +650,16 @@ def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
     assert torch.isfinite(y).all()
     # some projections must land inside and some outside the partner image, or the case tests nothing
     assert rel_err(y, ref) < (1e-2 if dtype == _lib.BF16 else 2e-3), shape      # one rounding of the output
-    # bf16: the default blend rounds the bilinear weights to bf16 as well (v_dot2_f32_bf16): mean 2.1e-3 measured, 1.5e-3 with
-    # the fp32 blend (checked right below on the same case)
-    assert float((y - ref).abs().mean() / ref.abs().mean()) < (2.8e-3 if dtype == _lib.BF16 else 3e-4)
+    # bf16: the default blend (fp32 weights since round 5) measures a mean of 1.5e-3; the dot2 blend behind debug flag 4194304 (the
+    # round-4 default) rounds the bilinear weights to bf16 as well: 2.1e-3 (checked right below on the same case)
+    assert float((y - ref).abs().mean() / ref.abs().mean()) < (2e-3 if dtype == _lib.BF16 else 3e-4)
     if dtype == _lib.BF16:
-        _lib.check(lib.rgbm_debug_flags(1 << 22))          # packed-fp32 blend: exact weights, the rounds 1-3 gate
+        _lib.check(lib.rgbm_debug_flags(1 << 22))          # v_perm + v_dot2_f32_bf16 blend: 8-bit weights
         try:
             yp, refp, _ = run(None)
         finally:
             _lib.check(lib.rgbm_debug_flags(0))
-        assert float((yp - refp).abs().mean() / refp.abs().mean()) < 2e-3
+        assert float((yp - refp).abs().mean() / refp.abs().mean()) < 2.8e-3
     y2, ref2, _ = run(1)                                       # pose 1 = views 1 and 3 gets a singular view-2 projection
     assert torch.equal(y2[0], y[0]) and torch.equal(y2[2], y[2])
     assert torch.isnan(y2[1]).any() and torch.isnan(y2[3]).any()
