@@ -358,8 +358,10 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  30     conv_igemm_w256_kernel (experimental)      31 / 32  ws 256 x 128 tile 16-bit / its row-halo variant
  *  33     ws 256 x 128 tile bf16x3                   34 / 35 / 36  ws 64 x 256 four-multiply-wave tile bf16x3 / 16-bit / f32
  *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  upconv_final_kernel
+ *  40 / 41 conv_igemm_m32_kernel<T, 128>: the 256 x 128 tail launches of rows 31 / 33 (16-bit / bf16x3; round 5: rows 31 / 33 are
+ *          conv_igemm_m32_kernel<T, 256> under the default gemm_kernel = 2, conv_igemm_ws_kernel<T, wide> under gemm_kernel = 0)
  * stop synchronises on the recorded events. */
-#define RGBM_PROF_ROWS 40
+#define RGBM_PROF_ROWS 42
 /* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):
  *      4  (experiments build) register-staged implicit GEMM instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel

@@ -18,7 +18,7 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 
 
 # rows of rgbm_prof_stop (include/rgbm.h): (kernel name as rocprofv3 prints it, arithmetic dtype)
-PROF_ROWS = 40          # == RGBM_PROF_ROWS (include/rgbm.h); load() checks it against rgbm_prof_rows()
+PROF_ROWS = 42          # == RGBM_PROF_ROWS (include/rgbm.h); load() checks it against rgbm_prof_rows()
 PROF_KERNELS = [
     ("conv_igemm_glds_kernel<float, 16, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 32, 256>", "fp32"),
     ("conv_igemm_glds_kernel<float, 64, 256>", "fp32"), ("conv_igemm_glds_kernel<float, 128, 128>", "fp32"),
@@ -42,14 +42,16 @@ PROF_KERNELS = [
 ] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
      ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false> (128 channels x 256 pixels)", "bf16x3"),
      ("conv_igemm_w256_kernel<unsigned short> (experimental, debug flag 8192)", "bf16"),
-     ("conv_igemm_ws_kernel<unsigned short, true, false> (256 channels x 128 pixels)", "bf16"),
+     ("conv_igemm_m32_kernel<unsigned short, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<unsigned short, true, false>, 256 x 128)", "bf16"),
      ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
-     ("conv_igemm_ws_kernel<rgbm::bx3_t, true, false> (256 channels x 128 pixels)", "bf16x3"),
+     ("conv_igemm_m32_kernel<rgbm::bx3_t, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<rgbm::bx3_t, true, false>, 256 x 128)", "bf16x3"),
      ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"),
      ("conv_igemm_ws_kernel<unsigned short, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16"),
      ("conv_igemm_ws_kernel<float, false, false, true> (64 channels x 256 pixels, four multiply waves)", "fp32"),
      ("upconv_combine_kernel<16-bit> (PSPUpsample tap combination)", "bf16"), ("upconv_combine_kernel<4-byte> (PSPUpsample tap combination)", "bf16x3"),
-     ("upconv_final_kernel (up_3 + final in one kernel; either storage width)", "bf16")]
+     ("upconv_final_kernel (up_3 + final in one kernel; either storage width)", "bf16"),
+     ("conv_igemm_m32_kernel<unsigned short, 128> (256 channels x 128 pixels: the tail launches of the 256 x 256 kernel)", "bf16"),
+     ("conv_igemm_m32_kernel<rgbm::bx3_t, 128> (256 channels x 128 pixels: the tail launches of the 256 x 256 kernel)", "bf16x3")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 

@@ -6,7 +6,7 @@ namespace rgbm {
 // 14 conv0_sweep_kernel (bf16); 15 conv_igemm_ws64_kernel (bf16); 16..25 conv3d_tile_kernel bf16, one row per layer (conv0..conv6, conv7, conv9, conv11);
 // 26..29 the bf16x3 kernels, 30 conv_igemm_w256_kernel, 31 / 32 conv_igemm_ws_kernel<bf16, wide> / <bf16, wide, row halo>, 33 conv_igemm_ws_kernel<bx3_t, wide>, 34 / 35 / 36 the 64-channel x 256-pixel four-multiply-wave shape of conv_igemm_ws_kernel for bx3_t / 16-bit / f32 tensors,
 // 37 / 38 upconv_combine_kernel on 16-bit / 4-byte storage, 39 upconv_final_kernel.  Row 9 stays empty (the bf16 3-D layers are listed one by one); row 8 aggregates the f32 3-D layers.
-constexpr int kProfVariants = 40;      // == RGBM_PROF_ROWS (include/rgbm.h)
+constexpr int kProfVariants = 42;      // == RGBM_PROF_ROWS (include/rgbm.h)
 bool prof_enabled();
 void prof_begin_launch(hipStream_t s, int variant, double flops, double bytes);
 void prof_end_launch(hipStream_t s);
