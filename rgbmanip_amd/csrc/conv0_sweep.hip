@@ -57,6 +57,13 @@ constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
 constexpr int SW_VS = SW_VS_BYTES;               // LDS bytes per voxel: 64 data + 16 pad (conflict-free b128 rows)
 constexpr int SW_SLOT = SW_NV * SW_VS;           // 20160
 constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
+#ifndef SW_SKIP
+#define SW_SKIP 0     // 1 = bf16 producers: planes on which a wave's 64 voxels all project outside the partner image store the reference features
+                      // unblended (round 4: stable in every gate once the library held no packed fp32, -2.4 % bf16 / +4 % f16 with the dot2 blend).
+                      // Round 5, with four consumer waves and the fp32 blend, same box, two interleaved rounds (tools/kernel_ms.py): dense 16.7 ->
+                      // 16.4 ms, but 10.11 -> 10.13 ms on the tiles the sparse cost regularisation needs (the planes that can be skipped lie in
+                      // tiles that are skipped anyway); all 53 sweep / golden / stability / overlap tests green.  Off: nothing on the shipped path.
+#endif
 #ifndef SW_CR
 #define SW_CR 3       // tile rows (= 16-voxel fragments) per consumer wave: 4 -> 3 consumer waves (rounds 1-4), 3 -> 4 (round 5, below), 2 -> 6.
                       // Measured alone (no producer work at all) the 4-row consumer needs 2140 cycles per plane for 1152 cycles of MFMA: one
@@ -107,6 +114,7 @@ struct Corner {                     // everything the blend of one plane needs b
   unsigned off[4];                  // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
   float w[4];                       // bilinear weights: 0 for a corner outside the image, NaN for a non-finite projection
   unsigned wp[2];                   // blend mode 2: {bf16(w0) | bf16(w1) << 16, bf16(w2) | bf16(w3) << 16}
+  bool skip;                        // SW_SKIP: every lane of the wave has four zero weights on this plane (wave-uniform)
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -320,6 +328,18 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       c.off[1] = (r0 + (unsigned)xc1) * 64u;
       c.off[2] = (r1 + (unsigned)xc0) * 64u;
       c.off[3] = (r1 + (unsigned)xc1) * 64u;
+      if constexpr (SW_SKIP && std::is_same<T, unsigned short>::value) {
+        // A plane on which all 64 voxels of this wave project outside the partner image (20-30 % of the (wave, plane) pairs at the
+        // synthetic camera geometry): the blend is ref + 0, so the reference chunk is stored as it is, and the wave's gathers for that
+        // plane all read pixel 0 (one cache line).  The gathers are still ISSUED — the counted waits stay valid for every plane (DESIGN
+        // 5c: a counted wait is valid for one issue history) — only their addresses and the blend arithmetic depend on the flag.
+        c.skip = __builtin_amdgcn_ballot_w64(c.w[0] != 0.f || c.w[1] != 0.f || c.w[2] != 0.f || c.w[3] != 0.f) == 0ull;      // NaN != 0: a non-finite projection is never skipped
+        const unsigned keep = c.skip ? 0u : ~0u;           // wave-uniform mask instead of a branch: no control flow is added to the address path
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c.off[q] &= keep;
+      } else {
+        c.skip = false;
+      }
 #if SW_ABL & 8        // timing experiment: groups of 4 lanes gather the same pixel (16 instead of 64 lines per instruction)
 #pragma unroll
       for (int q = 0; q < 4; ++q) c.off[q] = (unsigned)__builtin_amdgcn_ds_bpermute((lane & ~3) * 4, (int)c.off[q]);
@@ -334,6 +354,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
     // touched before gather_wait(): the empty-bodied asm there names them as in/out so every use is ordered after it.
     Corner cur, nxt;
     auto blend = [](const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e, const Corner& cn) {
+      if (SW_SKIP && std::is_same<T, unsigned short>::value && cn.skip) return r;      // wave-uniform; the gathers and their counted waits around this call are unconditional
       if constexpr (std::is_same<T, f16_t>::value) return blend_chunk_f16(r, a, b, c, e, cn);
       else return blend_chunk<T, BL>(r, a, b, c, e, cn);
     };
