@@ -322,6 +322,12 @@ int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float
 int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
                         const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_dev,
                         int V, int B, int D, int H, int W, void* stream);
+/* what a bf16 net runs by default since round 5 (option "sweep_f16" = 1): feat is f16 [V][H][W][32] (written so by the net's `final`
+ * layer), the conv0 weights are rounded to f16, the blend is packed-f16 arithmetic, out is bf16 [V][D][H][W][8].  Features beyond
+ * +-65504 saturate (as in an fp16 net); set the option to 0 for the all-bf16 form (rgbm_conv0_sweep). */
+int rgbm_conv0_sweep_f16feat(const void* feat_f16_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,
+                             const float* w_host, const float* bn_scale_host, const float* bn_shift_host, void* out_bf16_dev,
+                             int V, int B, int D, int H, int W, void* stream);
 /* debugging access to a named intermediate of the last rgbm_adapose_forward on (h, B, workspace):
  * converts it to fp32 into out_dev (elems = capacity in floats); *n_elems returns its size.  Intermediates of the
  * PSPNet phase are overwritten by the cost-volume phase, so pass stop_after = 1 to rgbm_adapose_forward_ex first.

@@ -125,6 +125,7 @@ SIGNATURES = {
     "rgbm_build_volume": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_conv0_sweep": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_conv0_sweep_dt": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbm_conv0_sweep_f16feat": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbm_prepare_inputs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_prepare_inputs_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rgbm_prepare_inputs_ex": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

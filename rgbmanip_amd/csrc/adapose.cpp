@@ -183,6 +183,7 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
         conv0_sweep_pack(w->data, scale.data(), packed);
         if (dtype == BF16X3) { if (conv0_sweep_x3_upload(packed, &sweep_w)) return -2; }
         else if (upload_packed(packed, dtype, &sweep_w)) return -2;
+        if (dtype == BF16 && upload_packed(packed, F16, &sweep_w_f16)) return -2;
       }
     }
   }
@@ -249,6 +250,8 @@ void AdaPose::destroy() {
   for (auto& t : t3d) { if (t.w) (void)hipFree(t.w); if (t.bias) (void)hipFree(t.bias); t.w = nullptr; t.bias = nullptr; }
   if (sweep_w) (void)hipFree(sweep_w);
   sweep_w = nullptr;
+  if (sweep_w_f16) (void)hipFree(sweep_w_f16);
+  sweep_w_f16 = nullptr;
   if (w11_x3) (void)hipFree(w11_x3);
   w11_x3 = nullptr;
   if (wprob) (void)hipFree(wprob);
@@ -259,6 +262,14 @@ void AdaPose::destroy() {
 
 bool AdaPose::feat_f32_only() const {
   return dtype == BF16X3 && cost_impl == 3 && sweep_w != nullptr && norm_mode == 0 && !(g_debug_flags & 4096);
+}
+
+// bf16 nets: what `final` writes and what the plane sweep and the point heads read is f16 - same bytes, three more mantissa bits, and the
+// sweep's blend becomes four v_pk_fma_f16 per dword.  Needs the one-kernel up_3 + final (its epilogue knows the f16 form) and the
+// depth-sweeping conv0 (the halo-tile / volume paths read the storage type).
+bool AdaPose::feat_f16() const {
+  return dtype == BF16 && sweep_f16 != 0 && cost_impl == 3 && sweep_w_f16 != nullptr && norm_mode == 0 && !(g_debug_flags & 4096) && (upconv & 4) &&
+         tail.ready();
 }
 
 bool AdaPose::sparse_active() const {
@@ -415,7 +426,7 @@ int AdaPose::pspnet(const Buffers& bf, int V, const float* img1, const float* im
   }
   fin.out_plain_f32 = feat_f32_only();
   if ((upconv & 4) && tail.ready())       // up_3 + final from the half-resolution tensor in one kernel: no up-sampled tensor, no z, no u3
-    return tail.run(bf.u2, fin.out_plain_f32 ? (void*)bf.featf : bf.feat, fin.out_plain_f32, V, 4 * H, 4 * W, s);
+    return tail.run(bf.u2, fin.out_plain_f32 ? (void*)bf.featf : bf.feat, fin.out_plain_f32 ? 1 : feat_f16() ? 2 : 0, V, 4 * H, 4 * W, s);
   if (int rc = launch_resize_bilinear_ac(dtype, bf.u2, bf.ups, V, 4 * H, 4 * W, 64, 8 * H, 8 * W, 64, 0, s)) return rc;
   // up_3 + final: one launch on the bf16 path (the 64-channel up_3 output then never reaches HBM: `u3` is not written)
   // bf16x3, default path: `final` writes the plain-fp32 feature map directly (no split-pair copy, no 6.6 GB conversion pass)
@@ -456,6 +467,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     // should a compiler update bring the sweep kernels' hand-counted asm gathers out of step)
     if (layer == 10 && cost_impl == 3 && b16 && sweep_w && !(g_debug_flags & 4096)) {
       d.wgt = sweep_w;
+      if (feat_f16()) { d.wgt = sweep_w_f16; d.feat_f16 = 1; }
       return launch_conv0_sweep(d, dtype, s);
     }
     if (layer == 10 && cost_impl == 3 && dtype == BF16X3 && sweep_w && !(g_debug_flags & 4096)) {
@@ -581,6 +593,7 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
       if (int rc = launch_bx3_to_f32(bf.feat, bf.featf, (long long)V * S * S * 32, s)) return rc;
     featg = bf.featf; fdt = F32;
   }
+  if (feat_f16()) fdt = F16;
   if (stop_after == 1) return 0;
 
   const int Vh = view2_heads ? V : B;      // views that get heads: both crops of every pose, or the view-1 crops only (option view2_heads)

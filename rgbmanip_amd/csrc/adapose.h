@@ -58,6 +58,8 @@ struct AdaPose {
                                 // filled with NaN): what `AdaPoseEstimator_v5.estimate` consumes — interface_v5.py:318-374 builds the box from
                                 // view1_nocs / view1_depth / view1_r and drops the rest — at ~3/4 of the time; the backbone still runs on both views
   int sparse_tail = 1;          // cost_impl 3: evaluate conv11 + prob only where prob is gathered (0 = dense conv11, for A/B and tests)
+  int sweep_f16 = 1;            // bf16 nets: `final` writes the feature map as f16 and the plane sweep blends it with packed f16 FMAs (conv0_sweep.hip; 0 = bf16 feature map, fp32 blend)
+  void* sweep_w_f16 = nullptr;  // bf16 nets: the same conv0 weights as f16 (sweep_f16)
   void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (16-bit nets; bf16x3 nets: hi + lo operand arrays of conv0_sweep_x3.hip)
   int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,
                                 // 3 = 2 with the depth-sweeping conv0 kernel (bf16; fp32 nets run 2)
@@ -104,6 +106,7 @@ struct AdaPose {
   // bf16x3 on the default path: nothing reads the split-pair feature map (the sweep and the point heads gather from plain fp32), so
   // `final` writes fp32 directly; the A/B paths (materialised volume, halo-tile conv0, per-sample BN) still want split pairs
   bool feat_f32_only() const;
+  bool feat_f16() const;        // bf16 nets: the feature map (bf.feat) holds f16 in this forward (option sweep_f16 and the paths that can produce / consume it)
   // the conditions under which cost_volume() skips tiles outside the chosen pixels' dependency cones (option sparse_dec)
   bool sparse_active() const;
 };

@@ -98,6 +98,7 @@ int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value) {
   else if (k == "sparse_dec") { RGBM_REQUIRE(value >= 0 && value <= 2, "sparse_dec"); h->net.sparse_dec = value; }
   else if (k == "stem") { RGBM_REQUIRE(value == 0 || value == 1, "stem"); h->net.stem = value; }
   else if (k == "view2_heads") { RGBM_REQUIRE(value == 0 || value == 1, "view2_heads"); h->net.view2_heads = value; }
+  else if (k == "sweep_f16") { RGBM_REQUIRE(value == 0 || value == 1, "sweep_f16"); h->net.sweep_f16 = value; }
   else if (k == "cost_impl") { RGBM_REQUIRE(value >= 0 && value <= 3, "cost_impl"); h->net.cost_impl = value; }
   else { set_error("unknown option " + k); return -1; }
   ++h->opt_version;
@@ -213,7 +214,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
   else if (nm == "u1") { src = bf.u1; cnt = V * (S / 4) * (S / 4) * 256; }
   else if (nm == "u2") { src = bf.u2; cnt = V * (S / 2) * (S / 2) * 64; }
   else if (nm == "u3") { src = bf.u3; cnt = V * S * S * 64; }
-  else if (nm == "feat") { src = bf.feat; cnt = V * S * S * 32; if (n.feat_f32_only()) { src = bf.featf; dt = F32; } }
+  else if (nm == "feat") { src = bf.feat; cnt = V * S * S * 32; if (n.feat_f32_only()) { src = bf.featf; dt = F32; } else if (n.feat_f16()) dt = F16; }
   else if (nm == "vol") { src = bf.vol; cnt = Vc * D * S * S * 32; }
   else if (nm == "c0") { src = bf.c[0]; cnt = Vc * D * S * S * 8; }
   else if (nm == "c2") { src = bf.c[2]; cnt = Vc * (D / 2) * (S / 2) * (S / 2) * 16; }
@@ -310,7 +311,7 @@ int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int
   RGBM_REQUIRE(in_dev && w3_host && b3_host && wf_host && bf_host && out_dev, "upsample_conv3x3_final arguments");
   UpConvFinal L;
   int rc = L.init(dtype, w3_host, b3_host, slope, wf_host, bf_host);
-  if (!rc) rc = L.run(in_dev, out_dev, out_f32 != 0, V, h, w, (hipStream_t)stream);
+  if (!rc) rc = L.run(in_dev, out_dev, out_f32, V, h, w, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   L.destroy();
   return rc;
@@ -412,9 +413,9 @@ extern "C" int rgbm_conv3d_tile(int layer, int dtype, const void* in_dev, int N,
 }
 
 // Kernel-level entry for the depth-sweeping conv0 + fused plane sweep (tests): bf16 features [V][H][W][32] -> [V][D][H][W][8].
-extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev,
-                                   float* homog_scratch, const float* w_host, const float* bn_scale_host, const float* bn_shift_host,
-                                   void* out_dev, int V, int B, int D, int H, int W, void* stream) {
+static int conv0_sweep_entry(int dtype, int feat_f16, const void* feat_dev, const float* P_views_dev, const float* depths_dev,
+                             float* homog_scratch, const float* w_host, const float* bn_scale_host, const float* bn_shift_host,
+                             void* out_dev, int V, int B, int D, int H, int W, void* stream) {
   RGBM_REQUIRE(feat_dev && P_views_dev && depths_dev && homog_scratch && w_host && bn_scale_host && bn_shift_host && out_dev,
                "conv0_sweep arguments");
   RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "conv0_sweep: 16-bit storage types or bf16x3 (fp32 features in, split-pair c0 out)");
@@ -423,7 +424,7 @@ extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float*
   conv0_sweep_pack(w_host, bn_scale_host, packed);
   void* wdev = nullptr; float* bdev = nullptr;
   if (dtype == BF16X3) { if (conv0_sweep_x3_upload(packed, &wdev)) return -2; }
-  else if (upload_packed(packed, dtype, &wdev)) return -2;
+  else if (upload_packed(packed, feat_f16 ? (int)F16 : dtype, &wdev)) return -2;
   std::vector<float> bpad(16, 0.f);
   for (int o = 0; o < 8; ++o) bpad[o] = bn_shift_host[o];
   if (upload_f32(bpad.data(), bpad.size(), &bdev)) return -2;
@@ -433,10 +434,25 @@ extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float*
   d.N = V; d.Di = D; d.Hi = H; d.Wi = W; d.Do = D; d.Ho = H; d.Wo = W; d.Dq = D; d.Hq = H; d.Wq = W;
   d.Cout = 8; d.relu = 1; d.prof_variant = -1;
   d.feat = feat_dev; d.homog = homog_scratch; d.depths = depths_dev; d.v0 = 0; d.V = V; d.B = B;
+  d.feat_f16 = feat_f16;
   int rc = dtype == BF16X3 ? launch_conv0_sweep_x3(d, (hipStream_t)stream) : launch_conv0_sweep(d, dtype, (hipStream_t)stream);
   if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = -2; } }
   (void)hipFree(wdev); (void)hipFree(bdev);
   return rc;
+}
+
+extern "C" int rgbm_conv0_sweep_dt(int dtype, const void* feat_dev, const float* P_views_dev, const float* depths_dev,
+                                   float* homog_scratch, const float* w_host, const float* bn_scale_host, const float* bn_shift_host,
+                                   void* out_dev, int V, int B, int D, int H, int W, void* stream) {
+  return conv0_sweep_entry(dtype, 0, feat_dev, P_views_dev, depths_dev, homog_scratch, w_host, bn_scale_host, bn_shift_host, out_dev, V, B, D,
+                           H, W, stream);
+}
+
+extern "C" int rgbm_conv0_sweep_f16feat(const void* feat_f16_dev, const float* P_views_dev, const float* depths_dev,
+                                        float* homog_scratch, const float* w_host, const float* bn_scale_host,
+                                        const float* bn_shift_host, void* out_bf16_dev, int V, int B, int D, int H, int W, void* stream) {
+  return conv0_sweep_entry(BF16, 1, feat_f16_dev, P_views_dev, depths_dev, homog_scratch, w_host, bn_scale_host, bn_shift_host, out_bf16_dev,
+                           V, B, D, H, W, stream);
 }
 
 extern "C" int rgbm_conv0_sweep(const void* feat_dev, const float* P_views_dev, const float* depths_dev, float* homog_scratch,

@@ -24,8 +24,9 @@
 #include "prof.h"
 
 #ifndef SW_ABL
-#define SW_ABL 0      // ablation builds only (tools/abl_build.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel,
-                      // 16 no output stores, 32 no per-plane projection (the first plane's corners are reused), 64 gathers from one address
+#define SW_ABL 0      // ablation builds only (tools/abl_sweep_flags.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel,
+                      // 16 no output stores, 32 no per-plane projection (the first plane's corners are reused), 64 gathers from one address,
+                      // 256 s_memtime phase timers, printed by a few workgroups
 #endif
 
 namespace rgbm {
@@ -63,6 +64,9 @@ constexpr int SW_NPW = (SW_NV + 63) / 64;        // 4 producer waves
                       // Round 5, with four consumer waves and the fp32 blend, same box, two interleaved rounds (tools/kernel_ms.py): dense 16.7 ->
                       // 16.4 ms, but 10.11 -> 10.13 ms on the tiles the sparse cost regularisation needs (the planes that can be skipped lie in
                       // tiles that are skipped anyway); all 53 sweep / golden / stability / overlap tests green.  Off: nothing on the shipped path.
+#endif
+#ifndef SW_OCC
+#define SW_OCC 3     // minimum waves per SIMD the register allocation must allow (3: 168 VGPRs, one 8-wave workgroup per CU plus the next one's early waves)
 #endif
 #ifndef SW_CR
 #define SW_CR 3       // tile rows (= 16-voxel fragments) per consumer wave: 4 -> 3 consumer waves (rounds 1-4), 3 -> 4 (round 5, below), 2 -> 6.
@@ -113,7 +117,7 @@ struct SweepDesc {
 struct Corner {                     // everything the blend of one plane needs besides the gathered data
   unsigned off[4];                  // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
   float w[4];                       // bilinear weights: 0 for a corner outside the image, NaN for a non-finite projection
-  unsigned wp[2];                   // blend mode 2: {bf16(w0) | bf16(w1) << 16, bf16(w2) | bf16(w3) << 16}
+  unsigned wp[4];                   // blend mode 2: [0..1] = {bf16(w0) | bf16(w1) << 16, bf16(w2) | bf16(w3) << 16}; f16_t: [q] = f16(w[q]) in both halves
   bool skip;                        // SW_SKIP: every lane of the wave has four zero weights on this plane (wave-uniform)
 };
 
@@ -210,6 +214,7 @@ __device__ __forceinline__ uint4 blend_chunk(const uint4& r, const u32x4& a, con
 // MODE.FP16_OVFL, so the final v_cvt_pk_f16_f32 saturates at +-65504 by itself (NaN stays NaN) — sat_f16() in front of it
 // costs 6 more instructions per dword.
 #define SW_MIX(HI, D, H, W, C) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(D) : "v"(H), "v"(W), "v"(C))
+template <bool PK>
 __device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e,
                                                  const Corner& cn) {
   typedef Sw16<f16_t>::h2 h2;
@@ -218,6 +223,21 @@ __device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a,
   const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
   const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
   unsigned o[4];
+  if constexpr (PK) {
+  // Round 5: packed f16 FMAs with the weights as f16 pairs (cn.wp) - four instructions per dword and no conversion at the end.
+  // tools/micro/mfma_valu_coissue.hip: a SIMD issues NO fp32 arithmetic (v_fma_f32, v_fma_mix_f32, v_dot2_f32_bf16, v_cvt_pk_*) of one
+  // wave while another wave's MFMAs occupy the matrix pipe - the two times add - whereas v_pk_fma_f16, v_perm_b32 and integer
+  // instructions fit between the MFMAs (about two per MFMA).
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned t;
+    asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(t) : "v"(aa[q]), "v"(cn.wp[0]), "v"(rr[q]));
+    asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(bb[q]), "v"(cn.wp[1]));
+    asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(cc[q]), "v"(cn.wp[2]));
+    asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(ee[q]), "v"(cn.wp[3]));
+    o[q] = t;
+  }
+  } else {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float lo, hi;
@@ -231,6 +251,7 @@ __device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a,
     const h2 h = {(f16_t)lo, (f16_t)hi};
     o[q] = __builtin_bit_cast(unsigned, h);
   }
+  }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 #undef SW_MIX
@@ -240,8 +261,10 @@ __device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a,
 // min 3 waves per SIMD (<= 168 VGPRs): the hardware then starts the next workgroup's producers while this one's consumers
 // finish (12 wave slots per CU for 7-wave workgroups).  The bf16 instantiation needs 164 anyway; uncapped, the f16_t one
 // took 170 and lost that overlap.
-template <typename T, int BL>
-__global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepDesc d) {
+// T: storage type of the feature maps and the conv0 weights = the MFMA operand type; TO: storage type of c0.  <f16_t, unsigned short> is the
+// bf16 nets' default since round 5 (`final` writes their feature map as f16 for this kernel: adapose.cpp feat_f16()).
+template <typename T, typename TO, int BL>
+__global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -323,6 +346,13 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
         c.wp[0] = pack2_bf16(c.w[0], c.w[1]);
         c.wp[1] = pack2_bf16(c.w[2], c.w[3]);
       }
+      if constexpr (std::is_same<T, f16_t>::value && BL == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const Sw16<f16_t>::h2 h = {(f16_t)c.w[q], (f16_t)c.w[q]};
+          c.wp[q] = __builtin_bit_cast(unsigned, h);
+        }
+      }
       const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
       c.off[0] = (r0 + (unsigned)xc0) * 64u;
       c.off[1] = (r0 + (unsigned)xc1) * 64u;
@@ -355,7 +385,7 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
     Corner cur, nxt;
     auto blend = [](const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e, const Corner& cn) {
       if (SW_SKIP && std::is_same<T, unsigned short>::value && cn.skip) return r;      // wave-uniform; the gathers and their counted waits around this call are unconditional
-      if constexpr (std::is_same<T, f16_t>::value) return blend_chunk_f16(r, a, b, c, e, cn);
+      if constexpr (std::is_same<T, f16_t>::value) return blend_chunk_f16<BL == 3>(r, a, b, c, e, cn);
       else return blend_chunk<T, BL>(r, a, b, c, e, cn);
     };
     u32x4 g[4][4];                                       // [chunk][corner]
@@ -378,7 +408,14 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       corners(0, cur);
       SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
     }
+#if SW_ABL & 256
+    unsigned long long tm[3] = {0, 0, 0}, tq[3];
+#define SW_TP(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SW_TP(I) do {} while (0)
+#endif
     for (int z = 0; z <= D; ++z) {
+      SW_TP(0);
       if (act && z < D) {
 #if SW_ABL & 32
         nxt = cur;
@@ -419,9 +456,18 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       }
       // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SW_TP(1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
+#if SW_ABL & 256
+      SW_TP(2);
+      if (z >= 1 && z < D) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += 1; }
+#endif
     }
+#if SW_ABL & 256
+    if (lane == 0 && (blockIdx.x % 4099) == 17)
+      printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
+#endif
 #if SW_EXIT_BARRIER
     __builtin_amdgcn_s_barrier();
 #endif
@@ -515,13 +561,20 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
             v[r] = (hi[r] + Lp[pr][r]) + bias[r];
             if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
           }
-          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(reinterpret_cast<T*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
+          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(reinterpret_cast<TO*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
         }
         Lp[pr] = lo;
       }
     };
 
+#if SW_ABL & 256
+    unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq[5];
+#define SW_T(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SW_T(I) do {} while (0)
+#endif
     for (int z = 0; z <= D; ++z) {
+      SW_T(0);
       if (z >= 1) {
         const int p = z - 1;
         const unsigned char* slot = planes + (p % SW_NSLOT) * SW_SLOT + boff;
@@ -553,10 +606,19 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
           }
         }
 #endif
+#if SW_ABL & 256
+        asm volatile("s_nop 0" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]));      // all MFMAs issued
+#endif
+        SW_T(1);
+#if SW_ABL & 256
+        asm volatile("v_mov_b32 %0, %0" : "+v"(Xp[SW_CR_ - 1][0]));      // the last MFMA's result has landed
+#endif
+        SW_T(2);
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
         for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
       }
+      SW_T(3);
       // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
       // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
       // with a memory clobber pins every LDS access to its side of the barrier.  The lgkmcnt(0) covers the other direction:
@@ -566,7 +628,16 @@ __global__ __launch_bounds__(SW_THREADS, 3) void conv0_sweep_kernel(const SweepD
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#if SW_ABL & 256
+      SW_T(4);
+      if (z >= 2) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += tq[3] - tq[2]; tm[3] += tq[4] - tq[3]; tm[4] += 1; }
+#endif
     }
+#if SW_ABL & 256
+    if (lane == 0 && (blockIdx.x % 4099) == 17)
+      printf("consumer %d of block %d: per plane: reads + MFMA issue %llu, last MFMA lands %llu, epilogue %llu, barrier %llu cycles\n", cw, (int)blockIdx.x,
+             tm[0] / tm[4], tm[1] / tm[4], tm[2] / tm[4], tm[3] / tm[4]);
+#endif
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
 #if SW_EXIT_BARRIER
     __builtin_amdgcn_s_barrier();
@@ -595,6 +666,7 @@ void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& pa
 
 int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   RGBM_REQUIRE(dtype == BF16 || dtype == F16, "conv0 sweep: 16-bit storage types only");
+  RGBM_REQUIRE(!t.feat_f16 || dtype == BF16, "conv0 sweep: feat_f16 is the bf16 nets' option");
   SweepDesc d;
   d.feat = reinterpret_cast<const unsigned short*>(t.feat);
   d.wgt = reinterpret_cast<const unsigned short*>(t.wgt);
@@ -608,19 +680,29 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   RGBM_REQUIRE((d.tile_list == nullptr) == (d.tile_count == nullptr), "conv0 sweep: tile list and count go together");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 0>), SW_LDS)) return rc;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 1>), SW_LDS)) return rc;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<unsigned short, 2>), SW_LDS)) return rc;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_sweep_kernel<f16_t, 0>), SW_LDS)) return rc;
-  prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
-  // bf16 blend mode (see blend_chunk).  Default since round 5: the plain fp32 blend (mode 0; the library is built without packed fp32
-  // instructions, so it is scalar v_fma_f32 code) — on this build the three modes are level (44.11 / 44.15 / 44.09 ms per forward, same-box
-  // interleaved) and the dot2 form rounds the four bilinear weights to 8 bits (c0 mean error 1.9e-3 against < 1e-3).  Debug flag
-  // 4194304 = v_perm + v_dot2_f32_bf16 (the round-4 default), 2097152 = fp32 FMAs from inline asm.
-  if (dtype == BF16 && (g_debug_flags & (1 << 22))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 2>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
-  else if (dtype == BF16 && (g_debug_flags & (1 << 21))) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 1>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
-  else if (dtype == BF16) hipLaunchKernelGGL((conv0_sweep_kernel<unsigned short, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
-  else hipLaunchKernelGGL((conv0_sweep_kernel<f16_t, 0>), dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);
+  typedef unsigned short u16;
+#define SW_LAUNCH(...)                                                                                             \
+  do {                                                                                                             \
+    auto kern = conv0_sweep_kernel<__VA_ARGS__>;                                                                   \
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), SW_LDS)) return rc;                       \
+    prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);                               \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(SW_THREADS), SW_LDS, s, d);                                \
+  } while (0)
+  // Blend (see blend_chunk / blend_chunk_f16).  bf16 nets whose `final` wrote the feature map as f16 (t.feat_f16, the default): packed f16
+  // FMAs (mode 3) - the only form whose instructions fit between another wave's MFMAs (tools/micro/mfma_valu_coissue.hip); three more
+  // mantissa bits than the bf16 features had.  fp16 nets keep the fp32-accumulating v_fma_mix form (their c0 stays within 1e-4 of the
+  // halo-tile conv0; the packed form measures 4.7e-4 and saturates per partial sum): debug flag 2097152 selects the packed form for them
+  // (sweep 15.3 -> 14.6 ms dense).  bf16 feature maps (option sweep_f16 = 0): the plain fp32 blend (mode 0; on the library
+  // without packed fp32 instructions the three bf16 modes are level - 44.11 / 44.15 / 44.09 ms per forward - and the dot2 form rounds the
+  // bilinear weights to 8 bits); debug flag 4194304 = v_perm + v_dot2_f32_bf16 (the round-4 default), 2097152 = fp32 FMAs from inline asm.
+  const bool f21 = (g_debug_flags & (1 << 21)) != 0, f22 = (g_debug_flags & (1 << 22)) != 0;
+  if (dtype == BF16 && t.feat_f16) SW_LAUNCH(f16_t, u16, 3);
+  else if (dtype == BF16 && f22) SW_LAUNCH(u16, u16, 2);
+  else if (dtype == BF16 && f21) SW_LAUNCH(u16, u16, 1);
+  else if (dtype == BF16) SW_LAUNCH(u16, u16, 0);
+  else if (f21) SW_LAUNCH(f16_t, f16_t, 3);
+  else SW_LAUNCH(f16_t, f16_t, 0);
+#undef SW_LAUNCH
   prof_end_launch(s);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

@@ -322,8 +322,8 @@ void UpConvFinal::destroy() {
   wz = wf = nullptr; bias = biasf = nullptr;
 }
 
-int UpConvFinal::run(const void* in, void* out, bool out_f32, int V, int h, int w, hipStream_t s) const {
-  return launch_upconv_final(dtype, in, wz, bias, slope, wf, biasf, out, out_f32 ? 1 : 0, V, h, w, s);
+int UpConvFinal::run(const void* in, void* out, int out_kind, int V, int h, int w, hipStream_t s) const {
+  return launch_upconv_final(dtype, in, wz, bias, slope, wf, biasf, out, out_kind, V, h, w, s);
 }
 
 }  // namespace rgbm

@@ -90,8 +90,8 @@ struct UpConvFinal {
   // w3 [64][64][3][3], b3 [64], wfin [32][64], bfin [32] (nn.Conv2d layouts)
   int init(int dtype, const float* w3, const float* b3, float slope, const float* wfin, const float* bfin);
   void destroy();
-  // in [V][h][w][64] -> out [V][2h][2w][32] (storage type, or plain fp32 when out_f32: split-pair path only)
-  int run(const void* in, void* out, bool out_f32, int V, int h, int w, hipStream_t s) const;
+  // in [V][h][w][64] -> out [V][2h][2w][32] (storage type; plain fp32: split-pair path only; f16: bf16 path only)
+  int run(const void* in, void* out, int out_kind, int V, int h, int w, hipStream_t s) const;      // out_kind: launch_upconv_final's out_f32 (0 storage type, 1 plain fp32, 2 f16)
 };
 
 // device upload helpers

@@ -72,7 +72,7 @@ __device__ __forceinline__ void combine_tap(const unsigned char* zl, const float
   }
 }
 
-template <typename T, bool OUTF32>
+template <typename T, int OUTK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void upconv_final_kernel(const T* __restrict__ x, const T* __restrict__ wz,
                                                            const float* __restrict__ bias, float nslope, const T* __restrict__ wf,
                                                            const float* __restrict__ biasf, void* __restrict__ out, int V, int h,
@@ -282,19 +282,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       float r[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = facc[m][q][e] + bv[e];
-      if constexpr (OUTF32) store4(reinterpret_cast<float*>(out) + o, r);
+      if constexpr (OUTK == 1) store4(reinterpret_cast<float*>(out) + o, r);
+      else if constexpr (OUTK == 2) store4(reinterpret_cast<f16_t*>(out) + o, r);      // saturating
       else store4(reinterpret_cast<T*>(out) + o, r);
     }
   }
 }
 
-template <typename T, bool OUTF32>
+template <typename T, int OUTK>
 int launch_t(const void* x, const void* wz, const float* bias, float nslope, const void* wf, const float* biasf, void* out, int V,
              int h, int w, hipStream_t s) {
   constexpr int XROW = kC * (int)sizeof(T) + 16;
   constexpr int lds_taps = 16 * kNT * XROW + 16 * kNT * kZRow, lds_y = 256 * XROW;
   constexpr int lds = lds_taps > lds_y ? lds_taps : lds_y;
-  auto kern = upconv_final_kernel<T, OUTF32>;
+  auto kern = upconv_final_kernel<T, OUTK>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
   const long long ntile = (long long)V * (2 * h / 16) * (2 * w / 16);
   RGBM_REQUIRE(ntile > 0 && ntile < (1ll << 30), "upconv + final grid out of range");
@@ -309,22 +310,25 @@ int launch_t(const void* x, const void* wz, const float* bias, float nslope, con
 }  // namespace
 
 // x [V][h][w][64] -> out [V][2h][2w][32] = final(PReLU(up_3(x)));  wz [9 * 64][64] (tap-major rows, storage type), wf [32][64].
-// out_f32: the feature map as plain fp32 (the bf16x3 path's sweep kernel reads it so).
+// out_f32 (the output kind): 0 = storage type; 1 = the feature map as plain fp32 (bf16x3 nets: the split-pair sweep kernel reads it so);
+// 2 = f16 (bf16 nets: the plane sweep's packed-f16 blend and the point heads read it so - AdaPose::feat_f16()).
 int launch_upconv_final(int dtype, const void* x, const void* wz, const float* bias, float slope, const void* wf, const float* biasf,
                         void* out, int out_f32, int V, int h, int w, hipStream_t s) {
   RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "upconv + final: 16-bit or split-pair storage");
   RGBM_REQUIRE(h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "upconv + final: low-resolution size must be a multiple of 8");
-  RGBM_REQUIRE(!out_f32 || dtype == BF16X3, "upconv + final: plain fp32 output is the split-pair path's");
+  RGBM_REQUIRE(out_f32 >= 0 && out_f32 <= 2 && (out_f32 != 1 || dtype == BF16X3) && (out_f32 != 2 || dtype == BF16),
+               "upconv + final: plain fp32 output is the split-pair path's, f16 output the bf16 path's");
   const double npx = (double)V * 4.0 * h * w;
   // profiler row 39; algorithmic flops: the commuted product (9 x 64 x 64 per low-resolution pixel), 36 multiply-adds per up_3
   // output element, the 1x1; bytes: x in + feature map out
   prof_begin_launch(s, 39, 2.0 * (npx / 4.0) * 9.0 * kC * kC + 72.0 * npx * kC + 2.0 * npx * kC * kC2,
-                    (npx / 4.0) * kC * dtype_size(dtype) + npx * kC2 * (out_f32 ? 4.0 : (double)dtype_size(dtype)));
+                    (npx / 4.0) * kC * dtype_size(dtype) + npx * kC2 * (out_f32 == 1 ? 4.0 : (double)dtype_size(dtype)));
   int rc;
-  if (dtype == BF16) rc = launch_t<unsigned short, false>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
-  else if (dtype == F16) rc = launch_t<f16_t, false>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
-  else if (out_f32) rc = launch_t<bx3_t, true>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
-  else rc = launch_t<bx3_t, false>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
+  if (dtype == BF16 && out_f32 == 2) rc = launch_t<unsigned short, 2>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
+  else if (dtype == BF16) rc = launch_t<unsigned short, 0>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
+  else if (dtype == F16) rc = launch_t<f16_t, 0>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
+  else if (out_f32) rc = launch_t<bx3_t, 1>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
+  else rc = launch_t<bx3_t, 0>(x, wz, bias, slope, wf, biasf, out, V, h, w, s);
   prof_end_launch(s);
   return rc;
 }

@@ -609,16 +609,21 @@ def _sweep_case(B, D, H, W, seed, singular_pose=None):
     return feat, torch.from_numpy(P), torch.from_numpy(depths)
 
 
-@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16])
+@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16, "f16feat", "f16pk"])
 @pytest.mark.parametrize("shape", [(5, 20, 37), (1, 16, 16), (24, 33, 16), (3, 48, 50)])
 def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
     """Depth-sweeping conv0 (plane sweep fused, paired depth taps, producer/consumer waves) against the two kernels it
     replaces run one after the other: build_volume (pinned to the reference's homo_warping golden above) followed by a
-    plain fp32 conv3d + folded BN + ReLU on that bf16 volume.  Ragged tiles in H and W, D = 1, and NaN isolation."""
+    plain fp32 conv3d + folded BN + ReLU on that volume.  Ragged tiles in H and W, D = 1, and NaN isolation.
+    "f16feat": what a bf16 net runs by default since round 5 — f16 features and weights, packed-f16 blend, bf16 c0
+    (rgbm_conv0_sweep_f16feat); "f16pk": an fp16 net's sweep with the packed-f16 blend (debug flag 2097152)."""
     from gpu_util import to_channels_last, from_channels_last, rel_err, host_f32, TORCH_DT
     lib = _lib.load()
     D, H, W = shape
     B, V = 2, 4
+    variant = dtype
+    dtype = _lib.F16 if variant in ("f16feat", "f16pk") else dtype       # the type of the features, the weights and the volume of the reference
+    odt = _lib.BF16 if variant == "f16feat" else dtype                   # the type of c0
     tdt = TORCH_DT[dtype]
     g = torch.Generator().manual_seed(7)
     w = torch.randn(8, 32, 3, 3, 3, generator=g) / np.sqrt(32 * 27)
@@ -638,9 +643,17 @@ def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
         vol = torch.empty(V, D, H, W, 32, dtype=tdt, device="cuda")
         _lib.check(lib.rgbm_build_volume(dtype, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), _lib.ptr(vol),
                                          V, B, D, H, W, _lib.stream_ptr()), "rgbm_build_volume")
-        out = torch.full((V, D, H, W, 8), float("nan"), dtype=tdt, device="cuda")
-        _lib.check(lib.rgbm_conv0_sweep_dt(dtype, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out),
-                                           V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_dt")
+        out = torch.full((V, D, H, W, 8), float("nan"), dtype=TORCH_DT[odt], device="cuda")
+        if variant == "f16feat":
+            _lib.check(lib.rgbm_conv0_sweep_f16feat(_lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out),
+                                                    V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_f16feat")
+        else:
+            _lib.check(lib.rgbm_debug_flags((1 << 21) if variant == "f16pk" else 0))
+            try:
+                _lib.check(lib.rgbm_conv0_sweep_dt(dtype, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out),
+                                                   V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_dt")
+            finally:
+                _lib.check(lib.rgbm_debug_flags(0))
         torch.cuda.synchronize()
         x = vol.float().cpu().permute(0, 4, 1, 2, 3)
         ref = F.relu(F.conv3d(x, wf, None, 1, 1) + shift.view(1, -1, 1, 1, 1))
@@ -649,11 +662,12 @@ def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
     y, ref, x = run(None)
     assert torch.isfinite(y).all()
     # some projections must land inside and some outside the partner image, or the case tests nothing
-    assert rel_err(y, ref) < (1e-2 if dtype == _lib.BF16 else 2e-3), shape      # one rounding of the output
+    assert rel_err(y, ref) < (1e-2 if odt == _lib.BF16 else 2e-3), shape      # one rounding of the output
     # bf16: the default blend (fp32 weights since round 5) measures a mean of 1.5e-3; the dot2 blend behind debug flag 4194304 (the
-    # round-4 default) rounds the bilinear weights to bf16 as well: 2.1e-3 (checked right below on the same case)
-    assert float((y - ref).abs().mean() / ref.abs().mean()) < (2e-3 if dtype == _lib.BF16 else 3e-4)
-    if dtype == _lib.BF16:
+    # round-4 default) rounds the bilinear weights to bf16 as well: 2.1e-3 (checked right below on the same case).  f16 features ->
+    # bf16 c0: the output's rounding alone.  fp16 with the packed blend: four f16 roundings per blended value, 4.2e-4 measured.
+    assert float((y - ref).abs().mean() / ref.abs().mean()) < {_lib.BF16: 2e-3, "f16feat": 2e-3, "f16pk": 6e-4}.get(variant, 3e-4)
+    if variant == _lib.BF16:
         _lib.check(lib.rgbm_debug_flags(1 << 22))          # v_perm + v_dot2_f32_bf16 blend: 8-bit weights
         try:
             yp, refp, _ = run(None)
@@ -751,6 +765,24 @@ def test_conv0_sweep_fp16_blend_saturates():
     y = from_channels_last(out)
     assert torch.isfinite(y).all()
     assert rel_err(y, ref) < 2e-3
+    # the packed-f16 blend (debug flag 2097152; what a bf16 net's sweep runs on its f16 feature map) clamps every partial sum, not the final
+    # one: a different number where partial sums overflow (4e-2 of this case's scale), but never inf or NaN
+    for entry in ("pk", "f16feat"):
+        out2 = torch.full((V, D, H, W, 8), float("nan"), dtype=torch.float16 if entry == "pk" else torch.bfloat16, device="cuda")
+        if entry == "pk":
+            _lib.check(lib.rgbm_debug_flags(1 << 21))
+            try:
+                _lib.check(lib.rgbm_conv0_sweep_dt(_lib.F16, _lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out2),
+                                                   V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_dt")
+            finally:
+                _lib.check(lib.rgbm_debug_flags(0))
+        else:
+            _lib.check(lib.rgbm_conv0_sweep_f16feat(_lib.ptr(fd), _lib.ptr(Pd), _lib.ptr(dd), _lib.ptr(hom), wp, sp, hp, _lib.ptr(out2),
+                                                    V, B, D, H, W, _lib.stream_ptr()), "rgbm_conv0_sweep_f16feat")
+        torch.cuda.synchronize()
+        y2 = from_channels_last(out2)
+        assert torch.isfinite(y2).all(), entry
+        assert rel_err(y2, ref) < 8e-2, entry
 
 
 @pytest.mark.parametrize("dtype", [_lib.F32, _lib.BF16])
