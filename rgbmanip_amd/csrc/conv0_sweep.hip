@@ -26,7 +26,7 @@
 #ifndef SW_ABL
 #define SW_ABL 0      // ablation builds only (tools/abl_sweep_flags.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel,
                       // 16 no output stores, 32 no per-plane projection (the first plane's corners are reused), 64 gathers from one address,
-                      // 256 s_memtime phase timers, printed by a few workgroups
+                      // 256 s_memtime phase timers, printed by a few workgroups, 512 no operand reads in the consumers
 #endif
 
 namespace rgbm {
@@ -49,8 +49,26 @@ constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
                       // one workgroup per CU forced and with all waves retiring together as well, while the ring + barrier protocol in
                       // isolation (tools/micro/ring_barrier.hip: two slots, 5.4e9 checked reads per variant) never fails.
 #endif
+#ifndef SW_COOP
+#define SW_COOP 1     // packed-f16 instantiations: cooperative gathers - four lanes read the four 16-byte chunks of ONE corner pixel (a gather instruction
+                      // touches 16 pixels' 64-byte runs instead of 64 lanes' 16-byte pieces of 64 pixels).  Same box, dense, ms per step:
+                      // lane per voxel 14.05, quads with a DPP exchange 13.2 (and 15.4 with 16 consecutive voxels per round + ds_bpermute_b32)
+#endif
+#ifndef SW_RELU_PK
+#define SW_RELU_PK 0  // bf16 c0: ReLU after the conversion, on the packed pair, as max(int16, 0): half the epilogue's instructions and no gain (14.45 -> 14.3 ms), and it
+                      // zeroes the NaN voxels of a singular pose (their sign bit is set when they leave the MFMAs: the NaN-isolation test fails) - off
+#endif
+#ifndef SW_PRE
+#define SW_PRE 0      // > 0 (3, 6, 9): the consumers run TWO planes behind the producers (four ring slots) and read the first SW_PRE operand fragments
+                      // of the next plane while the current plane's output epilogue runs.  Round 5, timers in the kernel (-DSW_ABL=256): since
+                      // the packed-f16 blend the consumers are the critical path - 1160-1200 cycles from the barrier to the last MFMA issue for
+                      // 864 cycles of MFMAs - but taking the first reads' LDS round trip out of that phase only moves the time (the phase
+                      // shrinks by 100 cycles, the epilogue with the reads in it grows by as much): 13.2 ms dense with 0, 13.3 with 6, and
+                      // 9 does not fit the 168-register budget.  Off; kept because the two-plane lag is what a persistent version would need.
+#endif
+constexpr int SW_LAG = SW_PRE > 0 ? 2 : 1;
 #ifndef SW_NSLOT_N
-#define SW_NSLOT_N 3
+#define SW_NSLOT_N (SW_PRE > 0 ? 4 : 3)
 #endif
 #ifndef SW_VS_BYTES
 #define SW_VS_BYTES 80
@@ -100,7 +118,8 @@ constexpr int SW_NSLOT = SW_NSLOT_N;
 #define SW_EXIT_BARRIER 0  // experiment builds: one more barrier after the last plane, so that all waves of a workgroup retire together
 #endif
 constexpr int SW_LDS = SW_NSLOT * SW_SLOT + SW_LDS_PAD;
-static_assert(SW_TH % SW_CR_ == 0 && !(SW_HAND && SW_CR_ != 4), "a consumer wave owns SW_CR rows");
+static_assert(SW_TH % SW_CR_ == 0 && !(SW_HAND && SW_CR_ != 4) && !(SW_HAND && SW_PRE), "a consumer wave owns SW_CR rows");
+static_assert((SW_PRE == 0 || SW_PRE == 3 || SW_PRE == 6 || SW_PRE == 9) && SW_PRE <= 3 * SW_CR_ && SW_NSLOT_N > SW_LAG, "the prefetched fragments are those of the first in-plane tap row; the ring holds the plane being written and the SW_LAG behind it");
 constexpr int SW_NPAIR = (SW_CR_ + 1) / 2;       // fragment pairs of the output epilogue; with an odd SW_CR the last fragment pairs with itself
 
 struct SweepDesc {
@@ -267,6 +286,10 @@ template <typename T, typename TO, int BL>
 __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if SW_ABL & 256
+  unsigned long long t_entry;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+#endif
 
   // XCD-aware tile order: every XCD walks a contiguous run of tiles (whole views) so the partner feature maps its CUs
   // gather from stay in that XCD's L2
@@ -287,6 +310,166 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
   if (wave < SW_NPW) {
     // ------------------------------------------------------------------ producers
     if (std::is_same<T, f16_t>::value) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);      // MODE.FP16_OVFL = 1 (see blend_chunk<f16_t>)
+#if SW_ABL & 256
+    unsigned long long tm[3] = {0, 0, 0}, tq[3];
+#define SW_TP(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SW_TP(I) do {} while (0)
+#endif
+    if constexpr (BL == 3 && SW_COOP != 0) {
+    // ---- cooperative form (packed-f16 blend).  The projection stays one lane per voxel (lane l of producer wave w owns voxel 64 w + l and
+    // computes its four corner offsets and weights); the gathers, the blend and the LDS store run per (voxel, 16-byte chunk): in round r
+    // lane l handles chunk l & 3 of voxel 64 w + (l & ~3) + r - one of its own quad's four voxels - and takes that voxel's offsets and
+    // weights from lane (l & ~3) + r with a DPP quad broadcast (a VALU move; the first version took 16 consecutive voxels per round and
+    // fetched with ds_bpermute_b32: 32 LDS round trips per plane made the producers 30 % slower than lane-per-voxel).  A gather instruction
+    // touches 16 pixels' 64-byte runs instead of 64 lanes' 16-byte pieces.  Same rolling schedule as the lane-per-voxel form: round r of plane z + 1 is requested right after
+    // round r of plane z has been blended out of the same registers; 12 of 16 gathers stay in flight.
+    const int ck = lane & 3;
+    const int pv = tid;                                  // the projection's voxel
+    const bool act = pv < SW_NV;
+    const int hh = pv / SW_HW, hw = pv - hh * SW_HW;
+    const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+    const bool inb = act && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+    const int partner = (vv + d.B) % d.V, bb = vv % d.B;
+    const float* __restrict__ hm = d.homog + (long long)vv * 12;
+    const float* __restrict__ dep = d.depths + (long long)bb * D;
+    const unsigned char* __restrict__ srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
+    uint4 ref[4];                                        // [round]: chunk ck of the round's voxel
+    unsigned dsto[4];                                    // LDS byte offset of that chunk inside a plane slot
+    bool actr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cv = wave * 64 + (lane & ~3) + r;
+      const int ch_ = cv / SW_HW, cw_ = cv - ch_ * SW_HW;
+      const int ggh = h0 - 1 + ch_, ggw = w0 - 1 + cw_;
+      actr[r] = cv < SW_NV;
+      dsto[r] = (unsigned)(cv * SW_VS + ck * 16);
+      ref[r] = make_uint4(0u, 0u, 0u, 0u);               // outside the image: conv zero padding
+      if (actr[r] && (unsigned)ggh < (unsigned)H && (unsigned)ggw < (unsigned)W)
+        ref[r] = *reinterpret_cast<const uint4*>(d.feat + (((long long)vv * H + ggh) * W + ggw) * 32 + ck * 8);
+    }
+    const float x = (float)gw, y = (float)gh;
+    const float rx = hm[0] * x + hm[1] * y + hm[2];
+    const float ry = hm[3] * x + hm[4] * y + hm[5];
+    const float rz = hm[6] * x + hm[7] * y + hm[8];
+    const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
+    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+    const int dbits = __float_as_int(lane < D ? dep[lane] : 1.f);
+    // per voxel: four byte offsets of the (clamped) corner pixels and the four weights as f16 pairs (0 outside the image, NaN for a
+    // non-finite projection) - the same arithmetic as the lane-per-voxel form below
+    auto corners = [&](int z, unsigned (&off)[4], unsigned (&wp)[4]) {
+      const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
+      const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
+      const float rinv = __builtin_amdgcn_rcpf(pz);
+      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
+      const bool fin = isfinite(ix) && isfinite(iy);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+      const float ux = 1.f - tx, uy = 1.f - ty;
+      float w[4];
+      w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
+      w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
+      w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
+      w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
+      if (inb && !fin) w[0] = __builtin_nanf("");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
+        wp[q] = __builtin_bit_cast(unsigned, h);
+      }
+      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+      off[0] = (r0 + (unsigned)xc0) * 64u;
+      off[1] = (r0 + (unsigned)xc1) * 64u;
+      off[2] = (r1 + (unsigned)xc0) * 64u;
+      off[3] = (r1 + (unsigned)xc1) * 64u;
+    };
+    u32x4 g[4][4];                                       // [round][corner]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
+    unsigned wco[4][4];                                  // [round][corner]: weights of the gathers in flight
+#define SW_CGATHER(R, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(g[R][Q]) : "v"(OFF), "s"(srcb) : "memory")
+#if SW_ABL & 4
+#undef SW_CGATHER
+#define SW_CGATHER(R, Q, OFF) do { (void)(OFF); } while (0)
+#endif
+#define SW_CWAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+    // request round R of the plane whose per-voxel values are (off, wp): every lane fetches its voxel's four offsets and weights
+#define SW_CREQ(R, OFFV, WPV)                                                                                         \
+    do {                                                                                                              \
+      unsigned o_[4];                                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                 \
+        o_[q] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(OFFV)[q], (R) * 0x55, 0xf, 0xf, false) | (unsigned)(ck * 16);      \
+        wco[R][q] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(WPV)[q], (R) * 0x55, 0xf, 0xf, false);             \
+      }                                                                                                               \
+      SW_CGATHER(R, 0, o_[0]); SW_CGATHER(R, 1, o_[1]); SW_CGATHER(R, 2, o_[2]); SW_CGATHER(R, 3, o_[3]);             \
+    } while (0)
+    unsigned noff[4], nwp[4];
+    corners(0, noff, nwp);
+    SW_CREQ(0, noff, nwp); SW_CREQ(1, noff, nwp); SW_CREQ(2, noff, nwp); SW_CREQ(3, noff, nwp);
+    auto blend4 = [&](const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e, const unsigned (&w)[4]) {
+      const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb4[4] = {b[0], b[1], b[2], b[3]};
+      const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned t;
+        asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(t) : "v"(aa[q]), "v"(w[0]), "v"(rr[q]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(bb4[q]), "v"(w[1]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(cc[q]), "v"(w[2]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(ee[q]), "v"(w[3]));
+        o[q] = t;
+      }
+      return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    // (two loops, not `if (z < D)` inside one: the plane loop that holds the counted waits has no branch but its back edge - check_asm_gathers.py)
+    for (int z = 0; z < D; ++z) {
+      SW_TP(0);
+#if !(SW_ABL & 32)
+      corners(min(z + 1, D - 1), noff, nwp);             // last plane: a harmless re-request keeps the wait counts static
+#endif
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ref[k].x), "+v"(ref[k].y), "+v"(ref[k].z), "+v"(ref[k].w));
+      unsigned char* dst = planes + (z % SW_NSLOT) * SW_SLOT;
+#define SW_CROUND(R)                                                                                                  \
+      do {                                                                                                            \
+        SW_CWAIT12(R);                                                                                                \
+        if (!(SW_ABL & 1)) {                                                                                          \
+          const uint4 o4 = blend4(ref[R], g[R][0], g[R][1], g[R][2], g[R][3], wco[R]);                                \
+          if (actr[R]) *reinterpret_cast<uint4*>(dst + dsto[R]) = o4;                                                 \
+        }                                                                                                             \
+        SW_CREQ(R, noff, nwp);                                                                                        \
+      } while (0)
+      SW_CROUND(0); SW_CROUND(1); SW_CROUND(2); SW_CROUND(3);
+#undef SW_CROUND
+      // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SW_TP(1);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
+#if SW_ABL & 256
+      SW_TP(2);
+      if (z >= 1) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += 1; }
+#endif
+    }
+    for (int z = D; z < D + SW_LAG; ++z) {               // the consumers run SW_LAG planes behind
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#if SW_ABL & 256
+    if (lane == 0 && (blockIdx.x % 4099) == 17)
+      printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
+#endif
+#undef SW_CGATHER
+#undef SW_CWAIT12
+#undef SW_CREQ
+    } else {
     const int pv = tid;                                  // voxel of the (TH+2) x 18 plane
     const bool act = pv < SW_NV;
     const int hh = pv / SW_HW, hw = pv - hh * SW_HW;
@@ -408,13 +591,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       corners(0, cur);
       SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
     }
-#if SW_ABL & 256
-    unsigned long long tm[3] = {0, 0, 0}, tq[3];
-#define SW_TP(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SW_TP(I) do {} while (0)
-#endif
-    for (int z = 0; z <= D; ++z) {
+    for (int z = 0; z < D + SW_LAG; ++z) {
       SW_TP(0);
       if (act && z < D) {
 #if SW_ABL & 32
@@ -468,6 +645,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
     if (lane == 0 && (blockIdx.x % 4099) == 17)
       printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
 #endif
+    }
 #if SW_EXIT_BARRIER
     __builtin_amdgcn_s_barrier();
 #endif
@@ -523,9 +701,11 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
 #endif
     // after the lane-half swap a lane holds: fragment (lg < 2 ? first : second of the pair), voxel lr, channels (lg&1)*4..+3
     const int ch = (lg & 1) * 4;
-    float bias[4];
+    // the folded BatchNorm shift is the initial value of the accumulator rows that become outputs (rows 8-15 = lanes 32-63 before the lane-half
+    // swap: lane group lg holds rows 4 lg .. 4 lg + 3); rows 0-7 start at 0
+    f32x4 binit;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = d.bias[ch + r];
+    for (int r = 0; r < 4; ++r) binit[r] = lg >= 2 ? d.bias[(lg & 1) * 4 + r] : 0.f;
     const int ow = w0 + lr;
     int oh[SW_NPAIR];
     bool ook[SW_NPAIR];
@@ -556,31 +736,57 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         }
         if (o >= 0 && ook[pr]) {
           float v[4];
+          TO* const dst = reinterpret_cast<TO*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch;
+          if constexpr (std::is_same<TO, unsigned short>::value && SW_RELU_PK) {
+            // bf16 c0: round first, then ReLU on the packed pair as max(int16, 0) - negative values (and -0) have the sign bit, the NaN this
+            // kernel can hold (the producers' marker for a non-finite projection, propagated by FMAs and MFMAs) does not: 8 + 4 + 4
+            // instructions per 8 values where add / compare / wait states / select / convert took 36
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = (hi[r] + Lp[pr][r]) + bias[r];
-            if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
+            for (int r = 0; r < 4; ++r) v[r] = hi[r] + Lp[pr][r];
+            unsigned p0 = pack2_bf16(v[0], v[1]), p1 = pack2_bf16(v[2], v[3]);
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(p0) : "v"(p0));
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(p1) : "v"(p1));
+            if (!(SW_ABL & 16) || p0 == 12345u) *reinterpret_cast<uint2*>(dst) = make_uint2(p0, p1);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = hi[r] + Lp[pr][r];
+              v[r] = v[r] < 0.f ? 0.f : v[r];                        // conv0 always has its ReLU (the launcher checks); NaN propagates, like torch.relu
+            }
+            if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(dst, v);
           }
-          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(reinterpret_cast<TO*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
         }
         Lp[pr] = lo;
       }
     };
 
 #if SW_ABL & 256
+    unsigned long long t_loop;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop) :: "memory");
     unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq[5];
 #define SW_T(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SW_T(I) do {} while (0)
 #endif
-    for (int z = 0; z <= D; ++z) {
+    // operand fragments of a plane: b[r][c] = voxels (row cw * SW_CR + r, columns c .. c + 15) of the 14 x 18 input plane, r < SW_CR + 2
+    sw_u4v pre[SW_PRE > 0 ? SW_PRE : 1];      // fragment k = b[k % SW_CR][k / SW_CR] of the NEXT plane (the first in-plane taps' operands)
+#pragma unroll
+    for (int k = 0; k < (SW_PRE > 0 ? SW_PRE : 1); ++k) pre[k] = sw_u4v{0u, 0u, 0u, 0u};
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
+    auto prefetch = [&](int q) {       // plane q is complete (its barrier lies one iteration back) and stays untouched for SW_NSLOT - 1 more
+      const unsigned sa = lds_base + (unsigned)((q % SW_NSLOT) * SW_SLOT + boff);
+#pragma unroll
+      for (int k = 0; k < SW_PRE; ++k)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[k]) : "v"(sa), "n"(((k % SW_CR_) * SW_HW + k / SW_CR_) * SW_VS) : "memory");
+    };
+    for (int z = 0; z < D + SW_LAG; ++z) {
       SW_T(0);
-      if (z >= 1) {
-        const int p = z - 1;
+      if (z >= SW_LAG) {
+        const int p = z - SW_LAG;
         const unsigned char* slot = planes + (p % SW_NSLOT) * SW_SLOT + boff;
         f32x4 Xn[SW_CR_];
 #pragma unroll
-        for (int f = 0; f < SW_CR_; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < SW_CR_; ++f) Xn[f] = binit;
 #if SW_HAND
         // 18 half-tap steps of 2 fragment reads + 4 MFMAs; the reads of step i + 2 are issued behind the MFMAs of step i into the
         // set step i - 2 multiplied from; at step i the reads of steps i and i + 1 are outstanding and LDS operations complete
@@ -596,19 +802,36 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         // the accumulators so that no such read can be scheduled in front of them
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Xn[3]) :: "memory");
 #else
+        uint4 b[SW_CR_ + 2][3];
+#pragma unroll
+        for (int r = 0; r < SW_CR_ + 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            if (r < SW_CR_ && c * SW_CR_ + r < SW_PRE) b[r][c] = __builtin_bit_cast(uint4, pre[c * SW_CR_ + r]);      // read during the previous iteration
+#if SW_ABL & 512
+            else b[r][c] = make_uint4(0x3c003c00u + r + lane, 0x3c003c00u + c, 0x3c003c00u + (unsigned)p, 0x3c003c00u);
+#else
+            else b[r][c] = *reinterpret_cast<const uint4*>(slot + (r * SW_HW + c) * SW_VS);
+#endif
+          }
 #pragma unroll
         for (int tp = 0; tp < ((SW_ABL & 2) ? 0 : 9); ++tp) {
 #pragma unroll
           for (int f = 0; f < SW_CR_; ++f) {
-            const uint4 b = *reinterpret_cast<const uint4*>(slot + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
-            Xn[f] = Sw16<T>::mma(A01[tp], b, Xn[f]);
-            Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
+            Xn[f] = Sw16<T>::mma(A01[tp], b[f + tp / 3][tp % 3], Xn[f]);
+            Xp[f] = Sw16<T>::mma(A2[tp], b[f + tp / 3][tp % 3], Xp[f]);
           }
         }
 #endif
 #if SW_ABL & 256
         asm volatile("s_nop 0" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]));      // all MFMAs issued
 #endif
+        if (SW_PRE > 0 && p + 1 < D) {
+          // the next plane's first operands travel while the epilogue below runs; tied to the accumulators so that hipcc keeps the reads
+          // behind this plane's MFMAs (their registers are this plane's operands until then)
+          asm volatile("" : "+v"(Xp[0]), "+v"(Xn[SW_CR_ - 1]) :: "memory");
+          prefetch(p + 1);
+        }
         SW_T(1);
 #if SW_ABL & 256
         asm volatile("v_mov_b32 %0, %0" : "+v"(Xp[SW_CR_ - 1][0]));      // the last MFMA's result has landed
@@ -618,6 +841,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
 #pragma unroll
         for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
       }
+      else if (SW_PRE > 0 && z == SW_LAG - 1) prefetch(0);      // plane 0 is complete since the barrier of iteration 0
       SW_T(3);
       // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
       // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
@@ -625,20 +849,27 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       // MFMAs are not memory operations, so hipcc may sink a plane's last ds_read/MFMA pairs below the barrier (seen in
       // the peeled first iteration of an experimental build) — the read would then still be queued when the producers
       // start to overwrite the slot.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (SW_PRE == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]) :: "memory");
+      else if constexpr (SW_PRE == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]) :: "memory");
+      else if constexpr (SW_PRE == 9) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]), "+v"(pre[7]), "+v"(pre[8]) :: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #if SW_ABL & 256
       SW_T(4);
-      if (z >= 2) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += tq[3] - tq[2]; tm[3] += tq[4] - tq[3]; tm[4] += 1; }
+      if (z >= SW_LAG + 1) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += tq[3] - tq[2]; tm[3] += tq[4] - tq[3]; tm[4] += 1; }
 #endif
     }
 #if SW_ABL & 256
-    if (lane == 0 && (blockIdx.x % 4099) == 17)
-      printf("consumer %d of block %d: per plane: reads + MFMA issue %llu, last MFMA lands %llu, epilogue %llu, barrier %llu cycles\n", cw, (int)blockIdx.x,
-             tm[0] / tm[4], tm[1] / tm[4], tm[2] / tm[4], tm[3] / tm[4]);
-#endif
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
+    unsigned long long t_exit;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit) :: "memory");
+    if (lane == 0 && (blockIdx.x % 4099) == 17)
+      printf("consumer %d of block %d: per plane: reads + MFMA issue %llu, last MFMA lands %llu, epilogue %llu, barrier %llu cycles; entry -> loop %llu, loop %llu (%d iterations), wave total %llu\n", cw, (int)blockIdx.x,
+             tm[0] / tm[4], tm[1] / tm[4], tm[2] / tm[4], tm[3] / tm[4], t_loop - t_entry, tq[4] - t_loop, D + SW_LAG, t_exit - t_entry);
+#else
+    emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
+#endif
 #if SW_EXIT_BARRIER
     __builtin_amdgcn_s_barrier();
 #endif
@@ -677,6 +908,7 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   d.dbg = g_debug_flags;
   d.tile_list = t.tile_list; d.tile_count = t.tile_count;
   RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep arguments");
+  RGBM_REQUIRE(t.relu == 1, "conv0 sweep: the kernel applies conv0's ReLU unconditionally");
   RGBM_REQUIRE((d.tile_list == nullptr) == (d.tile_count == nullptr), "conv0 sweep: tile list and count go together");
   const long long nblk = (long long)d.N * d.nth * d.ntw;
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv0 sweep grid out of range");
