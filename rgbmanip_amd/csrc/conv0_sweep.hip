@@ -779,6 +779,13 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       for (int k = 0; k < SW_PRE; ++k)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[k]) : "v"(sa), "n"(((k % SW_CR_) * SW_HW + k / SW_CR_) * SW_VS) : "memory");
     };
+#if SW_ABL & 512
+    uint4 bfix[SW_CR_ + 2][3];       // timing experiment: operands read once per tile (no LDS reads in the plane loop)
+#pragma unroll
+    for (int r = 0; r < SW_CR_ + 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) bfix[r][c] = *reinterpret_cast<const uint4*>(planes + boff + (r * SW_HW + c) * SW_VS);
+#endif
     for (int z = 0; z < D + SW_LAG; ++z) {
       SW_T(0);
       if (z >= SW_LAG) {
@@ -809,7 +816,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
           for (int c = 0; c < 3; ++c) {
             if (r < SW_CR_ && c * SW_CR_ + r < SW_PRE) b[r][c] = __builtin_bit_cast(uint4, pre[c * SW_CR_ + r]);      // read during the previous iteration
 #if SW_ABL & 512
-            else b[r][c] = make_uint4(0x3c003c00u + r + lane, 0x3c003c00u + c, 0x3c003c00u + (unsigned)p, 0x3c003c00u);
+            else { b[r][c] = bfix[r][c]; asm volatile("" : "+v"(b[r][c].x), "+v"(b[r][c].y), "+v"(b[r][c].z), "+v"(b[r][c].w)); }
 #else
             else b[r][c] = *reinterpret_cast<const uint4*>(slot + (r * SW_HW + c) * SW_VS);
 #endif
@@ -876,6 +883,339 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- persistent form
+// Round 5.  Timers in the one-tile-per-workgroup kernel above (-DSW_ABL=256) put a workgroup's life at 60-65 k cycles of which the 25
+// steady-state plane iterations are 42 k: the rest is the pipeline's fill - the producers' chain of dependent loads (tile list -> homography,
+// depths, reference features -> first corner gathers) in front of plane 0, the consumers' 18 weight loads, the launch of the next
+// workgroup once this one's waves have retired.  Here ONE workgroup per CU walks its tiles and the two roles never drain: the producers go
+// from plane D - 1 of a tile straight to plane 0 of the next (whose reference features, depths and homography were requested a whole tile
+// earlier), the consumers follow one plane behind, keep their weights, and spend one extra output epilogue per tile instead of one
+// iteration.  f16 feature maps + packed-f16 blend + cooperative quad gathers only (what the bf16 nets run); TO = storage type of c0.
+#ifndef SWP_PRE
+#define SWP_PRE 0     // 1: the consumers run TWO planes behind and read ALL operand fragments of the next plane (15 x 16 bytes per lane: the 256-register
+                      // budget of one workgroup per CU has room) while the current plane's epilogue runs - no LDS round trip between the barrier and
+                      // the first MFMA, no read between the MFMAs.  Measured 12.9-13.0 ms dense against 12.5: a denser MFMA phase takes from the
+                      // producer on the same SIMD what it gives the consumer (fp32 arithmetic of another wave does not issue under MFMAs:
+                      // tools/micro/mfma_valu_coissue.hip).  Off.
+#endif
+constexpr int SWP_LAG = SWP_PRE ? 2 : 1;
+constexpr int SWP_NSLOT = 4;                       // 80.6 KB: also keeps a second workgroup off the CU (one workgroup per CU by construction)
+constexpr int SWP_LDS = SWP_NSLOT * SW_SLOT;
+
+template <typename TO>
+__global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(const SweepDesc d) {
+  typedef f16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = d.D, H = d.H, W = d.W;
+  const int nblk = d.tile_list ? d.tile_count[0] : d.N * d.nth * d.ntw;
+  // virtual block v = blockIdx.x + i * gridDim.x (the grid is a multiple of 8, so v % 8 is this workgroup's XCD for every i): the tile order
+  // of the one-tile kernel - every XCD walks a contiguous run of tiles, its CUs side by side on neighbouring tiles of the same views
+  const int bq = nblk >> 3, br = nblk & 7, xcd = blockIdx.x & 7;
+  const int xbase = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq, xcnt = bq + (xcd < br);
+  const int nt = ((int)(blockIdx.x >> 3) < xcnt) ? (xcnt - (int)(blockIdx.x >> 3) + (int)(gridDim.x >> 3) - 1) / (int)(gridDim.x >> 3) : 0;
+  if (nt <= 0) return;
+  auto tile_index = [&](int i) -> int {            // i-th tile of this workgroup (a load when the launch walks a list: callers prefetch)
+    const int t = xbase + (int)(blockIdx.x >> 3) + i * (int)(gridDim.x >> 3);
+    return __builtin_amdgcn_readfirstlane(d.tile_list ? d.tile_list[t] : t);
+  };
+
+  if (wave < SW_NPW) {
+    // ------------------------------------------------------------------ producers (see the cooperative form of conv0_sweep_kernel)
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);         // MODE.FP16_OVFL = 1
+    const int ck = lane & 3;
+    const int pv = tid;
+    const bool act = pv < SW_NV;
+    const int hh = pv / SW_HW, hw = pv - hh * SW_HW;
+    unsigned dsto[4];
+    bool actr[4];
+    int rhh[4], rhw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cv = wave * 64 + (lane & ~3) + r;
+      rhh[r] = cv / SW_HW; rhw[r] = cv - rhh[r] * SW_HW;
+      actr[r] = cv < SW_NV;
+      dsto[r] = (unsigned)(cv * SW_VS + ck * 16);
+    }
+    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+    // what the requests (projection + gathers) of a tile need, per lane = per voxel of the projection
+    struct TileP { int inb; float rx, ry, rz, t0, t1, t2; int dbits; const unsigned char* srcb; };
+    struct TileRaw { float hm[12]; int dbits; int gh, gw; const unsigned char* srcb; };      // loads in flight: nothing derived yet
+    auto tile_request = [&](int t, TileRaw& R, uint4 (&rf)[4]) {      // issue a tile's loads; nothing here waits for them
+      const int tw = t % d.ntw; t /= d.ntw;
+      const int th = t % d.nth; t /= d.nth;
+      const int n = t, h0 = th * SW_TH, w0 = tw * SW_TW, vv = d.v0 + n;
+      const int partner = (vv + d.B) % d.V, bb = vv % d.B;
+      const float* __restrict__ hm = d.homog + (long long)vv * 12;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) R.hm[e] = hm[e];
+      R.dbits = __float_as_int(lane < D ? d.depths[(long long)bb * D + lane] : 1.f);
+      R.gh = h0 - 1 + hh; R.gw = w0 - 1 + hw;
+      R.srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ggh = h0 - 1 + rhh[r], ggw = w0 - 1 + rhw[r];
+        rf[r] = make_uint4(0u, 0u, 0u, 0u);              // outside the image: conv zero padding
+        if (actr[r] && (unsigned)ggh < (unsigned)H && (unsigned)ggw < (unsigned)W)
+          rf[r] = *reinterpret_cast<const uint4*>(d.feat + (((long long)vv * H + ggh) * W + ggw) * 32 + ck * 8);
+      }
+    };
+    auto tile_finish = [&](const TileRaw& R, TileP& P) {
+      const float x = (float)R.gw, y = (float)R.gh;
+      P.inb = act && (unsigned)R.gh < (unsigned)H && (unsigned)R.gw < (unsigned)W;
+      P.rx = R.hm[0] * x + R.hm[1] * y + R.hm[2];
+      P.ry = R.hm[3] * x + R.hm[4] * y + R.hm[5];
+      P.rz = R.hm[6] * x + R.hm[7] * y + R.hm[8];
+      P.t0 = R.hm[9]; P.t1 = R.hm[10]; P.t2 = R.hm[11];
+      P.dbits = R.dbits; P.srcb = R.srcb;
+    };
+    auto corners = [&](int z, const TileP& P, unsigned (&off)[4], unsigned (&wp)[4]) {
+      const float depth = __int_as_float(__builtin_amdgcn_readlane(P.dbits, z));
+      const float px = P.rx * depth + P.t0, py = P.ry * depth + P.t1, pz = P.rz * depth + P.t2;
+      const float rinv = __builtin_amdgcn_rcpf(pz);
+      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
+      const bool fin = isfinite(ix) && isfinite(iy);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+      const float ux = 1.f - tx, uy = 1.f - ty;
+      float w[4];
+      w[0] = (P.inb && xin0 && yin0) ? ux * uy : 0.f;
+      w[1] = (P.inb && xin1 && yin0) ? tx * uy : 0.f;
+      w[2] = (P.inb && xin0 && yin1) ? ux * ty : 0.f;
+      w[3] = (P.inb && xin1 && yin1) ? tx * ty : 0.f;
+      if (P.inb && !fin) w[0] = __builtin_nanf("");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
+        wp[q] = __builtin_bit_cast(unsigned, h);
+      }
+      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+      off[0] = (r0 + (unsigned)xc0) * 64u;
+      off[1] = (r0 + (unsigned)xc1) * 64u;
+      off[2] = (r1 + (unsigned)xc0) * 64u;
+      off[3] = (r1 + (unsigned)xc1) * 64u;
+    };
+    u32x4 g[4][4];                                       // [round][corner]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
+    unsigned wco[4][4];                                  // [round][corner]: weights of the gathers in flight
+#define SWP_GATHER(R, Q, OFF, BASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(g[R][Q]) : "v"(OFF), "s"(BASE) : "memory")
+#define SWP_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+#define SWP_REQ(R, OFFV, WPV, BASE)                                                                                   \
+    do {                                                                                                              \
+      unsigned o_[4];                                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                 \
+        o_[q] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(OFFV)[q], (R) * 0x55, 0xf, 0xf, false) | (unsigned)(ck * 16);      \
+        wco[R][q] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(WPV)[q], (R) * 0x55, 0xf, 0xf, false);             \
+      }                                                                                                               \
+      SWP_GATHER(R, 0, o_[0], BASE); SWP_GATHER(R, 1, o_[1], BASE); SWP_GATHER(R, 2, o_[2], BASE); SWP_GATHER(R, 3, o_[3], BASE);  \
+    } while (0)
+    auto blend4 = [&](const uint4& r, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& e, const unsigned (&w)[4]) {
+      const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb4[4] = {b[0], b[1], b[2], b[3]};
+      const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned t;
+        asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(t) : "v"(aa[q]), "v"(w[0]), "v"(rr[q]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(bb4[q]), "v"(w[1]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(cc[q]), "v"(w[2]));
+        asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(ee[q]), "v"(w[3]));
+        o[q] = t;
+      }
+      return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    // one plane: blend the four rounds of the plane whose gathers are in flight (reference features `ref`), write them into ring slot
+    // `slot`, and request (projection at depth index ZREQ with the parameters PREQ) the plane that follows it in the stream
+#define SWP_PLANE(PREQ, ZREQ)                                                                                         \
+    do {                                                                                                              \
+      corners((ZREQ), (PREQ), noff, nwp);                                                                             \
+      unsigned char* dst = planes + slot * SW_SLOT;                                                                   \
+      SWP_ROUND(0, (PREQ).srcb); SWP_ROUND(1, (PREQ).srcb); SWP_ROUND(2, (PREQ).srcb); SWP_ROUND(3, (PREQ).srcb);     \
+      slot = (slot + 1) & (SWP_NSLOT - 1);                                                                            \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the plane is visible before the consumers are released */ \
+      __builtin_amdgcn_s_barrier();                                                                                   \
+      asm volatile("" ::: "memory");                                                                                  \
+    } while (0)
+#define SWP_ROUND(R, BASE)                                                                                            \
+    do {                                                                                                              \
+      SWP_WAIT12(R);                                                                                                  \
+      const uint4 o4 = blend4(ref[R], g[R][0], g[R][1], g[R][2], g[R][3], wco[R]);                                    \
+      if (actr[R]) *reinterpret_cast<uint4*>(dst + dsto[R]) = o4;                                                     \
+      SWP_REQ(R, noff, nwp, BASE);                                                                                    \
+    } while (0)
+    TileRaw raw;
+    TileP cur, nxt;
+    uint4 ref[4], nref[4];
+    unsigned noff[4], nwp[4];
+    int slot = 0;
+    int t1 = nt > 1 ? tile_index(1) : 0;                 // the next tile's index, fetched a tile ahead
+    tile_request(tile_index(0), raw, ref);
+    tile_finish(raw, cur);
+    corners(0, cur, noff, nwp);
+    SWP_REQ(0, noff, nwp, cur.srcb); SWP_REQ(1, noff, nwp, cur.srcb); SWP_REQ(2, noff, nwp, cur.srcb); SWP_REQ(3, noff, nwp, cur.srcb);
+    for (int ti = 0; ti < nt; ++ti) {
+      const bool has_next = ti + 1 < nt;
+      // the next tile's loads travel while this tile's planes are produced; their first use is behind the plane loop
+      if (has_next) tile_request(t1, raw, nref);
+      const int t2 = ti + 2 < nt ? tile_index(ti + 2) : 0;
+      for (int z = 0; z + 1 < D; ++z) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ref[k].x), "+v"(ref[k].y), "+v"(ref[k].z), "+v"(ref[k].w));
+        SWP_PLANE(cur, z + 1);
+      }
+      // last plane of the tile: what is requested behind it is plane 0 of the next tile (none left: a harmless re-request of this
+      // plane keeps the counted waits valid)
+      if (has_next) tile_finish(raw, nxt); else nxt = cur;
+      SWP_PLANE(nxt, has_next ? 0 : D - 1);
+      if (has_next) {
+        cur = nxt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ref[r] = nref[r];
+      }
+      t1 = t2;
+    }
+    for (int k = 0; k < SWP_LAG; ++k) {                  // the consumers run SWP_LAG planes behind
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#undef SWP_GATHER
+#undef SWP_WAIT12
+#undef SWP_REQ
+#undef SWP_PLANE
+#undef SWP_ROUND
+  } else {
+    // ------------------------------------------------------------------ consumers (the compiler-scheduled plane body of conv0_sweep_kernel)
+    const int cw = wave - SW_NPW;
+    const int lr = lane & 15, lg = lane >> 4;
+    uint4 A01[9], A2[9];
+    {
+      const uint4* wq = reinterpret_cast<const uint4*>(d.wgt);
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        A01[s] = wq[(s * 16 + lr) * 4 + lg];
+        A2[s] = wq[((9 + s) * 16 + lr) * 4 + lg];
+      }
+    }
+    const int ch = (lg & 1) * 4;
+    f32x4 binit;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) binit[r] = lg >= 2 ? d.bias[(lg & 1) * 4 + r] : 0.f;
+    const int boff = ((cw * SW_CR_) * SW_HW + lr) * SW_VS + lg * 16;     // fragment 0, tap (0,0)
+    constexpr int NF = 3 * (SW_CR_ + 2);                   // operand fragments of a plane: b[r][c] = fragment 3 r + c
+    sw_u4v pre[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) pre[k] = sw_u4v{0u, 0u, 0u, 0u};
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
+    auto prefetch = [&](int sl) {      // the plane in ring slot sl is complete (its barrier lies behind) and stays untouched for two more iterations
+      const unsigned sa = lds_base + (unsigned)(sl * SW_SLOT + boff);
+#pragma unroll
+      for (int k = 0; k < NF; ++k)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[k]) : "v"(sa), "n"(((k / 3) * SW_HW + k % 3) * SW_VS) : "memory");
+    };
+#define SWP_TIE_PRE(STR) asm volatile(STR : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]), "+v"(pre[7]), \
+                                       "+v"(pre[8]), "+v"(pre[9]), "+v"(pre[10]), "+v"(pre[11]), "+v"(pre[12]), "+v"(pre[13]), "+v"(pre[14]) :: "memory")
+    static_assert(NF == 15 || !SWP_PRE, "SWP_TIE_PRE names 15 fragments");
+    __builtin_amdgcn_s_barrier();      // plane 0 of the first tile is complete
+    asm volatile("" ::: "memory");
+    if (SWP_PRE) {
+      prefetch(0);
+      SWP_TIE_PRE("s_waitcnt lgkmcnt(0)");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    int slot = 0, rslot = 1, left = nt * D;                // ring slot of the plane to multiply / to read next; planes left in the stream
+    int t1 = nt > 1 ? tile_index(1) : 0;
+    int tcur = tile_index(0);
+    for (int ti = 0; ti < nt; ++ti) {
+      const int t2 = ti + 2 < nt ? tile_index(ti + 2) : 0;
+      int t = tcur;
+      const int tw = t % d.ntw; t /= d.ntw;
+      const int th = t % d.nth; t /= d.nth;
+      const int n = t, h0 = th * SW_TH, w0 = tw * SW_TW;
+      const int ow = w0 + lr;
+      int oh[SW_NPAIR];
+      bool ook[SW_NPAIR];
+#pragma unroll
+      for (int pr = 0; pr < SW_NPAIR; ++pr) {
+        const bool self = 2 * pr + 1 >= SW_CR_;
+        oh[pr] = h0 + cw * SW_CR_ + pr * 2 + (self ? 0 : (lg >> 1));
+        ook[pr] = oh[pr] < H && ow < W && !(self && lg >= 2);
+      }
+      f32x4 Xp[SW_CR_], Lp[SW_NPAIR];
+#pragma unroll
+      for (int f = 0; f < SW_CR_; ++f) Xp[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < SW_NPAIR; ++pr) Lp[pr] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto emit = [&](int o) {         // out plane o from Xp (= X[o]) and Lp (= rows 0-7 of X[o-1]); leaves Lp = rows 0-7 of X[o]
+#pragma unroll
+        for (int pr = 0; pr < SW_NPAIR; ++pr) {
+          f32x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f1 = 2 * pr + 1 < SW_CR_ ? 2 * pr + 1 : 2 * pr;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[2 * pr][r]), __float_as_uint(Xp[f1][r]), false, false);
+            lo[r] = __uint_as_float(sw[0]);
+            hi[r] = __uint_as_float(sw[1]);
+          }
+          if (o >= 0 && ook[pr]) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = hi[r] + Lp[pr][r];
+              v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
+            }
+            store4(reinterpret_cast<TO*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
+          }
+          Lp[pr] = lo;
+        }
+      };
+      for (int p = 0; p < D; ++p) {
+        const unsigned char* sl = planes + slot * SW_SLOT + boff;
+        slot = (slot + 1) & (SWP_NSLOT - 1);
+        f32x4 Xn[SW_CR_];
+#pragma unroll
+        for (int f = 0; f < SW_CR_; ++f) Xn[f] = binit;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+          for (int f = 0; f < SW_CR_; ++f) {
+            uint4 b;
+            if constexpr (SWP_PRE != 0) b = __builtin_bit_cast(uint4, pre[(f + tp / 3) * 3 + tp % 3]);
+            else b = *reinterpret_cast<const uint4*>(sl + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
+            Xn[f] = Sw16<T>::mma(A01[tp], b, Xn[f]);
+            Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
+          }
+        }
+        --left;
+        if (SWP_PRE != 0 && left > 0) {
+          // every MFMA of this plane has read its operands (the nops cover the last one's passes: a ds_read result landing in a register an
+          // MFMA still reads is the hazard tools/micro/mfma_lds_war.hip demonstrates) - the next plane's operands travel during the epilogue
+          asm volatile("s_nop 15\n\ts_nop 3" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[SW_CR_ - 1]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[SW_CR_ - 1]) :: "memory");
+          prefetch(rslot);
+        }
+        rslot = (rslot + 1) & (SWP_NSLOT - 1);
+        emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
+#pragma unroll
+        for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
+        if (SWP_PRE != 0) SWP_TIE_PRE("s_waitcnt lgkmcnt(0)");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (both directions: see conv0_sweep_kernel)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      emit(D - 1);                     // plane D is zero padding: X[D-1] is already complete
+      tcur = t1; t1 = t2;
+    }
+  }
+}
+
 // Pack conv0 weights [8][32][27] (x folded BN scale) into the consumer's A-fragment order [18][16 rows][4 k-groups][8]:
 // steps 0..8 = A01 of in-plane tap t (rows 0-7 kd=0, rows 8-15 kd=1), steps 9..17 = A2 (rows 8-15 kd=2, rows 0-7 zero).
 void conv0_sweep_pack(const float* w, const float* scale, std::vector<float>& packed) {
@@ -928,7 +1268,17 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   // without packed fp32 instructions the three bf16 modes are level - 44.11 / 44.15 / 44.09 ms per forward - and the dot2 form rounds the
   // bilinear weights to 8 bits); debug flag 4194304 = v_perm + v_dot2_f32_bf16 (the round-4 default), 2097152 = fp32 FMAs from inline asm.
   const bool f21 = (g_debug_flags & (1 << 21)) != 0, f22 = (g_debug_flags & (1 << 22)) != 0;
-  if (dtype == BF16 && t.feat_f16) SW_LAUNCH(f16_t, u16, 3);
+  if (dtype == BF16 && t.feat_f16 && !(g_debug_flags & (1 << 28))) {
+    // the persistent form (debug flag 268435456 = one workgroup per tile, for A/B)
+    auto kern = conv0_sweep_persistent_kernel<u16>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), SWP_LDS)) return rc;
+    int n_cu = 0;
+    if (int rc = persistent_grid_cus(&n_cu)) return rc;
+    const int grid = nblk < n_cu ? (int)((nblk + 7) / 8 * 8) : n_cu;      // a multiple of 8: XCD = block % 8 for every tile of a workgroup
+    prof_begin_launch(s, t.prof_variant >= 0 ? 14 : -1, t.algo_flops, t.algo_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SW_THREADS), SWP_LDS, s, d);
+  }
+  else if (dtype == BF16 && t.feat_f16) SW_LAUNCH(f16_t, u16, 3);
   else if (dtype == BF16 && f22) SW_LAUNCH(u16, u16, 2);
   else if (dtype == BF16 && f21) SW_LAUNCH(u16, u16, 1);
   else if (dtype == BF16) SW_LAUNCH(u16, u16, 0);

@@ -79,8 +79,33 @@ def check(asm_text):
         stray = [t for t in pro if t not in set(inside)]
         if stray:
             findings.append(f"{name[:50]}: prologue gathers into tuples the loop does not use: {stray}")
+        # (round 5) the persistent sweep kernel keeps the gathers rolling ACROSS tiles: the last plane of a tile is peeled out of the plane loop
+        # (its requests are the next tile's), so the rolling tuples are also written in the tile loop around it.  Anywhere behind the first
+        # request into a rolling tuple, up to the end of the kernel, no move / AGPR copy / scratch access may name one of its registers.
+        first = {}
+        in_asm = False
+        for i, l in enumerate(body):
+            if 'ASMSTART' in l:
+                in_asm = True
+            elif 'ASMEND' in l:
+                in_asm = False
+            if in_asm and is_gather(l):      # inline-asm requests only (the compiler's own loads reuse the register names)
+                t = l.split()[1].rstrip(',')
+                if t in set(inside):
+                    first.setdefault(t, i)
+        outside = 0
+        for i, l in enumerate(body):
+            ls = l.strip()
+            if not (x <= i <= y) and ls.startswith(('v_mov', 'v_accvgpr', 'scratch_', 'v_swap')):
+                touched = set()
+                for o in ls.split()[1:]:
+                    touched |= regs(o)
+                for t, fi in first.items():
+                    if i > fi and touched & regs(t):
+                        findings.append(f"{name[:50]}: line {i} (outside the plane loop, behind the first request into {t}): {ls}")
+                        outside += 1
         print(f"{name[:60]}: plane loop lines {x}..{y}, {len(inside)} gathers in the loop into {len(set(inside))} tuples, "
-              f"{len(pro)} prologue gathers, {len(dest)} registers checked")
+              f"{len(pro)} prologue gathers, {len(dest)} registers checked, {len(first)} tuples followed to the end of the kernel")
     return findings
 
 

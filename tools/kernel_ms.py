@@ -14,6 +14,8 @@ from rgbmanip_amd.adapose import AdaPoseNet
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 pats = sys.argv[2:] or [""]
 lib = _lib.load()
+if os.environ.get("RGBM_DEBUG_FLAGS"):
+    _lib.check(lib.rgbm_debug_flags(int(os.environ["RGBM_DEBUG_FLAGS"])))      # A/B of a debug-flag switch on one library
 B = 256
 inp = synth.adapose_inputs(16, seed=0)
 inp = {k: torch.from_numpy(np.concatenate([v] * (B // 16), 0)).cuda() for k, v in inp.items()}
