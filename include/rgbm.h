@@ -80,6 +80,10 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
  * "view2_heads" (1 [default] = all ten outputs; 0 = the probability volume, the point heads and the pose regression run for the
  * view-1 crops only and the five view-2 outputs are filled with NaN: what AdaPoseEstimator_v5.estimate consumes,
  * interface_v5.py:318-374, at about three quarters of the time; the backbone still runs on both views).
+ * "sweep_f16" (bf16 nets with cost_impl 3 and upconv bit 2; 1 [default since round 5] = `final` writes the 32-channel feature map as f16
+ * instead of bf16 - same bytes, three more mantissa bits - and the plane sweep (persistent conv0_sweep kernel) blends it with packed f16
+ * FMAs and multiplies with f16 MFMAs; c0 and everything behind it stay bf16.  Features beyond +-65504 saturate, as in an fp16 net; 0 =
+ * bf16 feature map and the fp32 blend of rounds 1-4.  The "feat" tap of rgbm_adapose_fetch converts from whichever form was written).
  * Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
@@ -358,7 +362,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  0..7   conv_igemm_glds_kernel<dtype, BCH> (row = dtype*4 + {0:16,1:32,2:64,3:128}-channel tile; dtype 0 f32, 1 16-bit)
  *  8 / 9  conv3d_tile_kernel f32 / (unused)          10 / 11  conv3d_tile_kernel conv0 + fused plane sweep f32 / 16-bit
  *  12 / 13 conv_igemm_ws_kernel 128 x 256 tile (and conv_igemm_v3_kernel) f32 / 16-bit
- *  14     conv0_sweep_kernel (16-bit)                15  conv_igemm_ws64_kernel (16-bit)
+ *  14     conv0_sweep[_persistent]_kernel (16-bit)            15  conv_igemm_ws64_kernel (16-bit)
  *  16..25 conv3d_tile_kernel 16-bit per layer (conv0..conv6, conv7, conv9, conv11)
  *  26..29 bf16x3: generic implicit GEMM, 3-D layers, conv0 + plane sweep, ws 128 x 256 tile
  *  30     conv_igemm_w256_kernel (experimental)      31 / 32  ws 256 x 128 tile 16-bit / its row-halo variant
@@ -376,12 +380,14 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
  *                                                                                  (default since round 3: channel block outer, taps inner)
- * 2097152  bf16 plane sweep: blend on fp32 FMAs from inline asm           4194304  ... on v_perm + v_dot2_f32_bf16 (8-bit bilinear weights; the
- *                                                                                  round-4 default; default since round 5: plain fp32 blend)
+ * 2097152  plane sweep of a bf16 feature map (option sweep_f16 = 0): blend on fp32 FMAs from inline asm; fp16 nets: the packed-f16 blend
+ *          instead of their fp32-accumulating one                        4194304  bf16 feature map: v_perm + v_dot2_f32_bf16 (8-bit bilinear
+ *                                                                                  weights; the round-4 default; since round 5: plain fp32 blend)
  * 8388608  one-workgroup-per-pose post-processing even with scratch      16777216  no 64 x 256 tile for small persistent launches
  * 33554432 post-processing: generic fp64 radix selection of the median only (the fall-back of the default selection on fp32
  *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose
- * 134217728 implicit-GEMM request waves: 64-bit global addresses + zero page instead of buffer descriptors (the form before round 5) */
+ * 134217728 implicit-GEMM request waves: 64-bit global addresses + zero page instead of buffer descriptors (the form before round 5)
+ * 268435456 plane sweep of an f16 feature map (bf16 nets, sweep_f16 = 1): one workgroup per tile instead of the persistent kernel */
 int rgbm_debug_flags(int flags);
 /* Kernel choice - tile shape, and with it the order of the fp32 sums - depends on a launch's GEMM rows, i.e. on the batch size: the
  * same pose in batches of different sizes agrees to the storage type's rounding (1e-6 .. 1e-5 relative in fp32 / bf16x3), not bit for

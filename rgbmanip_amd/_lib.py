@@ -28,7 +28,7 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<float, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "fp32"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 4, 8, 8, 1, false, true> (conv0 + fused plane sweep)", "bf16"),
     ("conv_igemm_ws_kernel<float, ...>", "fp32"), ("conv_igemm_ws_kernel<unsigned short, false, false> (128 channels x 256 pixels)", "bf16"),    # + conv_igemm_v3_kernel for non-uniform taps
-    ("conv0_sweep_kernel (conv0 + fused plane sweep)", "bf16"), ("conv_igemm_ws64_kernel", "bf16"),
+    ("conv0_sweep_persistent_kernel<unsigned short> (conv0 + fused plane sweep of bf16 nets; sweep_f16 = 0 / fp16 nets: conv0_sweep_kernel)", "bf16"), ("conv_igemm_ws64_kernel", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 32, 16, 6, 8, 8, 1, false, false> (conv0 on a materialised volume)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 8, 16, 2, 8, 8, 2, false, false> (conv1)", "bf16"),
     ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, false, false> (conv2)", "bf16"),

@@ -40,23 +40,10 @@ namespace {
 constexpr int SW_TH = 12, SW_TW = 16;
 constexpr int SW_HH = SW_TH + 2, SW_HW = SW_TW + 2;
 constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
-#ifndef SW_HAND
-#define SW_HAND 0     // consumer plane loop: 0 = the compiler-scheduled C++ loop (default: 18.1 ms per batch-256 step in bf16), 1 = hand-
-                      // scheduled like conv0_sweep_x3.hip (in-place asm MFMAs, operand reads rotating through four pinned register sets,
-                      // counted lgkmcnt: 20.0 ms).  Round-2 A/B on the f16 build, 5 runs at batch 256 (tools/f16_sweep_check.py): both
-                      // schedules are bit-stable with the three-slot plane ring and neither is with two slots (compiler schedule: ~100 of
-                      // 512 views differ, always one consumer wave's rows of output planes 2-4; hand schedule: every view differs) — with
-                      // one workgroup per CU forced and with all waves retiring together as well, while the ring + barrier protocol in
-                      // isolation (tools/micro/ring_barrier.hip: two slots, 5.4e9 checked reads per variant) never fails.
-#endif
 #ifndef SW_COOP
 #define SW_COOP 1     // packed-f16 instantiations: cooperative gathers - four lanes read the four 16-byte chunks of ONE corner pixel (a gather instruction
                       // touches 16 pixels' 64-byte runs instead of 64 lanes' 16-byte pieces of 64 pixels).  Same box, dense, ms per step:
                       // lane per voxel 14.05, quads with a DPP exchange 13.2 (and 15.4 with 16 consecutive voxels per round + ds_bpermute_b32)
-#endif
-#ifndef SW_RELU_PK
-#define SW_RELU_PK 0  // bf16 c0: ReLU after the conversion, on the packed pair, as max(int16, 0): half the epilogue's instructions and no gain (14.45 -> 14.3 ms), and it
-                      // zeroes the NaN voxels of a singular pose (their sign bit is set when they leave the MFMAs: the NaN-isolation test fails) - off
 #endif
 #ifndef SW_PRE
 #define SW_PRE 0      // > 0 (3, 6, 9): the consumers run TWO planes behind the producers (four ring slots) and read the first SW_PRE operand fragments
@@ -111,14 +98,8 @@ constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
 // barrier interval before its slot is reused (tools/f16_sweep_check.py 256).  60 KB per workgroup; occupancy is set by
 // the VGPRs, not by LDS.
 constexpr int SW_NSLOT = SW_NSLOT_N;
-#ifndef SW_LDS_PAD
-#define SW_LDS_PAD 0       // experiment builds: extra dynamic LDS per workgroup (forces one workgroup per CU)
-#endif
-#ifndef SW_EXIT_BARRIER
-#define SW_EXIT_BARRIER 0  // experiment builds: one more barrier after the last plane, so that all waves of a workgroup retire together
-#endif
-constexpr int SW_LDS = SW_NSLOT * SW_SLOT + SW_LDS_PAD;
-static_assert(SW_TH % SW_CR_ == 0 && !(SW_HAND && SW_CR_ != 4) && !(SW_HAND && SW_PRE), "a consumer wave owns SW_CR rows");
+constexpr int SW_LDS = SW_NSLOT * SW_SLOT;
+static_assert(SW_TH % SW_CR_ == 0, "a consumer wave owns SW_CR rows");
 static_assert((SW_PRE == 0 || SW_PRE == 3 || SW_PRE == 6 || SW_PRE == 9) && SW_PRE <= 3 * SW_CR_ && SW_NSLOT_N > SW_LAG, "the prefetched fragments are those of the first in-plane tap row; the ring holds the plane being written and the SW_LAG behind it");
 constexpr int SW_NPAIR = (SW_CR_ + 1) / 2;       // fragment pairs of the output epilogue; with an odd SW_CR the last fragment pairs with itself
 
@@ -145,10 +126,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;     // native vector
 
 template <typename T> struct Sw16;                                   // the two 16-bit storage types of this kernel
 typedef __attribute__((ext_vector_type(4))) unsigned sw_u4v;       // native vector: usable as a tied inline-asm operand
-#define SW_MFMA_BF16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
-#define SW_MFMA_F16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 template <> struct Sw16<unsigned short> {                            // bf16: a dword's halves are the high halves of two floats
-  __device__ static __forceinline__ void mma_inplace(f32x4& c, const sw_u4v& a, const sw_u4v& b) { SW_MFMA_BF16(c, a, b); }
   __device__ static __forceinline__ f32x2 unpack(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
   __device__ static __forceinline__ unsigned pack(f32x2 v) { return pack2_bf16(v.x, v.y); }
   __device__ static __forceinline__ f32x4 mma(const uint4& a, const uint4& b, const f32x4& c) {
@@ -157,7 +135,6 @@ template <> struct Sw16<unsigned short> {                            // bf16: a 
 };
 template <> struct Sw16<f16_t> {
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-  __device__ static __forceinline__ void mma_inplace(f32x4& c, const sw_u4v& a, const sw_u4v& b) { SW_MFMA_F16(c, a, b); }
   __device__ static __forceinline__ f32x2 unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(h2, u), f32x2); }
   __device__ static __forceinline__ unsigned pack(f32x2 v) {
     const h2 h = {(f16_t)sat_f16(v.x), (f16_t)sat_f16(v.y)};
@@ -583,10 +560,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
 #define SW_GATHER(K, Q, OFF) do { (void)(OFF); } while (0)
 #endif
 #define SW_GATHER4(K, C) do { SW_GATHER(K, 0, (C).off[0]); SW_GATHER(K, 1, (C).off[1]); SW_GATHER(K, 2, (C).off[2]); SW_GATHER(K, 3, (C).off[3]); } while (0)
-#ifndef SW_WAITSTR
-#define SW_WAITSTR "s_waitcnt vmcnt(12)"
-#endif
-#define SW_WAIT12(K) asm volatile(SW_WAITSTR : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
+#define SW_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     if (act) {
       corners(0, cur);
       SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
@@ -646,9 +620,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
 #endif
     }
-#if SW_EXIT_BARRIER
-    __builtin_amdgcn_s_barrier();
-#endif
 #undef SW_GATHER
 #undef SW_GATHER4
 #undef SW_WAIT12
@@ -656,39 +627,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
     // ------------------------------------------------------------------ consumers
     const int cw = wave - SW_NPW;
     const int lr = lane & 15, lg = lane >> 4;
-#if SW_HAND
-    sw_u4v A01[9], A2[9];
-    {
-      const uint4* wq = reinterpret_cast<const uint4*>(d.wgt);
-#pragma unroll
-      for (int s = 0; s < 9; ++s) {
-        const uint4 t0 = wq[(s * 16 + lr) * 4 + lg], t1 = wq[((9 + s) * 16 + lr) * 4 + lg];
-        A01[s] = sw_u4v{t0.x, t0.y, t0.z, t0.w};
-        A2[s] = sw_u4v{t1.x, t1.y, t1.z, t1.w};
-      }
-    }
-    // Operand registers of the plane loop: four fixed sets of two fragments, reloaded by hand (see conv0_sweep_x3.hip for the
-    // run-to-run corruption a compiler-scheduled loop of this shape showed there; this kernel's own hazard (3) in DESIGN.md
-    // has the same signature).  A set is reloaded only after two further half-tap steps (8 MFMAs) have been issued behind its
-    // last reader; accumulators are updated in place and never serve as load destinations.  (Three sets of four fragments,
-    // as in the split-pair kernel, do not fit the 168-register budget of three waves per SIMD.)
-    sw_u4v Bq[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Bq[i][0] = Bq[i][1] = sw_u4v{0u, 0u, 0u, 0u};
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
-#define SW_BOFF(TP, F) ((((F) + (TP) / 3) * SW_HW + (TP) % 3) * SW_VS)
-    // step I = in-plane tap I / 2, fragments 2 * (I % 2) and 2 * (I % 2) + 1, register set I % 4
-#define SW_LDB(I)                                                                                                    \
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "+v"(Bq[(I) % 4][0]), "+v"(Bq[(I) % 4][1])    \
-                 : "v"(sa), "n"(SW_BOFF((I) / 2, 2 * ((I) % 2))), "n"(SW_BOFF((I) / 2, 2 * ((I) % 2) + 1)) : "memory");
-#define SW_MMA4(I)                                                                                                   \
-    Sw16<T>::mma_inplace(Xn[2 * ((I) % 2)], A01[(I) / 2], Bq[(I) % 4][0]); Sw16<T>::mma_inplace(Xp[2 * ((I) % 2)], A2[(I) / 2], Bq[(I) % 4][0]);          \
-    Sw16<T>::mma_inplace(Xn[2 * ((I) % 2) + 1], A01[(I) / 2], Bq[(I) % 4][1]); Sw16<T>::mma_inplace(Xp[2 * ((I) % 2) + 1], A2[(I) / 2], Bq[(I) % 4][1]);
-#define SW_STEP(I, NEXT, WAITN)                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" ::: "memory");                                                      \
-    SW_MMA4(I)                                                                                                       \
-    NEXT
-#else
     uint4 A01[9], A2[9];
     {
       const uint4* wq = reinterpret_cast<const uint4*>(d.wgt);
@@ -698,7 +636,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         A2[s] = wq[((9 + s) * 16 + lr) * 4 + lg];
       }
     }
-#endif
     // after the lane-half swap a lane holds: fragment (lg < 2 ? first : second of the pair), voxel lr, channels (lg&1)*4..+3
     const int ch = (lg & 1) * 4;
     // the folded BatchNorm shift is the initial value of the accumulator rows that become outputs (rows 8-15 = lanes 32-63 before the lane-half
@@ -737,24 +674,12 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         if (o >= 0 && ook[pr]) {
           float v[4];
           TO* const dst = reinterpret_cast<TO*>(d.out) + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch;
-          if constexpr (std::is_same<TO, unsigned short>::value && SW_RELU_PK) {
-            // bf16 c0: round first, then ReLU on the packed pair as max(int16, 0) - negative values (and -0) have the sign bit, the NaN this
-            // kernel can hold (the producers' marker for a non-finite projection, propagated by FMAs and MFMAs) does not: 8 + 4 + 4
-            // instructions per 8 values where add / compare / wait states / select / convert took 36
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = hi[r] + Lp[pr][r];
-            unsigned p0 = pack2_bf16(v[0], v[1]), p1 = pack2_bf16(v[2], v[3]);
-            asm("v_pk_max_i16 %0, %1, 0" : "=v"(p0) : "v"(p0));
-            asm("v_pk_max_i16 %0, %1, 0" : "=v"(p1) : "v"(p1));
-            if (!(SW_ABL & 16) || p0 == 12345u) *reinterpret_cast<uint2*>(dst) = make_uint2(p0, p1);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = hi[r] + Lp[pr][r];
-              v[r] = v[r] < 0.f ? 0.f : v[r];                        // conv0 always has its ReLU (the launcher checks); NaN propagates, like torch.relu
-            }
-            if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(dst, v);
+          for (int r = 0; r < 4; ++r) {
+            v[r] = hi[r] + Lp[pr][r];
+            v[r] = v[r] < 0.f ? 0.f : v[r];                        // conv0 always has its ReLU (the launcher checks); NaN propagates, like torch.relu
           }
+          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(dst, v);
         }
         Lp[pr] = lo;
       }
@@ -794,21 +719,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         f32x4 Xn[SW_CR_];
 #pragma unroll
         for (int f = 0; f < SW_CR_; ++f) Xn[f] = binit;
-#if SW_HAND
-        // 18 half-tap steps of 2 fragment reads + 4 MFMAs; the reads of step i + 2 are issued behind the MFMAs of step i into the
-        // set step i - 2 multiplied from; at step i the reads of steps i and i + 1 are outstanding and LDS operations complete
-        // in order, so step i's have landed once at most 2 remain
-        (void)slot;
-        const unsigned sa = lds_base + (unsigned)((p % SW_NSLOT) * SW_SLOT + boff);
-        SW_LDB(0) SW_LDB(1)
-        SW_STEP(0, SW_LDB(2), 2) SW_STEP(1, SW_LDB(3), 2) SW_STEP(2, SW_LDB(4), 2) SW_STEP(3, SW_LDB(5), 2) SW_STEP(4, SW_LDB(6), 2)
-        SW_STEP(5, SW_LDB(7), 2) SW_STEP(6, SW_LDB(8), 2) SW_STEP(7, SW_LDB(9), 2) SW_STEP(8, SW_LDB(10), 2) SW_STEP(9, SW_LDB(11), 2)
-        SW_STEP(10, SW_LDB(12), 2) SW_STEP(11, SW_LDB(13), 2) SW_STEP(12, SW_LDB(14), 2) SW_STEP(13, SW_LDB(15), 2) SW_STEP(14, SW_LDB(16), 2)
-        SW_STEP(15, SW_LDB(17), 2) SW_STEP(16, , 2) SW_STEP(17, , 0)
-        // asm MFMAs are opaque to the compiler's hazard recogniser: wait states before any VALU read of their results, tied to
-        // the accumulators so that no such read can be scheduled in front of them
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Xn[3]) :: "memory");
-#else
         uint4 b[SW_CR_ + 2][3];
 #pragma unroll
         for (int r = 0; r < SW_CR_ + 2; ++r)
@@ -829,7 +739,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
             Xp[f] = Sw16<T>::mma(A2[tp], b[f + tp / 3][tp % 3], Xp[f]);
           }
         }
-#endif
 #if SW_ABL & 256
         asm volatile("s_nop 0" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]));      // all MFMAs issued
 #endif
@@ -876,9 +785,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
              tm[0] / tm[4], tm[1] / tm[4], tm[2] / tm[4], tm[3] / tm[4], t_loop - t_entry, tq[4] - t_loop, D + SW_LAG, t_exit - t_entry);
 #else
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
-#endif
-#if SW_EXIT_BARRIER
-    __builtin_amdgcn_s_barrier();
 #endif
   }
 }
