@@ -252,6 +252,46 @@ __device__ __forceinline__ uint4 blend_chunk_f16(const uint4& r, const u32x4& a,
 }
 #undef SW_MIX
 
+// Projection of a voxel's pixel onto the partner view and its bilinear corners - ONE definition with explicit FMAs for every form of the
+// producers (lane per voxel, cooperative, persistent), so that they agree bit for bit (left to -ffp-contract, hipcc fused `a * x + b * y + c`
+// differently in two of them: c0 of the persistent kernel differed from the one-tile kernel's in 1 % of its elements by one bf16 step).
+// ray = rot * (x, y, 1); per plane p = ray * depth + t, one reciprocal, and the reference's align_corners=True normalisation + grid_sample's
+// align_corners=False un-normalisation folded into ix = u * W / (W - 1) - 0.5 (sx, sy).  Algebraically network_v5.py:378-430; rounding
+// differs from the fp32 kernels in the last ulps of the coordinate (1e-5 pixel), far below one 16-bit step of the blended value.
+__device__ __forceinline__ void sw_ray(const float (&hm)[12], float x, float y, float& rx, float& ry, float& rz) {
+  rx = __builtin_fmaf(hm[0], x, __builtin_fmaf(hm[1], y, hm[2]));
+  ry = __builtin_fmaf(hm[3], x, __builtin_fmaf(hm[4], y, hm[5]));
+  rz = __builtin_fmaf(hm[6], x, __builtin_fmaf(hm[7], y, hm[8]));
+}
+// w: 0 for a corner outside the image (grid_sample padding_mode="zeros": its clamped address is read, times 0) and for a voxel outside the
+// image (conv zero padding, inb false); NaN in w[0] for a non-finite projection (the voxel becomes NaN like the reference's).  off: byte
+// offsets of the four clamped corner pixels inside the partner feature map (64 bytes per pixel).
+__device__ __forceinline__ void sw_corner_weights(float rx, float ry, float rz, float t0, float t1, float t2, float depth, float sx, float sy,
+                                                  int W, int H, bool inb, float (&w)[4], unsigned (&off)[4]) {
+  const float px = __builtin_fmaf(rx, depth, t0), py = __builtin_fmaf(ry, depth, t1), pz = __builtin_fmaf(rz, depth, t2);
+  const float rinv = __builtin_amdgcn_rcpf(pz);
+  const float ix = __builtin_fmaf(px * rinv, sx, -0.5f), iy = __builtin_fmaf(py * rinv, sy, -0.5f);
+  const bool fin = isfinite(ix) && isfinite(iy);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
+  const float tx = ix - fx, ty = iy - fy;
+  const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+  const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+  const float ux = 1.f - tx, uy = 1.f - ty;
+  w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
+  w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
+  w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
+  w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
+  if (inb && !fin) w[0] = __builtin_nanf("");
+  const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+  off[0] = (r0 + (unsigned)xc0) * 64u;
+  off[1] = (r0 + (unsigned)xc1) * 64u;
+  off[2] = (r1 + (unsigned)xc0) * 64u;
+  off[3] = (r1 + (unsigned)xc1) * 64u;
+}
+
 }  // namespace
 
 // min 3 waves per SIMD (<= 168 VGPRs): the hardware then starts the next workgroup's producers while this one's consumers
@@ -325,45 +365,23 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       if (actr[r] && (unsigned)ggh < (unsigned)H && (unsigned)ggw < (unsigned)W)
         ref[r] = *reinterpret_cast<const uint4*>(d.feat + (((long long)vv * H + ggh) * W + ggw) * 32 + ck * 8);
     }
-    const float x = (float)gw, y = (float)gh;
-    const float rx = hm[0] * x + hm[1] * y + hm[2];
-    const float ry = hm[3] * x + hm[4] * y + hm[5];
-    const float rz = hm[6] * x + hm[7] * y + hm[8];
-    const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
+    float hmv[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) hmv[e] = hm[e];
+    float rx, ry, rz;
+    sw_ray(hmv, (float)gw, (float)gh, rx, ry, rz);
+    const float t0 = hmv[9], t1 = hmv[10], t2 = hmv[11];
     const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
     const int dbits = __float_as_int(lane < D ? dep[lane] : 1.f);
-    // per voxel: four byte offsets of the (clamped) corner pixels and the four weights as f16 pairs (0 outside the image, NaN for a
-    // non-finite projection) - the same arithmetic as the lane-per-voxel form below
+    // per voxel: four byte offsets of the (clamped) corner pixels and the four weights as f16 pairs (sw_corner_weights)
     auto corners = [&](int z, unsigned (&off)[4], unsigned (&wp)[4]) {
-      const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
-      const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
-      const float rinv = __builtin_amdgcn_rcpf(pz);
-      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
-      const bool fin = isfinite(ix) && isfinite(iy);
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fx, y0 = (int)fy;
-      const float tx = ix - fx, ty = iy - fy;
-      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
-      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
-      const float ux = 1.f - tx, uy = 1.f - ty;
       float w[4];
-      w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
-      w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
-      w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
-      w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
-      if (inb && !fin) w[0] = __builtin_nanf("");
+      sw_corner_weights(rx, ry, rz, t0, t1, t2, __int_as_float(__builtin_amdgcn_readlane(dbits, z)), sx, sy, W, H, inb, w, off);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
         wp[q] = __builtin_bit_cast(unsigned, h);
       }
-      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
-      off[0] = (r0 + (unsigned)xc0) * 64u;
-      off[1] = (r0 + (unsigned)xc1) * 64u;
-      off[2] = (r1 + (unsigned)xc0) * 64u;
-      off[3] = (r1 + (unsigned)xc1) * 64u;
     };
     u32x4 g[4][4];                                       // [round][corner]
 #pragma unroll
@@ -467,41 +485,20 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       for (int k = 0; k < 4; ++k) ref[k] = *reinterpret_cast<const uint4*>(pr + k * 8);
     }
 
-    // Projection of this pixel: (rx,ry,rz) = rot * (x,y,1) once; per plane p = r*depth + t, one reciprocal, and the
-    // reference's align_corners=True normalisation + grid_sample's align_corners=False un-normalisation folded into
-    // ix = u*W/(W-1) - 0.5.  Algebraically network_v5.py:378-430; rounding differs from the fp32 kernels in the last
-    // ulps of the coordinate (1e-5 pixel), far below one bf16 step of the blended value.
-    const float x = (float)gw, y = (float)gh;
-    const float rx = hm[0] * x + hm[1] * y + hm[2];
-    const float ry = hm[3] * x + hm[4] * y + hm[5];
-    const float rz = hm[6] * x + hm[7] * y + hm[8];
-    const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
+    // projection of this pixel: sw_ray once, sw_corner_weights per plane
+    float hmv[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) hmv[e] = hm[e];
+    float rx, ry, rz;
+    sw_ray(hmv, (float)gw, (float)gh, rx, ry, rz);
+    const float t0 = hmv[9], t1 = hmv[10], t2 = hmv[11];
     const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
 
     // the D depths of this pose live in one VGPR (lane z holds depth z): a per-plane scalar read instead of a memory load
     const int dbits = __float_as_int(lane < D ? dep[lane] : 1.f);
 
     auto corners = [&](int z, Corner& c) {
-      const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
-      const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
-      const float rinv = __builtin_amdgcn_rcpf(pz);
-      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
-      const bool fin = isfinite(ix) && isfinite(iy);
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
-      const float tx = ix - fx, ty = iy - fy;
-      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
-      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
-      // grid_sample padding_mode="zeros": a corner outside the image contributes 0 (its clamped address is read, times 0);
-      // a voxel outside the image is conv zero padding; a non-finite projection makes the voxel NaN like the reference
-      const float ux = 1.f - tx, uy = 1.f - ty;
-      c.w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
-      c.w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
-      c.w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
-      c.w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
-      if (inb && !fin) c.w[0] = __builtin_nanf("");
+      sw_corner_weights(rx, ry, rz, t0, t1, t2, __int_as_float(__builtin_amdgcn_readlane(dbits, z)), sx, sy, W, H, inb, c.w, c.off);
       if constexpr (BL == 2) {
         c.wp[0] = pack2_bf16(c.w[0], c.w[1]);
         c.wp[1] = pack2_bf16(c.w[2], c.w[3]);
@@ -513,11 +510,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
           c.wp[q] = __builtin_bit_cast(unsigned, h);
         }
       }
-      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
-      c.off[0] = (r0 + (unsigned)xc0) * 64u;
-      c.off[1] = (r0 + (unsigned)xc1) * 64u;
-      c.off[2] = (r1 + (unsigned)xc0) * 64u;
-      c.off[3] = (r1 + (unsigned)xc1) * 64u;
       if constexpr (SW_SKIP && std::is_same<T, unsigned short>::value) {
         // A plane on which all 64 voxels of this wave project outside the partner image (20-30 % of the (wave, plane) pairs at the
         // synthetic camera geometry): the blend is ref + 0, so the reference chunk is stored as it is, and the wave's gathers for that
@@ -867,44 +859,19 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
       }
     };
     auto tile_finish = [&](const TileRaw& R, TileP& P) {
-      const float x = (float)R.gw, y = (float)R.gh;
       P.inb = act && (unsigned)R.gh < (unsigned)H && (unsigned)R.gw < (unsigned)W;
-      P.rx = R.hm[0] * x + R.hm[1] * y + R.hm[2];
-      P.ry = R.hm[3] * x + R.hm[4] * y + R.hm[5];
-      P.rz = R.hm[6] * x + R.hm[7] * y + R.hm[8];
+      sw_ray(R.hm, (float)R.gw, (float)R.gh, P.rx, P.ry, P.rz);
       P.t0 = R.hm[9]; P.t1 = R.hm[10]; P.t2 = R.hm[11];
       P.dbits = R.dbits; P.srcb = R.srcb;
     };
     auto corners = [&](int z, const TileP& P, unsigned (&off)[4], unsigned (&wp)[4]) {
-      const float depth = __int_as_float(__builtin_amdgcn_readlane(P.dbits, z));
-      const float px = P.rx * depth + P.t0, py = P.ry * depth + P.t1, pz = P.rz * depth + P.t2;
-      const float rinv = __builtin_amdgcn_rcpf(pz);
-      const float ix = (px * rinv) * sx - 0.5f, iy = (py * rinv) * sy - 0.5f;
-      const bool fin = isfinite(ix) && isfinite(iy);
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fx, y0 = (int)fy;
-      const float tx = ix - fx, ty = iy - fy;
-      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
-      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
-      const float ux = 1.f - tx, uy = 1.f - ty;
       float w[4];
-      w[0] = (P.inb && xin0 && yin0) ? ux * uy : 0.f;
-      w[1] = (P.inb && xin1 && yin0) ? tx * uy : 0.f;
-      w[2] = (P.inb && xin0 && yin1) ? ux * ty : 0.f;
-      w[3] = (P.inb && xin1 && yin1) ? tx * ty : 0.f;
-      if (P.inb && !fin) w[0] = __builtin_nanf("");
+      sw_corner_weights(P.rx, P.ry, P.rz, P.t0, P.t1, P.t2, __int_as_float(__builtin_amdgcn_readlane(P.dbits, z)), sx, sy, W, H, P.inb != 0, w, off);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
         wp[q] = __builtin_bit_cast(unsigned, h);
       }
-      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
-      off[0] = (r0 + (unsigned)xc0) * 64u;
-      off[1] = (r0 + (unsigned)xc1) * 64u;
-      off[2] = (r1 + (unsigned)xc0) * 64u;
-      off[3] = (r1 + (unsigned)xc1) * 64u;
     };
     u32x4 g[4][4];                                       // [round][corner]
 #pragma unroll

@@ -155,7 +155,10 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                                                                 norm_mode=cfg.get("hip_norm_mode", "eval"),
                                                                 graph=bool(cfg.get("hip_graph", False)),
                                                                 graph_max_batch=int(cfg.get("hip_graph_max_batch", 32)),
-                                                                options={"view2_heads": int(self.view2_heads)})
+                                                                options={**{str(k): int(v) for k, v in dict(cfg.get("hip_options", {}) or {}).items()},
+                                                                         "view2_heads": int(self.view2_heads)})
+        # hip_options: any rgbm_adapose_set_option key (include/rgbm.h), e.g. {"sweep_f16": 0} for a bf16 checkpoint whose 32-channel
+        # feature map can exceed the f16 range (the plane sweep of bf16 nets reads it as f16 since round 5)
         if net is not None:
             # a shared network keeps ITS setting (changing it on the shared handle would drop every captured graph and change the other
             # users' outputs): report what it computes, and refuse the combination that would feed never-written view-2 outputs to the PnP tail

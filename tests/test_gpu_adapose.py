@@ -276,6 +276,11 @@ def test_estimator_skips_view2_heads_unless_the_tail_needs_them():
     assert AdaPoseEstimator_v5(None, dict(cfg, direct_regression=False, use_depth=True), None, state_dict=sd, dtype="bf16").view2_heads is False
     assert AdaPoseEstimator_v5(None, dict(cfg, direct_regression=False, use_depth=False), None, state_dict=sd, dtype="bf16").view2_heads is True
     assert AdaPoseEstimator_v5(None, dict(cfg, hip_view2_heads=True), None, state_dict=sd, dtype="bf16").view2_heads is True
+    # hip_options: rgbm_adapose_set_option keys through the cfg (round 5: sweep_f16 = 0 keeps a bf16 net's feature map in bf16); an unknown key fails loudly
+    est = AdaPoseEstimator_v5(None, dict(cfg, hip_options={"sweep_f16": 0}), None, state_dict=sd, dtype="bf16")
+    assert est.estimator.options["sweep_f16"] == 0 and est.estimator.options["view2_heads"] == 0
+    with pytest.raises(Exception):
+        AdaPoseEstimator_v5(None, dict(cfg, hip_options={"no_such_option": 1}), None, state_dict=sd, dtype="bf16")
 
 
 def test_fp32_batch_invariance_and_chunking():
@@ -288,6 +293,17 @@ def test_fp32_batch_invariance_and_chunking():
         o1 = _run(net1, one)
         for k in OUT_KEYS:
             assert _rel(out3[k][b:b + 1], o1[k]) < 1e-5, (b, k)
+
+
+def test_bf16_sweep_f16_off_close_to_golden(inputs, golden_dir):
+    """option sweep_f16 = 0: the all-bf16 plane sweep of rounds 1-4 (bf16 feature map, fp32 blend, one workgroup per tile) stays inside the bf16 gates."""
+    g = np.load(os.path.join(golden_dir, "adapose_b2.npz"))
+    out = _run(_net("bf16", options={"sweep_f16": 0}), inputs)
+    errs = {k: _rel(out[k], g[k]) for k in OUT_KEYS}
+    print("bf16, sweep_f16 = 0, vs reference golden:", errs)
+    gate = {"nocs": 2.7e-2, "depth": 1.0e-2, "r": 6.0e-3, "t": 3.5e-3, "s": 1.2e-3}
+    for k in OUT_KEYS:
+        assert np.isfinite(out[k]).all() and errs[k] < gate[k.split("_")[1]], (k, errs)
 
 
 @pytest.mark.parametrize("cost_impl", [3, 2, 0])
@@ -359,6 +375,29 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps, blend):
     print(blend, "c0 vs the fp32 oracle: tile", rel[2], "sweep", rel[3])
     if blend == "f16_features":
         assert rel[3] < rel[2]      # more mantissa in the features: closer to fp32 than the all-bf16 conv0
+
+
+def test_persistent_sweep_is_bit_identical_to_the_one_tile_sweep(inputs):
+    """conv0_sweep_persistent_kernel (one workgroup per CU walks its tiles, the two roles stream across tile boundaries; the default of bf16
+    nets) against the one-workgroup-per-tile kernel with the same arithmetic (debug flag 268435456): the whole c0 volume, and the network
+    outputs with the sparse cost regularisation's tile list, bit for bit."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+
+    def run(flag, sparse_dec):
+        _lib.check(lib.rgbm_debug_flags(flag))
+        try:
+            net = _net("bf16", options={"sparse_dec": sparse_dec})
+            if sparse_dec == 0:
+                _run(net, inputs, stop_after=2)
+                return net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).cpu().numpy()
+            return _run(net, inputs)
+        finally:
+            _lib.check(lib.rgbm_debug_flags(0))
+    np.testing.assert_array_equal(run(0, 0), run(1 << 28, 0))
+    a, b = run(0, 2), run(1 << 28, 2)
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])

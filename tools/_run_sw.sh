@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/r5k
-SPARSE_DEC=2 timeout 300 python tools/kernel_ms.py bf16 2>&1 | grep -v amdgpu | awk '{printf "%-64s %s %s %s\n", substr($0, 47, 62), $(NF-2), $(NF-1), $NF}' | sort -k4 -n -r -t' ' | tee gpurun_out/r5k/rows.txt
+mkdir -p gpurun_out/r5f3
+timeout 900 python bench.py > gpurun_out/r5f3/bench_default.json 2> gpurun_out/r5f3/bench_default.err
+timeout 900 python -m pytest tests -m gpu -q -k "persistent or hip_options or skips_view2 or sweep_f16_off" 2>&1 | tail -3 > gpurun_out/r5f3/new_tests.txt
+timeout 300 python tools/kernel_ms.py bf16 conv0_sweep 2>&1 | tail -1 >> gpurun_out/r5f3/new_tests.txt
