@@ -610,13 +610,15 @@ def _sweep_case(B, D, H, W, seed, singular_pose=None):
 
 
 @pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16, "f16feat", "f16pk"])
-@pytest.mark.parametrize("shape", [(5, 20, 37), (1, 16, 16), (24, 33, 16), (3, 48, 50)])
+@pytest.mark.parametrize("shape", [(5, 20, 37), (1, 16, 16), (24, 33, 16), (3, 48, 50), (3, 100, 330), (1, 100, 330)])
 def test_conv0_sweep_matches_volume_then_conv(shape, dtype):
     """Depth-sweeping conv0 (plane sweep fused, paired depth taps, producer/consumer waves) against the two kernels it
     replaces run one after the other: build_volume (pinned to the reference's homo_warping golden above) followed by a
     plain fp32 conv3d + folded BN + ReLU on that volume.  Ragged tiles in H and W, D = 1, and NaN isolation.
     "f16feat": what a bf16 net runs by default since round 5 — f16 features and weights, packed-f16 blend, bf16 c0
-    (rgbm_conv0_sweep_f16feat); "f16pk": an fp16 net's sweep with the packed-f16 blend (debug flag 2097152)."""
+    (rgbm_conv0_sweep_f16feat: the persistent kernel); "f16pk": an fp16 net's sweep with the packed-f16 blend (debug flag 2097152).
+    The 100 x 330 shapes are 756 tiles, ragged in both directions: three tiles per workgroup of the persistent kernel (its producers
+    and consumers stream across tile boundaries), with a plane loop of two iterations + the peeled last plane, and with D = 1 (no loop)."""
     from gpu_util import to_channels_last, from_channels_last, rel_err, host_f32, TORCH_DT
     lib = _lib.load()
     D, H, W = shape
