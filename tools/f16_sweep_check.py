@@ -1,5 +1,5 @@
 """fp16 conv0 sweep: run-to-run bit stability (compared on the device, any batch size) and, for small batches, agreement with
-the halo-tile conv0 (debug flag 4096 selects the tile kernel).  usage: f16_sweep_check.py [B] [runs]"""
+the halo-tile conv0 (debug flag 4096 selects the tile kernel).  usage: f16_sweep_check.py [B] [runs] [dtype: fp16 (default) | bf16 = the persistent kernel on the f16 feature map]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 inp = synth.adapose_inputs(B, seed=0)
 sd = synth.adapose_state_dict(seed=0, prefix="module.")
-net = AdaPoseNet(sd, dtype="fp16", cost_impl=3)
+net = AdaPoseNet(sd, dtype=(sys.argv[3] if len(sys.argv) > 3 else "fp16"), cost_impl=3, options={"sparse_dec": 0})      # the whole c0 volume is compared
 
 
 def tap(name, per_view, flag=0):
