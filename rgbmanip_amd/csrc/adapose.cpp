@@ -624,11 +624,11 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   }
   if (int rc = pm1[0].run(pf_in, bf.Q128a, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, Vh, P, 128, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, bf.Q128a, Vh, P, 128, s)) return rc;
   if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, Vh, 128, 256, 256, 128, 0, s)) return rc;
   if (int rc = pm2[0].run(bf.Q128b, bf.G256a, Vh, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
   if (int rc = pm2[1].run(bf.G256a, bf.G256b, Vh, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, Vh, P, 256, s)) return rc;
+  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, bf.G256a, Vh, P, 256, s)) return rc;
   float* hout[3] = {bf.r6, bf.tv, bf.sv};
   const int hdim[3] = {6, 3, 3};
   if (int rc = launch_pose_heads(bf.pf2, head_w, head_b, hout, hdim, Vh, s)) return rc;

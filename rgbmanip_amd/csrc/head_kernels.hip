@@ -260,15 +260,20 @@ int launch_fuse_points(int dtype, const void* feat, const float* homog, const fl
 }
 
 // ---------------------------------------------------------------- mean over the P points of each view
-// in [V*P][C] (fp32, or fp16 for the pose MLP of bf16 nets) -> out [V][C] fp32.  One block of 256 threads per view: C/E
+// in [V*P][C] (fp32, or fp16 for the pose MLP of bf16 nets) -> out [V][C] fp32.  Blocks of 256 threads: C/E
 // threads cover a row with 16-byte loads (E = 4 or 8 channels), 256/(C/E) rows are read side by side, every thread sums
-// its channels over P / rows rows in fp32, and the row groups are added through LDS.  (One 2- or 4-byte element per thread
-// and row ran at 1.5 TB/s.)
+// its channels over its share of the rows in fp32, and the row groups are added through LDS.  (One 2- or 4-byte element per
+// thread and row ran at 1.5 TB/s.)
+// Round 5: kMeanSplit workgroups per view (a slice of P / kMeanSplit points each, partial sums into `part`) and a second launch that adds
+// the slices in a fixed order - one workgroup per view read its 256-512 KB through one CU's latency (20 + 38 us of a 1.49 ms forward at
+// B = 1).  The split does not depend on the batch size, so neither does the order of the sums.
+constexpr int kMeanSplit = 8;
 template <typename TI>
-__global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__ in, float* __restrict__ out, int P, int C) {
+__global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__ in, float* __restrict__ partial, int P, int C) {
   constexpr int E = 16 / sizeof(TI);
   __shared__ float part[256 * E];
-  const int v = blockIdx.x;
+  const int v = blockIdx.x / kMeanSplit, sl = blockIdx.x % kMeanSplit;
+  const int p0 = (int)((long long)P * sl / kMeanSplit), p1 = (int)((long long)P * (sl + 1) / kMeanSplit);
   const int tpr = C / E, rows = 256 / tpr;                 // threads per row, rows in flight
   const int cc = threadIdx.x % tpr, rp = threadIdx.x / tpr;
   float acc[E];
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
   if (rp < rows)
 #pragma unroll 8
-    for (int p = rp; p < P; p += rows) {                     // unrolled: eight 16-byte loads in flight per thread
+    for (int p = p0 + rp; p < p1; p += rows) {               // unrolled: eight 16-byte loads in flight per thread
       float t[E];
       unpack_chunk(*reinterpret_cast<const uint4*>(in + ((long long)v * P + p) * C + cc * E), t, TI());
 #pragma unroll
@@ -290,20 +295,34 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__
   for (int c = threadIdx.x; c < C; c += 256) {
     float sum = 0.f;
     for (int r = 0; r < rows; ++r) sum += part[r * C + c];
+    partial[(long long)blockIdx.x * C + c] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_points_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int C) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < kMeanSplit; ++sl) sum += partial[((long long)v * kMeanSplit + sl) * C + c];
     out[(long long)v * C + c] = sum / (float)P;
   }
 }
 
-int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s) {
+// scratch: V * 8 * C floats (any buffer that is free between the producer of `in` and the consumer of `out`)
+int launch_mean_points(int dtype, const void* in, float* out, float* scratch, int V, int P, int C, hipStream_t s) {
   RGBM_REQUIRE(dtype == F32 || dtype == F16 || dtype == BF16X3, "mean_points: fp32, fp16 or split-pair input");
+  RGBM_REQUIRE(scratch != nullptr && (const void*)scratch != in && scratch != out, "mean_points: scratch");
   const int E = dtype == F16 ? 8 : 4;
   RGBM_REQUIRE(C % E == 0 && C / E <= 256 && 256 % (C / E) == 0, "mean_points: channel count");
+  const dim3 g((unsigned)V * kMeanSplit);
   if (dtype == F16)
-    hipLaunchKernelGGL(mean_points_kernel<f16_t>, dim3(V), dim3(256), 0, s, (const f16_t*)in, out, P, C);
+    hipLaunchKernelGGL(mean_points_kernel<f16_t>, g, dim3(256), 0, s, (const f16_t*)in, scratch, P, C);
   else if (dtype == BF16X3)
-    hipLaunchKernelGGL(mean_points_kernel<bx3_t>, dim3(V), dim3(256), 0, s, (const bx3_t*)in, out, P, C);
+    hipLaunchKernelGGL(mean_points_kernel<bx3_t>, g, dim3(256), 0, s, (const bx3_t*)in, scratch, P, C);
   else
-    hipLaunchKernelGGL(mean_points_kernel<float>, dim3(V), dim3(256), 0, s, (const float*)in, out, P, C);
+    hipLaunchKernelGGL(mean_points_kernel<float>, g, dim3(256), 0, s, (const float*)in, scratch, P, C);
+  hipLaunchKernelGGL(mean_points_finish_kernel, dim3(V), dim3(256), 0, s, (const float*)scratch, out, P, C);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }

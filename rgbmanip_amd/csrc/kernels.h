@@ -42,7 +42,7 @@ int launch_prob_softmax_depth(int dtype, const void* u11, const float* wprob, co
 int launch_fuse_points(int dtype, const void* feat, const float* homog, const float* depths, const int* choose,
                        const float* prob, float* out, int V, int B, int P, int D, int H, int W, int ldo, int ch_off,
                        hipStream_t s, int Vn = -1);      // Vn: views 0 .. Vn - 1 only (default: all V)
-int launch_mean_points(int dtype, const void* in, float* out, int V, int P, int C, hipStream_t s);      // dtype of `in`: F32 or F16
+int launch_mean_points(int dtype, const void* in, float* out, float* scratch, int V, int P, int C, hipStream_t s);      // dtype of `in`: F32 or F16
 int launch_f32_to_f16(const float* in, void* out, long long n, hipStream_t s);
 // ResNet stem in one kernel (stem.hip): NCHW fp32 images -> maxpool3x3s2(relu(conv7x7s2)) [V][S/4][S/4][64]
 void stem_pack(const float* w, std::vector<float>& packed);

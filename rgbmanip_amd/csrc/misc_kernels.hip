@@ -348,6 +348,7 @@ __global__ __launch_bounds__(512) void adaptive_avgpool_kernel(const T* __restri
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
     if (cc < C / E)
+#pragma unroll 4                                            // four loads in flight per thread (round 5: the one-bin cell walks 98 pixels per lane; 39 -> 14 us at B = 1); same order of the sums
       for (int p = pl; p < npx; p += PL) {
         const int h = h0 + p / ww, w = w0 + p % ww;
         float x[E];
