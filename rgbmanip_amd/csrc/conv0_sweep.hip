@@ -1,23 +1,30 @@
 // conv0 of the cost-regularisation net (Conv3d 32->8, k3 p1 + BN + ReLU, network_v5.py:260-291) with the plane sweep
 // (homo_warping + "ref + warped" fusion, network_v5.py:378-430) built on the fly — depth-sweeping, role-specialised
-// bf16 kernel for gfx950.  Replaces the halo-tile kernel (conv3d_tile.hip, layer 10) whose staging, MFMA and store
+// 16-bit kernels for gfx950.  They replace the halo-tile kernel (conv3d_tile.hip, layer 10) whose staging, MFMA and store
 // phases ran back to back: all blocks of a launch march through identical phases in lock step, so nothing overlaps.
 //
-// One workgroup owns a 12x16 (H x W) column of one view and sweeps it through all D depth planes:
-//   * producer waves (4, one per SIMD): one thread per voxel of the 14x18 input plane incl. halo.  The thread keeps the reference
-//     feature of its pixel in registers for the whole sweep; per plane it projects the pixel with that plane's depth,
-//     gathers the 4 bilinear corners of the partner view's feature map (corners outside the image get weight 0:
-//     grid_sample padding_mode="zeros"), blends in fp32, rounds to bf16 and writes the 64-byte voxel into one of
-//     three LDS plane slots.  The corner loads of plane z+1 are issued before plane z is blended (two register sets), so
-//     gather latency is covered by VALU work.  Halo redundancy is 252/192 = 1.31x (the 4x8x8 tile: 2.34x).
-//   * consumer waves (3): MFMA 16x16x32 bf16, input-plane stationary.  Cout = 8 fills only half of the 16 MFMA rows,
-//     so two depth taps share one instruction: A01[t] = rows 0-7 W(kd=0,t), rows 8-15 W(kd=1,t); A2[t] = rows 8-15
+// A 12x16 (H x W) column of one view is swept through all D depth planes by one workgroup:
+//   * producer waves (4, one per SIMD): per plane they project the 14x18 input plane's voxels (incl. halo) with that plane's depth
+//     (sw_ray / sw_corner_weights), gather the 4 bilinear corners of the partner view's feature map (corners outside the image get
+//     weight 0: grid_sample padding_mode="zeros"), blend, and write the 64-byte voxels into an LDS ring of plane slots.  The corner
+//     loads of plane z+1 are issued (inline asm, counted vmcnt) right behind the blend of plane z out of the same registers, so
+//     gather latency is covered.  Halo redundancy is 252/192 = 1.31x (the 4x8x8 tile: 2.34x).
+//   * consumer waves (4 x 3 tile rows; 3 x 4 in rounds 1-4): MFMA 16x16x32, input-plane stationary.  Cout = 8 fills only half of the 16
+//     MFMA rows, so two depth taps share one instruction: A01[t] = rows 0-7 W(kd=0,t), rows 8-15 W(kd=1,t); A2[t] = rows 8-15
 //     W(kd=2,t).  For input plane p and in-plane tap t:  X[p] += A01[t]*B,  X[p-1] += A2[t]*B  (same B register), hence
 //     out[o] = rows 8-15 of X[o] (kd=1 from plane o, kd=2 from plane o+1)  +  rows 0-7 of X[o-1] (kd=0 from plane o-1).
-//     18 MFMAs per 16-voxel fragment and plane instead of 27, one LDS read per two MFMAs, weights live in registers.
-//     The two row halves sit in lanes 0-31 / 32-63 of the accumulator: v_permlane32_swap pairs two fragments so the
-//     final add, bias, ReLU and the 8-byte stores run on all 64 lanes.
-// One s_barrier per plane hands slot z%3 from the producers to the consumers; producers fill the next slot meanwhile.
+//     18 MFMAs per 16-voxel fragment and plane instead of 27, weights live in registers, the folded BN shift is the accumulators'
+//     initial value.  The two row halves sit in lanes 0-31 / 32-63 of the accumulator: v_permlane32_swap pairs two fragments so the
+//     final add, ReLU and the 8-byte stores run on all 64 lanes.
+// One s_barrier per plane hands a ring slot from the producers to the consumers; producers fill the next slot meanwhile.
+//
+// Three forms (launch_conv0_sweep picks):
+//   conv0_sweep_kernel<bf16, bf16, 0/1/2>   bf16 feature map, one lane per voxel, fp32 blend (rounds 1-4; option sweep_f16 = 0)
+//   conv0_sweep_kernel<f16, f16, 0/3>       fp16 nets: fp32-accumulating v_fma_mix blend (0) or packed f16 (3, debug flag 2097152)
+//   conv0_sweep_persistent_kernel<bf16>     bf16 nets since round 5: f16 feature map, packed-f16 blend, cooperative gathers (four lanes
+//                                           per corner pixel), one workgroup per CU walking its tiles with both roles streaming across
+//                                           tile boundaries; conv0_sweep_kernel<f16, bf16, 3> is its one-tile twin (debug flag 268435456),
+//                                           bit-identical.  Why packed f16: tools/micro/mfma_valu_coissue.hip, DESIGN 5e.
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -294,9 +301,10 @@ __device__ __forceinline__ void sw_corner_weights(float rx, float ry, float rz, 
 
 }  // namespace
 
-// min 3 waves per SIMD (<= 168 VGPRs): the hardware then starts the next workgroup's producers while this one's consumers
-// finish (12 wave slots per CU for 7-wave workgroups).  The bf16 instantiation needs 164 anyway; uncapped, the f16_t one
-// took 170 and lost that overlap.
+// The one-tile form.  Register cap of three waves per SIMD (<= 168 VGPRs; the instantiations need 150): with the seven-wave
+// workgroups of rounds 1-4 the hardware could start the next workgroup's first waves while this one's consumers finished; an
+// eight-wave workgroup (four consumer waves, round 5) leaves room for nothing else on the CU, which is what the persistent
+// form below turns into a design (-DSW_OCC=4, two workgroups per CU at 128 registers: 64 bytes of scratch, slower).
 // T: storage type of the feature maps and the conv0 weights = the MFMA operand type; TO: storage type of c0.  <f16_t, unsigned short> is the
 // bf16 nets' default since round 5 (`final` writes their feature map as f16 for this kernel: adapose.cpp feat_f16()).
 template <typename T, typename TO, int BL>
