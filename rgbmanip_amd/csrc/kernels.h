@@ -25,7 +25,7 @@ int launch_upconv_combine(int dtype, const void* z, const float* bias, void* out
                           float slope, hipStream_t s);
 // up_3 + final of the PSPNet tail in one kernel (upconv_final.hip): x [V][h][w][64] -> out [V][2h][2w][32]
 int launch_upconv_final(int dtype, const void* x, const void* wz, const float* bias, float slope, const void* wf, const float* biasf,
-                        void* out, int out_f32, int V, int h, int w, hipStream_t s);
+                        void* out, int out_f32, int V, int h, int w, hipStream_t s, const void* wf_f16 = nullptr);      // wf_f16: `final` weights in f16 (out_f32 == 2)
 
 // bn_kernels.hip — per-sample (train-mode, batch 1) BatchNorm3d + ReLU + skip add, in place on the un-normalised conv output
 size_t bn_scratch_bytes(int V);

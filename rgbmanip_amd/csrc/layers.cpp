@@ -310,6 +310,7 @@ int UpConvFinal::init(int dtype_, const float* w3, const float* b3, float slope_
       for (int c = 0; c < 64; ++c) z[((size_t)t * 64 + o) * 64 + c] = w3[((size_t)o * 64 + c) * 9 + t];
   if (int rc = upload_packed(z, dtype, &wz)) return rc;
   if (int rc = upload_packed(f, dtype, &wf)) return rc;
+  if (dtype == BF16) if (int rc = upload_packed(f, F16, &wf_h)) return rc;
   if (upload_f32(b3, 64, &bias) || upload_f32(bfin, 32, &biasf)) return -2;
   return 0;
 }
@@ -317,13 +318,15 @@ int UpConvFinal::init(int dtype_, const float* w3, const float* b3, float slope_
 void UpConvFinal::destroy() {
   if (wz) (void)hipFree(wz);
   if (wf) (void)hipFree(wf);
+  if (wf_h) (void)hipFree(wf_h);
+  wf_h = nullptr;
   if (bias) (void)hipFree(bias);
   if (biasf) (void)hipFree(biasf);
   wz = wf = nullptr; bias = biasf = nullptr;
 }
 
 int UpConvFinal::run(const void* in, void* out, int out_kind, int V, int h, int w, hipStream_t s) const {
-  return launch_upconv_final(dtype, in, wz, bias, slope, wf, biasf, out, out_kind, V, h, w, s);
+  return launch_upconv_final(dtype, in, wz, bias, slope, wf, biasf, out, out_kind, V, h, w, s, wf_h);
 }
 
 }  // namespace rgbm

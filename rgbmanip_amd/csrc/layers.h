@@ -82,6 +82,7 @@ struct UpConvLayer {
 struct UpConvFinal {
   void* wz = nullptr;            // [9 * 64][64] storage type, rows in (tap, channel) order
   void* wf = nullptr;            // [32][64] storage type
+  void* wf_h = nullptr;          // bf16 nets: the same in f16 (out_kind 2: the f16 tail)
   float* bias = nullptr;         // [64] up_3 bias
   float* biasf = nullptr;        // [32] final bias
   float slope = 0.f;
