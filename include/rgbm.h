@@ -83,7 +83,8 @@ int rgbm_adapose_set_chunk(rgbm_adapose_t* h, int max_chunk_views);
  * "sweep_f16" (bf16 nets with cost_impl 3 and upconv bit 2; 1 [default since round 5] = `final` writes the 32-channel feature map as f16
  * instead of bf16 - same bytes, three more mantissa bits - and the plane sweep (persistent conv0_sweep kernel) blends it with packed f16
  * FMAs and multiplies with f16 MFMAs; c0 and everything behind it stay bf16.  Features beyond +-65504 saturate, as in an fp16 net; 0 =
- * bf16 feature map and the fp32 blend of rounds 1-4.  The "feat" tap of rgbm_adapose_fetch converts from whichever form was written).
+ * bf16 feature map and the fp32 blend of rounds 1-4.  The "feat" tap of rgbm_adapose_fetch converts from whichever form was written.
+ * With 1 the one-kernel up_3 + `final` also runs its tap combination, PReLU and `final` in packed f16: faster, and closer to fp32).
  * Set before querying the workspace size. */
 int rgbm_adapose_set_option(rgbm_adapose_t* h, const char* key, int value);
 int rgbm_adapose_workspace_bytes(rgbm_adapose_t* h, int B, size_t* bytes);
