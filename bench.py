@@ -294,6 +294,25 @@ def time_steps(fn, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a child
+    process (one rank per GPU over RCCL, what the driver's own N > 1 command does), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def achievable_peaks(lib, device):
     """the peaks this box reaches, measured next to the datasheet ones (rgbm_microbench_*: a bare bf16 MFMA stream in the
     register shape of the implicit GEMM's multiply waves on constant and on pseudo-random operands, and a 16-byte copy).  ~0.3 s."""
@@ -372,7 +391,8 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / B = 8 latency leg (eager launches and hipGraph replay)")
     ap.add_argument("--no-peaks", action="store_true", help="skip the achievable-peak probes (bare MFMA stream, copy kernel; ~0.3 s)")
     ap.add_argument("--no-prof", action="store_true", help="timing experiment: no per-launch HIP events in the timed region (the roofline object is then empty)")
-    ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each extra mode leg")
+    ap.add_argument("--mode-steps", type=int, default=10, help="timed steps of each extra mode leg (behind --mode-warmup untimed ones)")
+    ap.add_argument("--mode-warmup", type=int, default=2, help="untimed steps in front of each extra mode leg")
     ap.add_argument("--debug-flags", type=int, default=0, help="kernel A/B switches (rgbm_debug_flags); a non-zero value is echoed in config")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the golden-vector accuracy leg (profiling runs: keeps the trace to the timed steps)")
     args = ap.parse_args()
@@ -383,8 +403,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
-                         f"(WORLD_SIZE={world})")
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} under a launcher that set WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}")
+        # Launched plainly (`python bench.py --gpus N`, the shape of the N = 1 command): start the ranks as a CHILD process — this process has
+        # not touched the GPU yet, and it never replaces itself (no exec) —, relay rank 0's JSON line and the child's exit code.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     # RGBM_BENCH_ONE_DEVICE=1 (+ RGBM_DIST_BACKEND=gloo) lets a 1-GPU box rehearse the multi-rank code path: every rank uses cuda:0
     if os.environ.get("RGBM_BENCH_ONE_DEVICE") == "1":
@@ -506,15 +529,15 @@ def main():
             mnet2 = AdaPoseNet(sd0, dtype=md, device=local_rank, max_chunk_views=args.chunk or None)
             macc = accuracy_vs_golden(mnet2, device)
             mstep2 = mkstep(mnet2, d)
-            mdt = time_steps(mstep2, 1, args.mode_steps)
+            mdt = time_steps(mstep2, args.mode_warmup, args.mode_steps)
             mnet2.poison_workspace = True
             batch_outs[md] = {k: v.clone() for k, v in mstep2()[0].items()}
             torch.cuda.synchronize()
             modes_res[md] = {"poses_per_sec": round(B / mdt, 1), "ms_per_step": round(mdt * 1e3, 2), "batch": B, "steps": args.mode_steps,
-                             "accuracy": macc}
+                             "warmup": args.mode_warmup, "accuracy": macc}
             if md == "bf16x3" and not args.no_dense_leg:
                 dn = AdaPoseNet(sd0, dtype=md, device=local_rank, max_chunk_views=args.chunk or None, options={"sparse_dec": 0})
-                ddt = time_steps(mkstep(dn, d), 1, args.mode_steps)
+                ddt = time_steps(mkstep(dn, d), args.mode_warmup, args.mode_steps)
                 modes_res[md]["dense"] = {"poses_per_sec": round(B / ddt, 1), "ms_per_step": round(ddt * 1e3, 2)}
                 del dn
             del mnet2
@@ -923,6 +946,10 @@ def main():
                        "cost_regularisation": ("library default (sparse_dec = 2): computed only where the chosen pixels' outputs depend on it, all ten "
                                                "outputs bit-identical to the dense computation; value_dense / value_worst_case of the same run are "
                                                "top-level keys" if args.dtype != "fp32" else "dense"),
+                       **({"storage_detail": "bf16 net with sweep_f16 = 1 (library default): the 32-channel feature map `final` writes, the conv0 weights of "
+                                             "the plane sweep and the y / z of the one-kernel PSPNet tail are IEEE f16 (saturating at +-65504), f16 MFMAs in the "
+                                             "sweep; every other tensor is bf16; hip_options {sweep_f16: 0} gives the all-bf16 net",
+                           "sweep_f16": int(net.options.get("sweep_f16", 1))} if args.dtype == "bf16" else {}),
                        **({"debug_flags": args.debug_flags} if args.debug_flags else {})},
             "world_size": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
             "tree": tree_hash(),

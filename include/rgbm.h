@@ -299,8 +299,12 @@ int rgbm_upsample_conv3x3(int dtype, const void* in_dev, int V, int h, int w, in
                           const float* bias_host, int act, float slope, void* z_scratch_dev, void* out_dev, void* stream);
 /* The PSPNet tail as the 16-bit / split-pair network runs it: up_3 (PSPUpsample 64 -> 64, PReLU `slope`) and `final`
  * (pspnet.py:136, Conv2d 1x1 64 -> 32 + bias) in one kernel (upconv_final.hip).  in_dev [V][h][w][64] (h, w multiples of 8),
- * w3_host [64][64][3][3], b3_host [64], wf_host [32][64], bf_host [32]; out_dev [V][2h][2w][32] in `dtype`, or plain fp32 when
- * out_f32 (RGBM_BF16X3 only).  dtype RGBM_BF16 / RGBM_F16 / RGBM_BF16X3. */
+ * w3_host [64][64][3][3], b3_host [64], wf_host [32][64], bf_host [32]; dtype RGBM_BF16 / RGBM_F16 / RGBM_BF16X3.
+ * out_f32 is an ENUM since round 5 (it was a boolean before; any other value is refused with RGBM_ERR_ARG):
+ *   0 = out_dev [V][2h][2w][32] in `dtype`;
+ *   1 = plain fp32 output (RGBM_BF16X3 only: the feature map the split-pair plane sweep gathers from);
+ *   2 = IEEE f16 output through the packed-f16 tail (RGBM_BF16 only: the bf16 network's `sweep_f16` feature map; refused when
+ *       `final`'s weights do not fit f16 — a value >= 65504 or more than 0.1 % of the weight mass below 2^-14). */
 int rgbm_upsample_conv3x3_final(int dtype, const void* in_dev, int V, int h, int w, const float* w3_host, const float* b3_host,
                                 float slope, const float* wf_host, const float* bf_host, void* out_dev, int out_f32, void* stream);
 /* The ResNet stem as the 16-bit / split-pair network runs it (stem.hip): Conv2d 7x7 stride 2 pad 3 (3 -> 64, no bias, pspnet.py:37)

@@ -183,7 +183,8 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
         conv0_sweep_pack(w->data, scale.data(), packed);
         if (dtype == BF16X3) { if (conv0_sweep_x3_upload(packed, &sweep_w)) return -2; }
         else if (upload_packed(packed, dtype, &sweep_w)) return -2;
-        if (dtype == BF16 && upload_packed(packed, F16, &sweep_w_f16)) return -2;
+        // the f16 form of the sweep (sweep_f16) only for weights that f16 can hold: otherwise sweep_w_f16 stays null and feat_f16() is false
+        if (dtype == BF16 && weights_fit_f16(packed) && upload_packed(packed, F16, &sweep_w_f16)) return -2;
       }
     }
   }
@@ -269,7 +270,7 @@ bool AdaPose::feat_f32_only() const {
 // depth-sweeping conv0 (the halo-tile / volume paths read the storage type).
 bool AdaPose::feat_f16() const {
   return dtype == BF16 && sweep_f16 != 0 && cost_impl == 3 && sweep_w_f16 != nullptr && norm_mode == 0 && !(g_debug_flags & 4096) && (upconv & 4) &&
-         tail.ready();
+         tail.ready() && tail.f16_ready();
 }
 
 bool AdaPose::sparse_active() const {

@@ -88,6 +88,7 @@ struct UpConvFinal {
   float slope = 0.f;
   int dtype = 0;
   bool ready() const { return wz != nullptr; }
+  bool f16_ready() const { return wf_h != nullptr; }      // `final`'s weights are representable in f16 (weights_fit_f16): the f16 tail exists
   // w3 [64][64][3][3], b3 [64], wfin [32][64], bfin [32] (nn.Conv2d layouts)
   int init(int dtype, const float* w3, const float* b3, float slope, const float* wfin, const float* bfin);
   void destroy();
@@ -96,6 +97,7 @@ struct UpConvFinal {
 };
 
 // device upload helpers
+bool weights_fit_f16(const std::vector<float>& w);      // no value saturates in IEEE f16, no appreciable weight mass below its smallest normal
 int upload_packed(const std::vector<float>& w, int dtype, void** dev);      // host fp32 -> device array in storage type dtype
 int upload_f32(const float* host, size_t n, float** dev);
 

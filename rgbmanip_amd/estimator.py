@@ -167,6 +167,13 @@ class AdaPoseEstimator_v5(BasePoseEstimator):
                 raise ValueError("AdaPoseEstimator_v5: this cfg needs the view-2 heads (hip_view2_heads, or the PnP tail of "
                                  "direct_regression=False / use_depth=False), but the shared net was built with view2_heads=0")
             self.view2_heads = net_v2
+            # ... and the same for hip_options: a key this cfg names must already hold on the shared net (round-5 advice: silently
+            # ignoring e.g. {"sweep_f16": 0} would run the f16 feature map the user opted out of)
+            want = {str(k): int(v) for k, v in dict(cfg.get("hip_options", {}) or {}).items()}
+            differ = {k: (v, net.options.get(k)) for k, v in want.items() if net.options.get(k) != v}
+            if differ:
+                raise ValueError("AdaPoseEstimator_v5: cfg.hip_options is not applied to a shared net; build the AdaPoseNet with "
+                                 f"options={want} (requested vs the net's: {differ})")
         self.rng = np.random          # the reference shuffles with the global numpy RNG (interface_v5.py:129)
         # "device" (default since round 5): frames are uploaded once and cropped / resized / sub-sampled on the GPU (rgbm_prepare_inputs);
         # a mask with more than 1024 pixels keeps the 1024 smallest hash keys (hip_prepare_seed) instead of the pixels np.random.shuffle

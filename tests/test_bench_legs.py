@@ -34,3 +34,21 @@ def test_cpu_baseline_leg_runs():
 def test_tree_hash_is_stable_and_ignores_profiles(tmp_path):
     import bench
     assert bench.tree_hash() == bench.tree_hash() and len(bench.tree_hash()) >= 12
+
+
+def test_plain_multi_gpu_launch_starts_its_ranks_as_children():
+    """`python bench.py --gpus 2` without a launcher must not die with a usage message (round-5 verdict item 6): it starts
+    torch.distributed.run as a child before any GPU call, relays the ranks' output and returns their exit code.  On this GPU-less
+    box both ranks stop at bench.py's own "needs a GPU" assertion — which proves they were started with WORLD_SIZE = 2."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU box: tests/test_gpu_dist.py runs the full rehearsal")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode != 0                                            # the children's failure is the parent's exit code
+    assert "needs `python -m torch.distributed.run" not in (r.stderr + r.stdout)
+    assert r.stderr.count("bench.py needs a GPU") >= 2                  # both ranks ran bench.py's main()

@@ -281,6 +281,34 @@ def test_estimator_skips_view2_heads_unless_the_tail_needs_them():
     assert est.estimator.options["sweep_f16"] == 0 and est.estimator.options["view2_heads"] == 0
     with pytest.raises(Exception):
         AdaPoseEstimator_v5(None, dict(cfg, hip_options={"no_such_option": 1}), None, state_dict=sd, dtype="bf16")
+    # a SHARED net keeps its own options: a cfg that asks for something else is refused, one that names what the net has is accepted
+    assert AdaPoseEstimator_v5(None, dict(cfg, hip_options={"sweep_f16": 0}), None, dtype="bf16", net=est.estimator).estimator is est.estimator
+    with pytest.raises(ValueError, match="shared net"):
+        AdaPoseEstimator_v5(None, dict(cfg, hip_options={"sweep_f16": 1}), None, dtype="bf16", net=est.estimator)
+
+
+def test_f16_feature_map_only_for_weights_that_fit_f16():
+    """sweep_f16 (bf16 nets: f16 feature map, f16 conv0 / `final` weights) is the default, but only for checkpoints whose folded conv0 and
+    `final` weights are representable in IEEE f16 (round-5 advice): scaled beyond +-65504 — or down into the f16 subnormals — the network
+    falls back to the all-bf16 form by itself instead of saturating silently."""
+    inp = synth.adapose_inputs(1, seed=3)
+
+    def feat_dtype(sd):
+        net = _net_sd(sd, "bf16")
+        _run(net, inp, stop_after=1)
+        f = net.fetch(1, "feat", 2 * 224 * 224 * 32)            # fp32 copies of the stored values
+        assert torch.isfinite(f).all() and float(f.abs().max()) > 0
+        # a bf16 value has 8 significand bits (low 16 bits of its fp32 form are zero), an f16 value up to 11
+        return torch.float16 if bool((f.view(torch.int32) & 0xFFFF).any()) else torch.bfloat16
+
+    sd = synth.adapose_state_dict(seed=0)
+    assert feat_dtype(sd) == torch.float16
+    big = dict(sd)
+    big["cost_regularization.conv0.conv.weight"] = sd["cost_regularization.conv0.conv.weight"] * 1e6
+    assert feat_dtype(big) == torch.bfloat16
+    tiny = dict(sd)
+    tiny["img_extractor.final.weight"] = sd["img_extractor.final.weight"] * 1e-6
+    assert feat_dtype(tiny) == torch.bfloat16
 
 
 def test_fp32_batch_invariance_and_chunking():
@@ -632,13 +660,15 @@ def _estimate_paths_agree(host, dev, cfg, sd, K, rgb, mask, E1, rgb2, mask2, E2,
     pipe = AdaPoseEstimator_v5(None, dict(cfg, hip_prepare="device", hip_prepare_seed=9, hip_upload_chunk=2), None, state_dict=sd, dtype="fp32")
     assert N > 4
     b_pipe = pipe.estimate(K, rgb.astype(np.float64), mask.astype(np.float64), E1, rgb2.astype(np.float64), mask2.astype(bool), E2)
-    np.testing.assert_allclose(b_pipe, b_dev, rtol=1e-6, atol=1e-7)
+    # BIT FOR BIT (round-5 advice): the caller pinned the tile selection (_generic_kernels_only), so a chunk of two poses and the batch
+    # of five sum in the same order — what is left to differ is chunk-boundary indexing, and an error there of any size must show
+    np.testing.assert_array_equal(b_pipe, b_dev)
     b_pipe2 = pipe.estimate(K, rgb, mask, E1, rgb2, mask2, E2)          # other dtypes through the same estimator: staging buffers are rebuilt
-    np.testing.assert_allclose(b_pipe2, b_dev, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(b_pipe2, b_dev)
     o = np.arange(N)[::-1].copy()                                       # the frame that takes the random-subset branch now sits in the LAST chunk
     r = lambda x: np.ascontiguousarray(x[o])                            # noqa: E731
-    np.testing.assert_allclose(pipe.estimate(r(K), r(rgb), r(mask), r(E1), r(rgb2), r(mask2), r(E2)),
-                               dev.estimate(r(K), r(rgb), r(mask), r(E1), r(rgb2), r(mask2), r(E2)), rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(pipe.estimate(r(K), r(rgb), r(mask), r(E1), r(rgb2), r(mask2), r(E2)),
+                                  dev.estimate(r(K), r(rgb), r(mask), r(E1), r(rgb2), r(mask2), r(E2)))
     u1, u2 = (np.clip(np.rint(x * 255.0), 0, 255).astype(np.uint8) for x in (rgb, rgb2))
     b_u8_host = host.estimate(K, u1, mask, E1, u2, mask2, E2)
     b_u8_dev = dev.estimate(K, u1, mask.astype(np.float32), E1, u2, mask2.astype(np.float32), E2)

@@ -145,6 +145,29 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     assert len(line["ppo"]["per_rank"]["collection_s"]) == 2 and line["ppo"]["env_steps_per_sec_all_ranks"] > 0
 
 
+def test_bench_plain_launch_spawns_its_ranks_on_one_device():
+    """`python bench.py --gpus 2` with NO launcher in front (the shape of the driver's N = 1 command): bench.py starts
+    `torch.distributed.run --nproc-per-node 2 bench.py <same args>` as a child process before it touches the GPU, relays rank 0's JSON
+    line and returns the child's exit code (round-5 verdict item 6).  Rehearsed on this box's one GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", RGBM_BENCH_ONE_DEVICE="1", RGBM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16", "--no-modes", "--ppo-envs", "0", "--no-prepare", "--no-mixed"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                             # ONE JSON line: rank 0's, relayed
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    # and the exit code is the child's: an argument the ranks refuse must fail the parent too
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, RGBM_HIP_LIB="/nonexistent/librgbm_hip.so"), cwd=root)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_single_process_line_has_every_leg():
     """`python bench.py` as the driver runs it at N = 1, shrunk (batch 16, 1 step): every leg of the line must come back — a crash in
     one of them at round end would lose the whole bench record.  Checks the keys the round-3 verdict asked for (dense / worst-case /

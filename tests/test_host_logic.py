@@ -216,3 +216,37 @@ def test_postprocess_squared_nocs_threshold_is_equivalent():
     s = bits.view(np.float32)
     root = np.sqrt(s.astype(np.float64)).astype(np.float32)
     assert np.array_equal(root > np.float32(0.01), s > nd2)
+
+
+def test_hash_pixel_subset_is_distributed_like_the_reference_shuffle():
+    """`hip_prepare: device` (the default since round 5) keeps the 1024 smallest hash keys of a mask's pixels instead of the pixels
+    `np.random.shuffle` would pick (interface_v5.py:126-130) — another random stream, so seeded runs are not comparable pixel by pixel
+    (INTEGRATION.md).  What has to hold is the DISTRIBUTION: every pixel of the mask is kept with probability 1024 / n, independently of its
+    position, and in index order.  Checked over 600 frames against the exact binomial moments and against the reference's shuffle itself."""
+    import numpy as np
+    from oracle import postproc_ref
+    n, P, F = 3000, 1024, 600
+    choose = np.sort(np.random.default_rng(0).permutation(224 * 224)[:n]).astype(np.int64)
+    pos = {int(p): i for i, p in enumerate(choose)}
+    cnt_hash = np.zeros(n)
+    for f in range(F):
+        sub = postproc_ref.choose_subset_hash(choose, P, 0, f)
+        assert len(sub) == P and np.all(np.diff(sub) > 0) and np.isin(sub, choose).all()      # an ordered subset, no repeats
+        cnt_hash[[pos[int(p)] for p in sub]] += 1
+    rng = np.random.RandomState(0)
+    cnt_ref = np.zeros(n)
+    for f in range(F):
+        c_mask = np.zeros(n, dtype=int)
+        c_mask[:P] = 1
+        rng.shuffle(c_mask)                                                                   # the reference's draw
+        cnt_ref += c_mask
+    p = P / n
+    mean, var = F * p, F * p * (1 - p)
+    for cnt in (cnt_hash, cnt_ref):
+        assert abs(cnt.mean() - mean) < 1e-9                                                  # exactly P kept per frame
+        # per-pixel counts: binomial spread (sampling without replacement barely changes it), no pixel favoured or starved
+        assert 0.85 * var < cnt.var() < 1.15 * var
+        assert np.abs(cnt - mean).max() < 5.5 * np.sqrt(var)
+    # no dependence on position inside the mask: the first and the second half of the index-ordered pixels are kept equally often
+    for cnt in (cnt_hash, cnt_ref):
+        assert abs(cnt[: n // 2].mean() - cnt[n // 2:].mean()) < 4 * np.sqrt(var / (n // 2)) * np.sqrt(2)
