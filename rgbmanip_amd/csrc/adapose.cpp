@@ -171,6 +171,13 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
       std::vector<float> bpad(coutp, 0.f);
       for (int o = 0; o < cout[i]; ++o) bpad[o] = shift[o];
       if (upload_f32(bpad.data(), bpad.size(), &t3d[i].bias)) return -2;
+      if (i == 9 && dtype != F32) {
+        // conv11 for the sparse tail (prob_sparse2_kernel): one operand per in-plane tap, both depth parities on the 16 MFMA rows
+        std::vector<float> pt;
+        prob_sparse_pack(w->data, scale.data(), pt);
+        if (dtype == BF16X3) { if (conv0_sweep_x3_upload(pt, &w11_taps)) return -2; }
+        else if (upload_packed(pt, dtype, &w11_taps)) return -2;
+      }
       if (i == 9 && dtype == BF16X3) {
         // conv11 for the sparse tail (prob_sparse.hip): its step structure is the 16-bit kernels' (two taps x 16 channels per
         // MFMA), so the weights are packed in that geometry and split into hi / lo operand arrays
@@ -255,6 +262,8 @@ void AdaPose::destroy() {
   sweep_w_f16 = nullptr;
   if (w11_x3) (void)hipFree(w11_x3);
   w11_x3 = nullptr;
+  if (w11_taps) (void)hipFree(w11_taps);
+  w11_taps = nullptr;
   if (wprob) (void)hipFree(wprob);
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
@@ -519,7 +528,7 @@ int AdaPose::cost_volume(const Buffers& bf, int V, int B, const float* depths, h
     if (cost_impl == 3 && (b16 || (dtype == BF16X3 && w11_x3)) && sparse_tail) {
       // conv11 + skip + prob conv + softmax + depth only on the 3x3 neighbourhoods of the chosen pixels (prob_sparse.hip)
       if (int rc = launch_prob_sparse(bf.u9, bf.c[0], dtype == BF16X3 ? w11_x3 : t3d[9].w, t3d[9].bias, wprob, bf.choose, depths, bf.prob,
-                                      bf.depth, v0, Vc, B, P, D, S, S, dtype, s)) return rc;
+                                      bf.depth, v0, Vc, B, P, D, S, S, dtype, s, w11_taps)) return rc;
       continue;
     }
     if (int rc = tile(9, bf.u9, bf.u11, bf.c[0], Vc, D / 2, S / 2, S / 2, D, S, S, true, v0)) return rc;

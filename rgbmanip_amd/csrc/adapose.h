@@ -59,6 +59,7 @@ struct AdaPose {
                                 // view1_nocs / view1_depth / view1_r and drops the rest — at ~3/4 of the time; the backbone still runs on both views
   int sparse_tail = 1;          // cost_impl 3: evaluate conv11 + prob only where prob is gathered (0 = dense conv11, for A/B and tests)
   int sweep_f16 = 1;            // bf16 nets: `final` writes the feature map as f16 and the plane sweep blends it with packed f16 FMAs (conv0_sweep.hip; 0 = bf16 feature map, fp32 blend)
+  void* w11_taps = nullptr;     // conv11 for the sparse tail's round-6 kernel: prob_sparse_pack's nine in-plane-tap operands (bf16x3: hi operands, then lo)
   void* sweep_w_f16 = nullptr;  // bf16 nets: the same conv0 weights as f16 (sweep_f16)
   void* sweep_w = nullptr;      // conv0 weights in conv0_sweep.hip fragment order (16-bit nets; bf16x3 nets: hi + lo operand arrays of conv0_sweep_x3.hip)
   int cost_impl = 3;            // 0 generic igemm + materialised volume, 1 tiled + materialised volume, 2 tiled + fused warp,

@@ -808,7 +808,11 @@ constexpr int SWP_LAG = SWP_PRE ? 2 : 1;
 constexpr int SWP_NSLOT = 4;                       // 80.6 KB: also keeps a second workgroup off the CU (one workgroup per CU by construction)
 constexpr int SWP_LDS = SWP_NSLOT * SW_SLOT;
 
-template <typename TO>
+// MIX (fp16 nets, round 6): the blend accumulates in fp32 with v_fma_mix_f32 on fp32 corner weights and converts once per dword (the
+// arithmetic of blend_chunk_f16<false>: c0 within 1e-4 of the halo-tile conv0, where the packed form measures 4.7e-4 and clamps every
+// partial sum) - 10 fp32-class instructions per dword instead of 4 packed ones; the persistent walk, the quad gathers and the consumers
+// are the same.
+template <typename TO, bool MIX>
 __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(const SweepDesc d) {
   typedef f16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
@@ -877,8 +881,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
       sw_corner_weights(P.rx, P.ry, P.rz, P.t0, P.t1, P.t2, __int_as_float(__builtin_amdgcn_readlane(P.dbits, z)), sx, sy, W, H, P.inb != 0, w, off);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
-        wp[q] = __builtin_bit_cast(unsigned, h);
+        if constexpr (MIX) wp[q] = __float_as_uint(w[q]);      // fp32 weights for the v_fma_mix blend
+        else {
+          const Sw16<f16_t>::h2 h = {(f16_t)w[q], (f16_t)w[q]};
+          wp[q] = __builtin_bit_cast(unsigned, h);
+        }
       }
     };
     u32x4 g[4][4];                                       // [round][corner]
@@ -902,6 +909,24 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
       const unsigned rr[4] = {r.x, r.y, r.z, r.w}, aa[4] = {a[0], a[1], a[2], a[3]}, bb4[4] = {b[0], b[1], b[2], b[3]};
       const unsigned cc[4] = {c[0], c[1], c[2], c[3]}, ee[4] = {e[0], e[1], e[2], e[3]};
       unsigned o[4];
+      if constexpr (MIX) {
+        // the sum of blend_chunk_f16<false>, same order: ((a w0 + b w1) + c w2) + e w3, then + ref; MODE.FP16_OVFL saturates the conversion
+#define SWP_MIX(HI, D, H, W, C) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(D) : "v"(H), "v"(W), "v"(C))
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float lo, hi;
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(aa[q]), "v"(w[0]));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(aa[q]), "v"(w[0]));
+          SWP_MIX(0, lo, bb4[q], w[1], lo); SWP_MIX(1, hi, bb4[q], w[1], hi);
+          SWP_MIX(0, lo, cc[q], w[2], lo); SWP_MIX(1, hi, cc[q], w[2], hi);
+          SWP_MIX(0, lo, ee[q], w[3], lo); SWP_MIX(1, hi, ee[q], w[3], hi);
+          asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(rr[q]), "v"(lo));
+          asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(rr[q]), "v"(hi));
+          const Sw16<f16_t>::h2 h = {(f16_t)lo, (f16_t)hi};
+          o[q] = __builtin_bit_cast(unsigned, h);
+        }
+#undef SWP_MIX
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         unsigned t;
@@ -910,6 +935,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
         asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(cc[q]), "v"(w[2]));
         asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(t) : "v"(ee[q]), "v"(w[3]));
         o[q] = t;
+      }
       }
       return make_uint4(o[0], o[1], o[2], o[3]);
     };
@@ -1149,9 +1175,11 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   // without packed fp32 instructions the three bf16 modes are level - 44.11 / 44.15 / 44.09 ms per forward - and the dot2 form rounds the
   // bilinear weights to 8 bits); debug flag 4194304 = v_perm + v_dot2_f32_bf16 (the round-4 default), 2097152 = fp32 FMAs from inline asm.
   const bool f21 = (g_debug_flags & (1 << 21)) != 0, f22 = (g_debug_flags & (1 << 22)) != 0;
-  if (dtype == BF16 && t.feat_f16 && !(g_debug_flags & (1 << 28))) {
-    // the persistent form (debug flag 268435456 = one workgroup per tile, for A/B)
-    auto kern = conv0_sweep_persistent_kernel<u16>;
+  if (((dtype == BF16 && t.feat_f16) || dtype == F16) && !(g_debug_flags & (1 << 28))) {
+    // the persistent form (debug flag 268435456 = one workgroup per tile, for A/B); fp16 nets (round 6): with their fp32-accumulating blend,
+    // debug flag 2097152 = the packed blend for them too
+    auto kern = dtype == BF16 ? conv0_sweep_persistent_kernel<u16, false> : f21 ? conv0_sweep_persistent_kernel<f16_t, false>
+                                                                                : conv0_sweep_persistent_kernel<f16_t, true>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), SWP_LDS)) return rc;
     int n_cu = 0;
     if (int rc = persistent_grid_cus(&n_cu)) return rc;

@@ -4,7 +4,12 @@
 //     bilinear blend runs in fp32, and only then each voxel is split into bf16 hi + lo (common.h, bx3_t) — so the volume
 //     the convolution sees carries 16 significand bits (a single-term 16-bit volume alone puts the depth output at 2.4e-4
 //     from the reference, tools/split_emulation.py);
-//   * three products per tap: W_lo*x_hi, W_hi*x_lo, W_hi*x_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulation;
+//   * three products per tap: W_lo*x_hi, W_hi*x_lo, W_hi*x_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulation - since round 6 as FIVE
+//     MFMAs per (in-plane tap, fragment) instead of six: the 16 MFMA rows are 8 output channels x two row groups, and the nine
+//     (depth tap, product) row groups of a voxel pair up as  [W_lo(kd0); W_lo(kd1)] x_hi,  [W_hi(kd0); W_hi(kd1)] x_lo,
+//     [W_hi(kd0); W_hi(kd1)] x_hi  (accumulator Xn, as before)  and  [W_lo(kd2); W_hi(kd2)] x_hi,  [W_hi(kd2); 0] x_lo  (accumulator Y:
+//     rows 0-7 collect the two small products, rows 8-15 the large one; summed in the epilogue) - before, the three kd = 2 products each
+//     filled half an instruction;
 //   * one persistent workgroup per CU walking its tiles (the 121 KB plane ring and the 36 weight operands a consumer lane
 //     keeps in registers allow one resident workgroup anyway): weights are loaded once per launch, the plane ring runs on
 //     across tile boundaries.
@@ -47,7 +52,9 @@ constexpr int X3_RING = X3_NSLOT * X3_SLOT;      // 120960
 constexpr int X3_WLDS = 9 * 64 * 16;             // lo operands of the kd=2 taps, lane-linear per tap (the consumers' register budget)
 constexpr int X3_REC = X3_COOP ? 4 * 2 * 64 * 32 : 0;   // cooperative producers: per wave [plane parity][lane] {4 corner offsets, 4 weights}
 constexpr int X3_LDS = X3_RING + X3_WLDS + X3_REC;
-constexpr int X3_NPW = 4, X3_NCW = 3;            // producer waves (one per SIMD), consumer waves (4 rows of 16 voxels each)
+constexpr int X3_NPW = 4, X3_NCW = 4;            // producer waves and consumer waves, one of each per SIMD (round 6; rounds 2-5: three consumer waves of 4 rows)
+constexpr int X3_CR = X3_TH / X3_NCW;            // rows of 16 voxels (= fragments) per consumer wave: 3
+static_assert(X3_CR == 3, "the consumers' unit schedule below is written for three fragments per wave");
 constexpr int X3_THREADS = (X3_NPW + X3_NCW) * 64;
 constexpr int X3_NCH = 8;                        // 16-byte chunks (4 fp32 channels) per voxel of the feature map
 static_assert(X3_NV <= X3_NPW * 64, "one producer thread per voxel");
@@ -100,7 +107,7 @@ __device__ __forceinline__ void split8(const float* o, uint4& hi, uint4& lo) {
 
 }  // namespace
 
-// one workgroup per CU (<= 256 VGPRs): 7 waves
+// one workgroup per CU (<= 256 VGPRs): 8 waves, a producer and a consumer per SIMD
 __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Sweep3Desc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,10 +126,11 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     n = t; h0 = th * X3_TH; w0 = tw * X3_TW;
   };
 
-  // lo operands of the kd=2 taps -> LDS (read by the consumers every plane): lane-linear rows [tap][lane]
+  // the [W_hi(kd=2); 0] operands of the nine in-plane taps -> LDS (read by the consumers every plane): lane-linear rows [tap][lane].
+  // d.wgt holds conv0_sweep_pack's A2 block as rows 0-7 = 0, rows 8-15 = W(kd=2): MFMA row r < 8 of this operand is its row r + 8.
   for (int i = tid; i < 9 * 64; i += X3_THREADS) {
-    const int s9 = i >> 6, ln = i & 63;
-    reinterpret_cast<uint4*>(planes + X3_RING)[i] = d.wgt[((27 + s9) * 16 + (ln & 15)) * 4 + (ln >> 4)];
+    const int s9 = i >> 6, ln = i & 63, row = ln & 15;
+    reinterpret_cast<uint4*>(planes + X3_RING)[i] = row < 8 ? d.wgt[((9 + s9) * 16 + row + 8) * 4 + (ln >> 4)] : make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
 
@@ -434,15 +442,17 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
 #undef X3_WAIT
 #endif
   } else {
-    // ------------------------------------------------------------------ consumers: 4 rows x 16 voxels per wave
+    // ------------------------------------------------------------------ consumers: 3 rows x 16 voxels per wave
     const int cw = wave - X3_NPW;
     const int lr = lane & 15, lg = lane >> 4;
-    // weights of all 9 in-plane taps, hi and lo: rows 0-7 of A01 = W(kd=0), rows 8-15 = W(kd=1); rows 8-15 of A2 = W(kd=2)
-    // (the paired-tap scheme of conv0_sweep.hip).  108 registers, loaded once per launch; the fourth set (lo operands of the
-    // kd=2 taps) sits in LDS, one lane-linear 1 KB row per tap — with it in registers too the kernel spilled at the 256 cap
-    // (7 waves on 4 SIMDs: two waves share a SIMD's 512 registers), and a spill reload in a consumer waits on vmcnt, i.e. on
-    // its output stores.
-    u4v A01h[9], A01l[9], A2h[9];
+    // Weights of all 9 in-plane taps (conv0_sweep_pack's paired-tap scheme, d.wgt = [hi: A01[9], A2[9]][lo: A01[9], A2[9]] with
+    // A01 rows 0-7 = W(kd=0), rows 8-15 = W(kd=1) and A2 rows 0-7 = 0, rows 8-15 = W(kd=2)):
+    //   A01h, A01l : hi / lo of [W(kd0); W(kd1)]
+    //   A2x        : rows 0-7 = lo of W(kd2), rows 8-15 = hi of W(kd2)     (regrouped from the A2 blocks at load time)
+    //   AL (LDS)   : rows 0-7 = hi of W(kd2), rows 8-15 = 0                (one lane-linear 1 KB row per tap, see above)
+    // 108 registers, loaded once per launch; with the fourth set in registers too the kernel spilled at the 256 cap (8 waves on 4 SIMDs:
+    // two waves share a SIMD's 512 registers), and a spill reload in a consumer waits on vmcnt, i.e. on its output stores.
+    u4v A01h[9], A01l[9], A2x[9];
     // Operand registers of the plane loop.  The first version of this loop was plain C++ (ds_read into `uint4` temporaries,
     // MFMA builtins, hipcc's own waits): about one (workgroup, consumer wave, input plane) in a thousand came out wrong,
     // differently from run to run, always as ONE consumer wave's rows of three consecutive output planes — the signature of
@@ -456,82 +466,85 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     // (tools/micro/mfma_lds_war.hip: B-operand reload, accumulator-input reload, dependent chains, with and without a
     // VALU / ds_write stress wave on the same SIMD) shows NO corruption, so the mechanism is not isolated; what is established
     // is the cure: nothing is left to the register allocator or the scheduler here.  Accumulators are updated in place by
-    // inline-asm MFMAs and never serve as load destinations, operands rotate through three fixed register sets (a set is
-    // reloaded only after a whole further step of 12 MFMAs has been issued behind its last reader), LDS reads and their counted
+    // inline-asm MFMAs and never serve as load destinations, operands rotate through SIX fixed register sets (a set is
+    // reloaded only after three further units = 15 MFMAs have been issued behind its last reader), LDS reads and their counted
     // waits are placed by hand.  Bit-stable over repeated runs at every size tried
     // (test_conv0_sweep_bf16x3_matches_volume_then_conv, tools/debug_sweep_x3.py).
-    u4v B[3][4];                       // [set][frag0 hi, frag0 lo, frag1 hi, frag1 lo]
-    u4v AL[3];                         // lo weight operand of the kd=2 taps (from LDS), one per tap in flight
+    u4v B[6][2];                       // [set][hi, lo] of one (tap, fragment) unit
+    u4v AL[3];                         // the [W_hi(kd2); 0] operand (from LDS), one per tap in flight
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      AL[i] = u4v{0u, 0u, 0u, 0u};
+    for (int i = 0; i < 3; ++i) AL[i] = u4v{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) B[i][q] = u4v{0u, 0u, 0u, 0u};
-    }
+    for (int i = 0; i < 6; ++i) B[i][0] = B[i][1] = u4v{0u, 0u, 0u, 0u};
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
-    const unsigned wa = lds_base + X3_RING + lane * 16;      // this lane's lo-weight operand of tap 0
+    const unsigned wa = lds_base + X3_RING + lane * 16;      // this lane's LDS-resident operand of tap 0
 #define X3_BOFF(TP, F) ((((F) + (TP) / 3) * X3_HW + (TP) % 3) * X3_VS)
-#define X3_LDB(SET, TP, F0)                                                                                          \
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8" \
-                 : "+v"(B[SET][0]), "+v"(B[SET][1]), "+v"(B[SET][2]), "+v"(B[SET][3])                                 \
-                 : "v"(sa), "n"(X3_BOFF(TP, F0)), "n"(X3_BOFF(TP, F0) + 64), "n"(X3_BOFF(TP, F0 + 1)), "n"(X3_BOFF(TP, F0 + 1) + 64) : "memory");
-#define X3_LDW(SET, TP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(AL[SET]) : "v"(wa), "n"((TP) * 1024) : "memory");
+    // unit U = 3 * tap + fragment: its hi / lo operand pair into set U % 6
+#define X3_LDB(U)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                    \
+                 : "+v"(B[(U) % 6][0]), "+v"(B[(U) % 6][1])                                                           \
+                 : "v"(sa), "n"(X3_BOFF((U) / 3, (U) % 3)), "n"(X3_BOFF((U) / 3, (U) % 3) + 64) : "memory");
+#define X3_LDW(TP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(AL[(TP) % 3]) : "v"(wa), "n"((TP) * 1024) : "memory");
 #define X3_MFMA(ACC, A, BB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(BB))
-#ifdef X3_SINGLE      // timing experiment only: the hi x hi products alone (a third of the matrix work, wrong results)
-#define X3_MMA12(I)                                                                                                  \
-    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][0]);                \
-    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][2]);
-#else
-#define X3_MMA12(I)                                                                                                  \
-    X3_MFMA(Xn[2 * ((I) % 2)], A01l[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], AL[((I) / 2) % 3], B[(I) % 3][0]);           \
-    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01l[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], AL[((I) / 2) % 3], B[(I) % 3][2]);   \
-    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][1]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][1]);                \
-    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][3]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][3]);        \
-    X3_MFMA(Xn[2 * ((I) % 2)], A01h[(I) / 2], B[(I) % 3][0]); X3_MFMA(Xp[2 * ((I) % 2)], A2h[(I) / 2], B[(I) % 3][0]);                \
-    X3_MFMA(Xn[2 * ((I) % 2) + 1], A01h[(I) / 2], B[(I) % 3][2]); X3_MFMA(Xp[2 * ((I) % 2) + 1], A2h[(I) / 2], B[(I) % 3][2]);
-#endif
+    // the five MFMAs of a unit: small products first (as in rounds 2-5), the two accumulators alternating
+#define X3_MMA5(U)                                                                                                   \
+    X3_MFMA(Xn[(U) % 3], A01l[(U) / 3], B[(U) % 6][0]);                                                              \
+    X3_MFMA(Y[(U) % 3], A2x[(U) / 3], B[(U) % 6][0]);                                                                \
+    X3_MFMA(Xn[(U) % 3], A01h[(U) / 3], B[(U) % 6][1]);                                                              \
+    X3_MFMA(Y[(U) % 3], AL[((U) / 3) % 3], B[(U) % 6][1]);                                                           \
+    X3_MFMA(Xn[(U) % 3], A01h[(U) / 3], B[(U) % 6][0]);
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      A01h[s] = ld_u4v(d.wgt + (s * 16 + lr) * 4 + lg);
-      A2h[s] = ld_u4v(d.wgt + ((9 + s) * 16 + lr) * 4 + lg);
-      A01l[s] = ld_u4v(d.wgt + ((18 + s) * 16 + lr) * 4 + lg);
+    for (int s9 = 0; s9 < 9; ++s9) {
+      A01h[s9] = ld_u4v(d.wgt + (s9 * 16 + lr) * 4 + lg);
+      A01l[s9] = ld_u4v(d.wgt + ((18 + s9) * 16 + lr) * 4 + lg);
+      // rows 0-7: lo of W(kd2) = row lr + 8 of the lo A2 block; rows 8-15: hi of W(kd2) = row lr of the hi A2 block
+      A2x[s9] = lr < 8 ? ld_u4v(d.wgt + ((27 + s9) * 16 + lr + 8) * 4 + lg) : ld_u4v(d.wgt + ((9 + s9) * 16 + lr) * 4 + lg);
     }
     const int ch = (lg & 1) * 4;       // after the lane-half swap: fragment (lg < 2 ? first : second of the pair), voxel lr, channels ch..ch+3
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = d.bias[ch + r];
-    const int boff = ((cw * 4) * X3_HW + lr) * X3_VS + lg * 16;     // fragment 0, tap (0,0), hi part
+    const int boff = ((cw * X3_CR) * X3_HW + lr) * X3_VS + lg * 16;     // fragment 0, tap (0,0), hi part
     int pg0 = 0;                                                     // ring index of this tile's plane 0
     for (int k = 0; k < n_my; ++k) {
       int n, h0, w0;
       tile_of(k, n, h0, w0);
       const int ow = w0 + lr;
+      // output rows of the two fragment pairs of the epilogue: (0, 1) and (2, 2) — the third fragment pairs with itself, its copy in
+      // the upper lane half is not stored
       int oh[2];
       bool ook[2];
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        oh[pr] = h0 + cw * 4 + pr * 2 + (lg >> 1);
-        ook[pr] = oh[pr] < H && ow < W;
+        const bool self = pr == 1;
+        oh[pr] = h0 + cw * X3_CR + pr * 2 + (self ? 0 : (lg >> 1));
+        ook[pr] = oh[pr] < H && ow < W && !(self && lg >= 2);
       }
-      f32x4 Xp[4], Xn[4], Lp[2];
+      f32x4 Xp[3], Xn[3], Y[3], Lp[2];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) Xp[f] = Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < 3; ++f) Xp[f] = Xn[f] = Y[f] = f32x4{0.f, 0.f, 0.f, 0.f};
       Lp[0] = Lp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      auto emit = [&](int o) {         // out plane o from Xp (= X[o]) and Lp (= rows 0-7 of X[o-1]); leaves Lp = rows 0-7 of X[o]
+      // out plane o = rows 8-15 of Xp (kd=1 taps of plane o) + rows 0-7 of X[o-1] (kd=0 taps of plane o-1, kept in Lp) + the kd=2 taps of
+      // plane o+1, which the plane just multiplied left in Y (rows 8-15: W_hi x_hi, rows 0-7: W_lo x_hi + W_hi x_lo); leaves Lp = rows 0-7 of Xp
+      auto emit = [&](int o) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          f32x4 hi, lo;
+          const int f0 = 2 * pr, f1 = pr == 0 ? 1 : 2;
+          f32x4 hi, lo, yh, yl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[2 * pr][r]), __float_as_uint(Xp[2 * pr + 1][r]), false, false);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Xp[f0][r]), __float_as_uint(Xp[f1][r]), false, false);
             lo[r] = __uint_as_float(sw[0]);
             hi[r] = __uint_as_float(sw[1]);
+            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(Y[f0][r]), __float_as_uint(Y[f1][r]), false, false);
+            yl[r] = __uint_as_float(sy[0]);
+            yh[r] = __uint_as_float(sy[1]);
           }
-          if (o >= 0 && ook[pr] && !(X3_DBG & 4)) {
+          if (o >= 0 && ook[pr]) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              v[r] = (hi[r] + Lp[pr][r]) + bias[r];
+              v[r] = ((hi[r] + Lp[pr][r]) + (yh[r] + yl[r])) + bias[r];
               if (d.relu) v[r] = v[r] < 0.f ? 0.f : v[r];            // NaN propagates, like torch.relu
             }
             store4(d.out + ((((long long)n * D + o) * H + oh[pr]) * W + ow) * 8 + ch, v);
@@ -544,36 +557,38 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
           const int p = z - 1;
           const unsigned sa = lds_base + (unsigned)(((pg0 + p) % X3_NSLOT) * X3_SLOT + boff);      // LDS address of (fragment 0, tap (0,0), hi)
 #pragma unroll
-          for (int f = 0; f < 4; ++f) Xn[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-          // 18 steps per plane: step i = in-plane tap i/2, fragments 2*(i%2), 2*(i%2)+1: 4 operand reads (5 with the tap's lo
-          // weights) and 12 MFMAs (W_lo*x_hi, W_hi*x_lo, W_hi*x_hi for the two depth-tap pairs; 4 independent accumulators
-          // between two MFMAs on the same one).  The reads of step i + 2 are issued behind the MFMAs of step i into the
-          // register set that step i - 1 multiplied from (see X3_LDB above for why the distance matters).  Counted waits: at
-          // step i the reads of steps i and i + 1 are outstanding, LDS operations complete in order, so step i's have landed
-          // once at most n(i + 1) remain: 4 behind an even step, 5 behind an odd one (the tap's lo weights ride with it).
-          X3_LDW(0, 0) X3_LDB(0, 0, 0) X3_LDB(1, 0, 2)
-#define X3_STEP(I, NEXT, WAITN)                                                                                      \
+          for (int f = 0; f < 3; ++f) Xn[f] = Y[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+          // (the zeroing happens HERE, not as v_mov instructions the compiler drops between the inline-asm MFMAs that name these
+          // registers as accumulator inputs: it cannot see that those statements are MFMAs and owes them no wait states)
+          asm volatile("s_nop 1" : "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]));
+          // 27 units per plane, unit u = (in-plane tap u / 3, fragment u % 3): two operand reads (three with the tap's LDS-resident
+          // weights, which ride with the tap's first unit) and five MFMAs.  The reads of unit u + 3 are issued behind the MFMAs of
+          // unit u, into the register set unit u - 3 multiplied from.  Counted waits: at unit u the reads of units u .. u + 2 are
+          // outstanding, LDS operations complete in order, so unit u's have landed once at most those of u + 1 and u + 2 remain:
+          // 4, or 5 when one of them opens a tap.
+          X3_LDW(0) X3_LDB(0) X3_LDB(1) X3_LDB(2)
+#define X3_UNIT(U, NEXT, WAITN)                                                                                      \
           asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" ::: "memory");                                                \
-          X3_MMA12(I)                                                                                                \
+          X3_MMA5(U)                                                                                                 \
           NEXT
-          X3_STEP(0, X3_LDW(1, 1) X3_LDB(2, 1, 0), 4)   X3_STEP(1, X3_LDB(0, 1, 2), 5)
-          X3_STEP(2, X3_LDW(2, 2) X3_LDB(1, 2, 0), 4)   X3_STEP(3, X3_LDB(2, 2, 2), 5)
-          X3_STEP(4, X3_LDW(0, 3) X3_LDB(0, 3, 0), 4)   X3_STEP(5, X3_LDB(1, 3, 2), 5)
-          X3_STEP(6, X3_LDW(1, 4) X3_LDB(2, 4, 0), 4)   X3_STEP(7, X3_LDB(0, 4, 2), 5)
-          X3_STEP(8, X3_LDW(2, 5) X3_LDB(1, 5, 0), 4)   X3_STEP(9, X3_LDB(2, 5, 2), 5)
-          X3_STEP(10, X3_LDW(0, 6) X3_LDB(0, 6, 0), 4)  X3_STEP(11, X3_LDB(1, 6, 2), 5)
-          X3_STEP(12, X3_LDW(1, 7) X3_LDB(2, 7, 0), 4)  X3_STEP(13, X3_LDB(0, 7, 2), 5)
-          X3_STEP(14, X3_LDW(2, 8) X3_LDB(1, 8, 0), 4)  X3_STEP(15, X3_LDB(2, 8, 2), 5)
-          X3_STEP(16, , 4)                              X3_STEP(17, , 0)
-#undef X3_STEP
+          X3_UNIT(0, X3_LDW(1) X3_LDB(3), 4)    X3_UNIT(1, X3_LDB(4), 5)    X3_UNIT(2, X3_LDB(5), 5)
+          X3_UNIT(3, X3_LDW(2) X3_LDB(6), 4)    X3_UNIT(4, X3_LDB(7), 5)    X3_UNIT(5, X3_LDB(8), 5)
+          X3_UNIT(6, X3_LDW(3) X3_LDB(9), 4)    X3_UNIT(7, X3_LDB(10), 5)   X3_UNIT(8, X3_LDB(11), 5)
+          X3_UNIT(9, X3_LDW(4) X3_LDB(12), 4)   X3_UNIT(10, X3_LDB(13), 5)  X3_UNIT(11, X3_LDB(14), 5)
+          X3_UNIT(12, X3_LDW(5) X3_LDB(15), 4)  X3_UNIT(13, X3_LDB(16), 5)  X3_UNIT(14, X3_LDB(17), 5)
+          X3_UNIT(15, X3_LDW(6) X3_LDB(18), 4)  X3_UNIT(16, X3_LDB(19), 5)  X3_UNIT(17, X3_LDB(20), 5)
+          X3_UNIT(18, X3_LDW(7) X3_LDB(21), 4)  X3_UNIT(19, X3_LDB(22), 5)  X3_UNIT(20, X3_LDB(23), 5)
+          X3_UNIT(21, X3_LDW(8) X3_LDB(24), 4)  X3_UNIT(22, X3_LDB(25), 5)  X3_UNIT(23, X3_LDB(26), 5)
+          X3_UNIT(24, , 4)                      X3_UNIT(25, , 2)            X3_UNIT(26, , 0)
+#undef X3_UNIT
           // the accumulators were written by inline-asm MFMAs, which the compiler's hazard recogniser does not see: the last
-          // of them must have retired before VALU code (emit, the Xp <- Xn copies) reads its result (8-pass MFMA: 11+ wait states)
+          // of them must have retired before VALU code (emit, the Xp <- Xn copies) reads its result (11+ wait states)
           // — and every later read is made to depend on this statement (operands tied): without that the compiler may place
           // emit's first VALU reads in front of the wait states, the asm having no visible connection to the accumulators
-          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Xn[3]) :: "memory");
+          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]) :: "memory");
           emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
-          for (int f = 0; f < 4; ++f) Xp[f] = Xn[f];
+          for (int f = 0; f < 3; ++f) Xp[f] = Xn[f];
           // ... and the copies must be done before the next plane's MFMAs overwrite Xn (VALU reads its operands at issue)
         }
         // LDS reads pinned to their side of the barrier in both directions (see conv0_sweep.hip)
@@ -581,7 +596,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
+      // plane D is zero padding: X[D-1] only lacks the (zero) kd=2 contribution
+#pragma unroll
+      for (int f = 0; f < 3; ++f) Y[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      emit(D - 1);
       pg0 += D;
     }
   }

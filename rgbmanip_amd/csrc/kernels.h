@@ -106,7 +106,9 @@ int launch_bx3_to_f32(const void* in, float* out, long long n, hipStream_t s);  
 // prob_sparse.hip — conv11 + skip + prob conv + softmax + depth on the neighbourhoods of the chosen pixels (bf16)
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
-                       int D, int H, int W, int dtype, hipStream_t s);
+                       int D, int H, int W, int dtype, hipStream_t s, const void* w11_taps = nullptr);
+// conv11 weights [16][8][27] (x BN scale) -> the nine in-plane-tap A operands of prob_sparse2_kernel, fp32 [9][16][4][8] (prob_sparse.hip)
+void prob_sparse_pack(const float* w, const float* scale, std::vector<float>& packed);
 
 // prepare.hip — batched device-side AdaPoseEstimator_v5.prepare_model_input
 int launch_prepare_inputs(const float* rgb, const unsigned char* mask, const double* K, const int* frame_map, int N, int H, int W, int S, int P,

@@ -26,6 +26,8 @@
 
 namespace rgbm {
 
+extern int g_debug_flags;
+
 namespace {
 
 constexpr int PS_DMAX = 24;
@@ -207,6 +209,250 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Round 6: the point kernel restructured (the default; debug flag 536870912 = the kernel above, for A/B).
+//
+// The round-3..5 kernel spends ~3500 instructions per point (waiting 0.74 with eight waves per SIMD) on per-lane index arithmetic: every
+// one of its sixteen MFMA fragments recomputes voxel coordinates, bounds and gather offsets per lane, two of four lane groups idle in the
+// epilogue, and twelve-voxel fragments fill 12 of 16 columns.  On the benchmark's masks a view's 1024 chosen pixels are 2-3 % of a crop-filling
+// mask (1-2 per 8 x 8 pixel tile), so sharing a tile's halo between its points buys nothing and would read all of c0; what is left is to spend
+// fewer instructions per point:
+//   * the point's u9 neighbourhood (3 x 3 input columns x D/2 depths x 16 channels) and c0 neighbourhood (3 x 3 x D x 8) are loaded ONCE
+//     with lane-linear indices (4 + 4 sixteen-byte loads per lane, all in flight together) into a wave-private LDS block; everything after
+//     that reads LDS at compile-time offsets;
+//   * the code is specialised on the parities of (y, x) (four wave-uniform variants): which input rows / columns and which kernel taps an
+//     output column needs is then a compile-time table (ps_nt / ps_rel / ps_k below);
+//   * one MFMA covers BOTH depth parities of an output column: K = 32 = [u9(iz) 16 channels | u9(iz + 1) 16 channels], rows 0-7 = the
+//     even output depths 2 iz (tap kd = 1 on u9(iz)), rows 8-15 = the odd ones 2 iz + 1 (kd = 2 on u9(iz), kd = 0 on u9(iz + 1)); one
+//     MFMA per in-plane tap, 16-25 per point, all four lane groups carry output voxels in the epilogue;
+//   * the prob conv's channel dot products stay in registers (three running sums per lane over the nine columns), 72 floats go through
+//     LDS once for the depth shift.
+// Same arithmetic per voxel (fp32 accumulation, fp32 u11, fp32 dot products); the summation ORDER of taps and columns differs from the
+// kernel above, so the two agree to fp32 rounding, not bit for bit (tests/test_gpu_kernels.py::test_prob_sparse_kernels_agree).
+namespace {
+
+template <typename T> struct Ps2 {
+  static constexpr bool X3 = std::is_same<T, bx3_t>::value;
+  static constexpr int EB = X3 ? 4 : 2;                      // bytes per element
+  static constexpr int VB = 16 * EB, CB = 8 * EB;            // bytes of a u9 voxel (16 channels) / a c0 voxel (8 channels)
+  static constexpr int UCH = VB / 16, CCH = CB / 16;         // 16-byte chunks per voxel
+  static constexpr int USLOT = PS_DMAX / 2 + 1;              // depth slots per u9 column: D/2 inputs + one zero slot behind them
+  static constexpr int U_BYTES = 9 * USLOT * VB, C_BYTES = 9 * PS_DMAX * CB, S_BYTES = 3 * PS_DMAX * 4;
+  static constexpr int WAVE_BYTES = U_BYTES + C_BYTES + S_BYTES;
+  static constexpr int NU = 9 * (PS_DMAX / 2) * UCH, NC = 9 * PS_DMAX * CCH;      // lane-loads of the two neighbourhoods
+  static constexpr int RU = (NU + 63) / 64, RC = (NC + 63) / 64;
+};
+constexpr int PS2_WP_BYTES = 27 * 8 * 4;
+static_assert(PS2_WP_BYTES % 16 == 0 && Ps2<unsigned short>::WAVE_BYTES % 16 == 0 && Ps2<bx3_t>::WAVE_BYTES % 16 == 0, "16-byte aligned LDS blocks");
+
+// ConvTranspose3d k3 s2 p1 op1 along one axis, for the three output coordinates c - 1 + r (r = 0..2) around a point at c = 2 h + par, with the
+// staged inputs starting at hb = (c - 1) >> 1 = h - 1 + par: output 2 h + m (m = par - 1 + r) reads input h + m / 2 with kernel index 1 if m is
+// even, inputs h + (m - 1) / 2 (index 2) and h + (m + 1) / 2 (index 0) if m is odd.
+constexpr int ps_nt(int par, int r) { return ((par + r + 1) & 1) ? 2 : 1; }
+constexpr int ps_rel(int par, int r, int j) { const int m = par - 1 + r; return ((m & 1) ? (m - 1) / 2 + j : m / 2) + 1 - par; }
+constexpr int ps_k(int par, int r, int j) { const int m = par - 1 + r; return (m & 1) ? (j == 0 ? 2 : 0) : 1; }
+static_assert(ps_rel(0, 0, 0) == 0 && ps_rel(0, 0, 1) == 1 && ps_rel(0, 1, 0) == 1 && ps_rel(0, 2, 0) == 1 && ps_rel(0, 2, 1) == 2, "even coordinate");
+static_assert(ps_rel(1, 0, 0) == 0 && ps_rel(1, 1, 0) == 0 && ps_rel(1, 1, 1) == 1 && ps_rel(1, 2, 0) == 1, "odd coordinate");
+static_assert(ps_nt(0, 0) == 2 && ps_nt(0, 1) == 1 && ps_nt(0, 2) == 2 && ps_nt(1, 0) == 1 && ps_nt(1, 1) == 2 && ps_nt(1, 2) == 1, "taps per output");
+
+__device__ __forceinline__ float ps_xor16(float v) {      // the value of lane ^ 16 (ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10)
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f));
+}
+
+template <typename T, int PY, int PX>
+__device__ __forceinline__ void ps2_columns(const unsigned char* U, const unsigned char* Cn, const float* wp, const uint4* wq, unsigned colmask,
+                                            int lr, int lg, unsigned bo, unsigned co, const float (&b11)[4], float (&S)[3]) {
+  using P = Ps2<T>;
+  // the nine in-plane taps' A operands (split pairs: hi, then lo): rows = MFMA row lr, K group lg
+  uint4 Ah[9], Al[P::X3 ? 9 : 1];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    Ah[t] = wq[(t * 16 + lr) * 4 + lg];
+    if constexpr (P::X3) Al[t] = wq[9 * 16 * 4 + (t * 16 + lr) * 4 + lg];
+  }
+  const int ch = (lg & 1) * 4;
+  auto column = [&](auto rc, auto cc) {
+    constexpr int R = decltype(rc)::value, Cc = decltype(cc)::value, col = R * 3 + Cc;
+    if (!((colmask >> col) & 1u)) return;                        // outside the image (wave-uniform): the prob conv's zero padding
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jr = 0; jr < ps_nt(PY, R); ++jr)
+#pragma unroll
+      for (int jc = 0; jc < ps_nt(PX, Cc); ++jc) {
+        const int ucol = ps_rel(PY, R, jr) * 3 + ps_rel(PX, Cc, jc), t9 = ps_k(PY, R, jr) * 3 + ps_k(PX, Cc, jc);
+        const unsigned char* bp = U + ucol * (P::USLOT * P::VB) + bo;
+        if constexpr (P::X3) {
+          uint4 bh, bl;
+          bx3_pair(*reinterpret_cast<const uint4*>(bp), *reinterpret_cast<const uint4*>(bp + 16), bh, bl);
+          acc = mma16<unsigned short>(Al[t9], bh, acc);
+          acc = mma16<unsigned short>(Ah[t9], bl, acc);
+          acc = mma16<unsigned short>(Ah[t9], bh, acc);
+        } else {
+          acc = mma16<T>(Ah[t9], *reinterpret_cast<const uint4*>(bp), acc);
+        }
+      }
+    // u11 channels ch .. ch + 3 of this lane's voxel (depth 2 lr + (lg >> 1) of the column) -> their share of the three channel dot
+    // products; the other four channels sit 16 lanes away
+    float cv[4];
+    load4(reinterpret_cast<const T*>(Cn + col * (PS_DMAX * P::CB) + co), cv);
+    const float* wl = wp + col * 8 + ch;
+    float q[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[e] + b11[e];
+      t = t < 0.f ? 0.f : t;                                     // NaN propagates, like torch.relu
+      const float u = cv[e] + t;                                 // the skip add is post-ReLU (network_v5.py:289)
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) q[kd] = fmaf(u, wl[kd * 72 + e], q[kd]);
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) S[kd] += q[kd] + ps_xor16(q[kd]);      // (a + b is the same number in both lanes of the pair)
+  };
+  column(PC<0>{}, PC<0>{}); column(PC<0>{}, PC<1>{}); column(PC<0>{}, PC<2>{});
+  column(PC<1>{}, PC<0>{}); column(PC<1>{}, PC<1>{}); column(PC<1>{}, PC<2>{});
+  column(PC<2>{}, PC<0>{}); column(PC<2>{}, PC<1>{}); column(PC<2>{}, PC<2>{});
+}
+
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256) void prob_sparse2_kernel(const ProbSparseDesc d) {
+  using P = Ps2<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ps_lds[];
+  float* wp = reinterpret_cast<float*>(ps_lds);                  // [27][8], shared by the four waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int i = tid; i < 27 * 8; i += 256) wp[i] = d.wprob[i];
+  unsigned char* U = ps_lds + PS2_WP_BYTES + wave * P::WAVE_BYTES;      // [9 columns][USLOT depths][16 channels]
+  unsigned char* Cn = U + P::U_BYTES;                                    // [9 columns][PS_DMAX depths][8 channels]
+  float* Sw = reinterpret_cast<float*>(Cn + P::C_BYTES);                 // [3 kd][PS_DMAX]
+  const int D = d.D, H = d.H, W = d.W, Dq = D >> 1, Hq = H >> 1, Wq = W >> 1;
+  // XCD-aware block order (see prob_sparse_kernel)
+  const long long nb = gridDim.x, bq = nb >> 3, br = nb & 7;
+  const long long xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const long long vblk = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bidx;
+  const long long pidx = vblk * 4 + wave;                                // point index within the chunk (wave-uniform)
+  const bool active = pidx < (long long)d.Vc * d.P;
+  const int vl = active ? (int)(pidx / d.P) : 0;
+  const int v = d.v0 + vl;
+  const long long o = (long long)v * d.P + (pidx - (long long)vl * d.P);
+  const int pix = active ? __builtin_amdgcn_readfirstlane(d.choose[o]) : 0;
+  const int y = pix / W, x = pix - y * W;
+  const int hb = (y - 1) >> 1, wb = (x - 1) >> 1;                        // first staged input row / column (-1 at the border: zeros)
+  const unsigned char* u9v = reinterpret_cast<const unsigned char*>(d.u9) + (long long)vl * Dq * Hq * Wq * P::VB;
+  const unsigned char* c0v = reinterpret_cast<const unsigned char*>(d.c0) + (long long)vl * D * H * W * P::CB;
+
+  // ---- the two neighbourhoods: every load of the point is requested before the first one is used ----
+  uint4 ub[P::RU], cb[P::RC];
+#pragma unroll
+  for (int r = 0; r < P::RU; ++r) {
+    const int i = r * 64 + lane;
+    const int col = i / ((PS_DMAX / 2) * P::UCH), rem = i - col * ((PS_DMAX / 2) * P::UCH);
+    const int iz = rem / P::UCH, chn = rem - iz * P::UCH;
+    const int row = hb + col / 3, cx = wb + col % 3;
+    const bool ok = active && i < P::NU && iz < Dq && (unsigned)row < (unsigned)Hq && (unsigned)cx < (unsigned)Wq;
+    const unsigned off = ok ? (unsigned)(((iz * Hq + row) * Wq + cx) * P::VB + chn * 16) : 0u;      // per-view offsets fit 32 bits (launcher checks)
+    const uint4 t = *reinterpret_cast<const uint4*>(u9v + off);
+    ub[r] = ok ? t : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int r = 0; r < P::RC; ++r) {
+    const int i = r * 64 + lane;
+    const int col = i / (PS_DMAX * P::CCH), rem = i - col * (PS_DMAX * P::CCH);
+    const int oz = rem / P::CCH, chn = rem - oz * P::CCH;
+    const int yy = y - 1 + col / 3, xx = x - 1 + col % 3;
+    const bool ok = active && i < P::NC && oz < D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const unsigned off = ok ? (unsigned)(((oz * H + yy) * W + xx) * P::CB + chn * 16) : 0u;
+    const uint4 t = *reinterpret_cast<const uint4*>(c0v + off);
+    cb[r] = ok ? t : make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (lane < 9 * P::UCH)                                                 // the zero slot behind the last input depth (tap kd = 0 of the last odd output)
+    *reinterpret_cast<uint4*>(U + ((lane / P::UCH) * P::USLOT + Dq) * P::VB + (lane % P::UCH) * 16) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int r = 0; r < P::RU; ++r) {
+    const int i = r * 64 + lane;
+    const int col = i / ((PS_DMAX / 2) * P::UCH), rem = i - col * ((PS_DMAX / 2) * P::UCH);
+    const int iz = rem / P::UCH, chn = rem - iz * P::UCH;
+    if (i < P::NU && iz < Dq) *reinterpret_cast<uint4*>(U + (col * P::USLOT + iz) * P::VB + chn * 16) = ub[r];
+  }
+#pragma unroll
+  for (int r = 0; r < P::RC; ++r) {
+    const int i = r * 64 + lane;
+    if (i < P::NC) *reinterpret_cast<uint4*>(Cn + i * 16) = cb[r];      // [col][oz][chunk] is the lane-linear order
+  }
+  __syncthreads();                                                       // wp (the neighbourhoods are wave-private: LDS runs a wave's accesses in order)
+
+  // ---- conv11 + skip + channel dot products of the nine output columns ----
+  const int lrc = lr < Dq ? lr : 0;                                      // lanes beyond the last input depth repeat voxel 0 (their results are not used)
+  const unsigned bo = (unsigned)((lrc + (lg >> 1)) * P::VB + (lg & 1) * (P::VB / 2));      // B operand: u9(iz = lr + (lg >> 1)), channels 8 (lg & 1) ..
+  const int oz_l = 2 * lrc + (lg >> 1);                                  // this lane's output depth: rows 0-7 even, rows 8-15 odd
+  const unsigned co = (unsigned)(oz_l * P::CB + (lg & 1) * (P::CB / 2)); // c0 channels 4 (lg & 1) .. of that voxel
+  unsigned colmask = 0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c)
+    colmask |= (unsigned)(active && (unsigned)(y - 1 + c / 3) < (unsigned)H && (unsigned)(x - 1 + c % 3) < (unsigned)W) << c;
+  float b11[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b11[e] = d.bias11[(lg & 1) * 4 + e];
+  float S[3] = {0.f, 0.f, 0.f};
+  const uint4* wq = reinterpret_cast<const uint4*>(d.w11);
+  const int par = ((y & 1) << 1) | (x & 1);                              // wave-uniform
+  if (par == 0) ps2_columns<T, 0, 0>(U, Cn, wp, wq, colmask, lr, lg, bo, co, b11, S);
+  else if (par == 1) ps2_columns<T, 0, 1>(U, Cn, wp, wq, colmask, lr, lg, bo, co, b11, S);
+  else if (par == 2) ps2_columns<T, 1, 0>(U, Cn, wp, wq, colmask, lr, lg, bo, co, b11, S);
+  else ps2_columns<T, 1, 1>(U, Cn, wp, wq, colmask, lr, lg, bo, co, b11, S);
+
+  // ---- logits: the three running sums meet across depths (kd = 0 comes from depth z - 1, kd = 2 from z + 1), then softmax and depth ----
+  if (lr < Dq && (lg & 1) == 0) {
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) Sw[kd * PS_DMAX + oz_l] = S[kd];
+  }
+  float logit = -INFINITY;
+  if (lane < D) {
+    float acc = 0.f;
+    if (lane > 0) acc += Sw[lane - 1];
+    acc += Sw[PS_DMAX + lane];
+    if (lane + 1 < D) acc += Sw[2 * PS_DMAX + lane + 1];
+    logit = acc;
+  }
+  float m = logit;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  // a NaN logit must poison the whole pixel like torch.softmax does (fmaxf drops NaNs)
+  float nanflag = (lane < D && logit != logit) ? 1.f : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nanflag += __shfl_xor(nanflag, off);
+  float e = lane < D ? expf(logit - m) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  float pr = e * (1.f / sum);
+  if (nanflag > 0.f) pr = __builtin_nanf("");
+  float dep = lane < D ? pr * d.depths[(v % d.B) * D + lane] : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) dep += __shfl_xor(dep, off);
+  if (active) {
+    if (lane < D) d.prob[o * D + lane] = pr;
+    if (lane == 0) d.depth_out[o] = dep;
+  }
+}
+
+// conv11's weights [16 in][8 out][3][3][3] (x folded BN scale) as the nine A operands of prob_sparse2_kernel, [9 in-plane taps kh * 3 + kw][16 rows]
+// [4 K groups][8]: K = 32 = [u9(iz): 16 channels | u9(iz + 1): 16 channels]; rows 0-7 (even output depths) = W(kd = 1) on the first half, rows
+// 8-15 (odd output depths) = W(kd = 2) on the first half and W(kd = 0) on the second.
+void prob_sparse_pack(const float* w, const float* scale, std::vector<float>& packed) {
+  packed.assign((size_t)9 * 16 * 4 * 8, 0.f);
+  for (int t = 0; t < 9; ++t)
+    for (int row = 0; row < 16; ++row)
+      for (int k = 0; k < 32; ++k) {
+        const int co = row & 7, ci = k & 15;
+        int kd;
+        if (row < 8) { if (k >= 16) continue; kd = 1; }
+        else kd = k < 16 ? 2 : 0;
+        packed[(((size_t)t * 16 + row) * 4 + (k >> 3)) * 8 + (k & 7)] = w[((long long)ci * 8 + co) * 27 + kd * 9 + t] * (scale ? scale[co] : 1.f);
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Sparse cost regularisation.  With the sparse tail the network reads the probability volume only at the chosen pixels, so every
 // tensor of the 3-D U-Net is needed only inside the dependency cone of those pixels: per axis and per chosen coordinate y the
 // needed index interval of each tensor follows from the layers' geometry (network_v5.py:260-291; Conv3d k3 p1 stride 1: i-1..i+1,
@@ -356,7 +602,7 @@ int launch_sparse_masks(const int* choose, int v0, int Vc, int P, int S, unsigne
 
 int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, const float* bias11, const float* wprob,
                        const int* choose, const float* depths, float* prob, float* depth_out, int v0, int Vc, int B, int P,
-                       int D, int H, int W, int dtype, hipStream_t s) {
+                       int D, int H, int W, int dtype, hipStream_t s, const void* w11_taps) {
   RGBM_REQUIRE(dtype == BF16 || dtype == F16 || dtype == BF16X3, "prob_sparse: 16-bit storage types or bf16x3");
   RGBM_REQUIRE(u9 && c0 && w11_packed && bias11 && wprob && choose && depths && prob && depth_out, "prob_sparse arguments");
   RGBM_REQUIRE(D <= PS_DMAX && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0, "prob_sparse supports even D <= 24 and even H, W");
@@ -367,6 +613,24 @@ int launch_prob_sparse(const void* u9, const void* c0, const void* w11_packed, c
   d.v0 = v0; d.Vc = Vc; d.B = B; d.P = P; d.D = D; d.H = H; d.W = W;
   const long long npts = (long long)Vc * P;
   RGBM_REQUIRE(npts > 0 && (npts + 3) / 4 < (1ll << 31), "prob_sparse grid out of range");
+  if (w11_taps != nullptr && !(g_debug_flags & (1 << 29))) {
+    // the round-6 kernel (w11_taps: prob_sparse_pack's operands)
+    RGBM_REQUIRE((long long)(D / 2) * (H / 2) * (W / 2) * 16 * 4 < (1ll << 31) && (long long)D * H * W * 8 * 4 < (1ll << 31), "prob_sparse view too large for 32-bit offsets");
+    d.w11 = w11_taps;
+    const unsigned grid = (unsigned)((npts + 3) / 4);
+#define PS2_LAUNCH(TT)                                                                                              \
+    do {                                                                                                            \
+      constexpr int lds = PS2_WP_BYTES + 4 * Ps2<TT>::WAVE_BYTES;                                                   \
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prob_sparse2_kernel<TT>), lds)) return rc;      \
+      hipLaunchKernelGGL(prob_sparse2_kernel<TT>, dim3(grid), dim3(256), lds, s, d);                                \
+    } while (0)
+    if (dtype == BF16) PS2_LAUNCH(unsigned short);
+    else if (dtype == BF16X3) PS2_LAUNCH(bx3_t);
+    else PS2_LAUNCH(f16_t);
+#undef PS2_LAUNCH
+    RGBM_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (dtype == BF16) hipLaunchKernelGGL(prob_sparse_kernel<unsigned short>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
   else if (dtype == BF16X3) hipLaunchKernelGGL(prob_sparse_kernel<bx3_t>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(prob_sparse_kernel<f16_t>, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, s, d);

@@ -405,17 +405,19 @@ def test_bf16_sweep_conv0_vs_tile_conv0(inputs, oracle_taps, blend):
         assert rel[3] < rel[2]      # more mantissa in the features: closer to fp32 than the all-bf16 conv0
 
 
-def test_persistent_sweep_is_bit_identical_to_the_one_tile_sweep(inputs):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_persistent_sweep_is_bit_identical_to_the_one_tile_sweep(inputs, dtype):
     """conv0_sweep_persistent_kernel (one workgroup per CU walks its tiles, the two roles stream across tile boundaries; the default of bf16
-    nets) against the one-workgroup-per-tile kernel with the same arithmetic (debug flag 268435456): the whole c0 volume, and the network
-    outputs with the sparse cost regularisation's tile list, bit for bit."""
+    nets, and since round 6 of fp16 nets with their fp32-accumulating v_fma_mix blend) against the one-workgroup-per-tile kernel with the
+    same arithmetic (debug flag 268435456): the whole c0 volume, and the network outputs with the sparse cost regularisation's tile list,
+    bit for bit."""
     from rgbmanip_amd import _lib
     lib = _lib.load()
 
     def run(flag, sparse_dec):
         _lib.check(lib.rgbm_debug_flags(flag))
         try:
-            net = _net("bf16", options={"sparse_dec": sparse_dec})
+            net = _net(dtype, options={"sparse_dec": sparse_dec})
             if sparse_dec == 0:
                 _run(net, inputs, stop_after=2)
                 return net.fetch(2, "c0", 4 * 24 * 224 * 224 * 8).cpu().numpy()
@@ -426,6 +428,37 @@ def test_persistent_sweep_is_bit_identical_to_the_one_tile_sweep(inputs):
     a, b = run(0, 2), run(1 << 28, 2)
     for k in OUT_KEYS:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "bf16x3"])
+def test_prob_sparse_kernels_agree(dtype):
+    """The sparse tail's round-6 point kernel (prob_sparse2_kernel: neighbourhoods staged once in LDS, parity-specialised code, both depth
+    parities on the 16 MFMA rows) against the round-3..5 kernel (debug flag 536870912) on the same network: same fp32 arithmetic per voxel
+    in another summation order, so prob / depth agree to fp32 rounding, and everything downstream with them.  Inputs with chosen pixels on
+    the crop's border rows / columns (zero padding of every axis) and wrap-padded duplicates."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    inp = {k: v.copy() for k, v in synth.adapose_inputs(3, seed=4).items()}
+    g = np.random.default_rng(1)
+    border = np.concatenate([np.arange(224), 223 * 224 + np.arange(224), np.arange(224) * 224, np.arange(224) * 224 + 223])
+    for k in ("choose1", "choose2"):
+        inp[k][0] = np.sort(g.choice(border, 1024))                          # corners, edges, duplicates
+        inp[k][1] = np.sort(np.concatenate([g.permutation(224 * 224)[:1000], g.permutation(224 * 224)[:24]]))
+    outs = {}
+    for flag in (0, 1 << 29):
+        _lib.check(lib.rgbm_debug_flags(flag))
+        try:
+            net = _net(dtype)
+            outs[flag] = _run(net, inp)
+            prob = net.fetch(3, "prob", 6 * 1024 * 24).view(6, 1024, 24).cpu().numpy()
+            assert np.isfinite(prob).all() and np.allclose(prob.sum(-1), 1.0, atol=1e-5)
+            outs[flag]["prob"] = prob
+        finally:
+            _lib.check(lib.rgbm_debug_flags(0))
+    a, b = outs[0], outs[1 << 29]
+    assert np.abs(a["prob"] - b["prob"]).max() < 2e-6
+    for k in OUT_KEYS:
+        assert _rel(a[k], b[k]) < 1e-5, k
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
