@@ -300,19 +300,35 @@ int UpConvLayer::init(int dtype, int Cin, int Cout_, const float* w, const float
       for (int c = 0; c < Cin; ++c) wz[((size_t)t * Cout + o) * Cin + c] = w[((size_t)o * Cin + c) * 9 + t];
   ConvGeom g;
   g.Cin = Cin; g.Cout = 9 * Cout; g.act = ACT_NONE;
-  if (int rc = gemm.init(dtype, g, wz.data(), nullptr, nullptr, nullptr, Cin, 9 * Cout)) return rc;
+  // The 256-channel tiles (conv_igemm_m32_kernel) take output channel counts that are multiples of 256; up_2's 9 x 64 = 576 stacked rows
+  // ran whole on the generic 128-channel tile at half that kernel's rate.  Rows [0, 512) now go to the 256-channel kernel and the last 64
+  // to the 64-channel one, both writing their channel range of the same z (two launches, same values: a row's dot product does not
+  // depend on which launch computes it up to the kernels' summation order).
+  split = (dtype != F32 && 9 * Cout > 256 && (9 * Cout) % 256 != 0 && (9 * Cout) % 256 <= 64 && Cin % 64 == 0) ? (9 * Cout) / 256 * 256 : 0;
+  if (split) {
+    ConvGeom g1 = g, g2 = g;
+    g1.Cout = split; g2.Cout = 9 * Cout - split;
+    if (int rc = gemm.init(dtype, g1, wz.data(), nullptr, nullptr, nullptr, Cin, g1.Cout)) return rc;
+    if (int rc = gemm2.init(dtype, g2, wz.data() + (size_t)split * Cin, nullptr, nullptr, nullptr, Cin, g2.Cout)) return rc;
+  } else {
+    if (int rc = gemm.init(dtype, g, wz.data(), nullptr, nullptr, nullptr, Cin, 9 * Cout)) return rc;
+  }
   if (bias_h) { if (upload_f32(bias_h, Cout, &bias)) return -2; }
   return 0;
 }
 
 void UpConvLayer::destroy() {
   gemm.destroy();
+  gemm2.destroy();
+  split = 0;
   if (bias) (void)hipFree(bias);
   bias = nullptr;
 }
 
 int UpConvLayer::run(const void* in, void* z, void* out, int V, int h, int w, int ldo, hipStream_t s) const {
   if (int rc = gemm.run(in, z, V, 1, h, w, 9 * Cout, nullptr, RES_NONE, nullptr, 0, s)) return rc;
+  if (split)
+    if (int rc = gemm2.run(in, reinterpret_cast<char*>(z) + (size_t)split * dtype_size(gemm.dtype), V, 1, h, w, 9 * Cout, nullptr, RES_NONE, nullptr, 0, s)) return rc;
   return launch_upconv_combine(gemm.dtype, z, bias, out, V, h, w, Cout, ldo, act, slope, s);
 }
 

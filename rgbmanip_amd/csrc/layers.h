@@ -66,6 +66,8 @@ struct ConvLayer {
 // resolution with the nine taps stacked on the output channels, followed by the tap-combining kernel (upconv.hip)
 struct UpConvLayer {
   ConvLayer gemm;                // 1x1: Cin -> 9*Cout rows in (tap, channel) order, no bias, no activation
+  ConvLayer gemm2;               // round 6: the stacked rows behind the last multiple of 256 (up_2: 576 = 512 + 64), see init()
+  int split = 0;                 // rows of `gemm` when the product runs as two launches (0: one launch)
   float* bias = nullptr;         // [Cout] fp32 or null
   int Cout = 0, act = ACT_NONE;
   float slope = 0.f;

@@ -147,6 +147,11 @@ WIDE_CASES = [c for c in CONV2D_CASES if c[0].startswith("wide_") or c[0] == "ws
     # without the residual that rides the matrix pipe as four identity K steps
     ("m32_big_res", 66, 64, 28, 56, 256, 3, 1, 2, 2, True, 1, 1),
     ("m32_big_nores_512", 34, 128, 56, 28, 512, 1, 1, 0, 1, False, 2, 0),
+    # round 6: one whole round of 256 x 256 tiles + 5024 left-over rows, which go to 64-channel x 128-pixel tiles (160 of them: one round)
+    ("m32_tail64_res", 90, 128, 28, 28, 256, 3, 1, 2, 2, True, 1, 1),
+    # ... and 8192 left-over rows of a 512-channel layer (layer4's case at batch 256, scaled: 2 x 272 = 544 tiles = two rounds + 32): they
+    # go to 128-channel x 128-pixel tiles (64 pixel tiles x 4 = 256: one round)
+    ("m32_tail128_res", 89, 64, 28, 28, 512, 3, 1, 4, 4, False, 1, 1),
 ]
 
 
