@@ -1963,6 +1963,16 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
         int n_cu = 0;
         if (int rc = persistent_grid_cus(&n_cu)) return rc;
         const long long slim_tiles = ((d.M + 255) / 256) * (d.Cout / 64);
+        if constexpr (sizeof(T) == 2 || std::is_same<T, bx3_t>::value) {
+          // round 6: launches that do not fill the grid with 256-pixel tiles of the 256-channel layers pick their tile by requested bytes
+          // (m32_small_choice; debug flag 1073741824: as in round 5)
+          if (d.Cout % 256 == 0 && ((d.M + 255) / 256) * (d.Cout / 256) < n_cu && g_gemm_kernel >= 1 && !(g_debug_flags & ((1 << 30) | 65536)) &&
+              conv_buffer_offsets_ok(d, 256, sizeof(T))) {
+            // (gemm_kernel = 1, the A/B reference: the same arithmetic on 256-channel x 128-pixel tiles - bit-identical results)
+            const int pick = g_gemm_kernel == 1 ? 256 : m32_small_choice(d, n_cu, slim_tiles <= n_cu);
+            if (pick) return launch_m32_small<T>(d, s, pick);
+          }
+        }
         if (slim_tiles <= n_cu) return launch_ws<T, false, false, true>(d, s);
       }
       if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) {
