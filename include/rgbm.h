@@ -370,19 +370,20 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  14     conv0_sweep[_persistent]_kernel (16-bit)            15  conv_igemm_ws64_kernel (16-bit)
  *  16..25 conv3d_tile_kernel 16-bit per layer (conv0..conv6, conv7, conv9, conv11)
  *  26..29 bf16x3: generic implicit GEMM, 3-D layers, conv0 + plane sweep, ws 128 x 256 tile
- *  30     conv_igemm_w256_kernel (experimental)      31 / 32  ws 256 x 128 tile 16-bit / its row-halo variant
+ *  30     (unused since round 6)                     31 / 32  ws 256 x 128 tile 16-bit / (32: unused since round 6)
  *  33     ws 256 x 128 tile bf16x3                   34 / 35 / 36  ws 64 x 256 four-multiply-wave tile bf16x3 / 16-bit / f32
  *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  upconv_final_kernel
- *  40 / 41 conv_igemm_m32_kernel<T, 128>: the 256 x 128 tail launches of rows 31 / 33 (16-bit / bf16x3; round 5: rows 31 / 33 are
- *          conv_igemm_m32_kernel<T, 256> under the default gemm_kernel = 2, conv_igemm_ws_kernel<T, wide> under gemm_kernel = 0)
+ *  40 / 41 conv_igemm_m32_kernel<T, 128, 64 / 128 / 256>: the 128-pixel tail and small-batch launches of rows 31 / 33 (16-bit / bf16x3;
+ *          rows 31 / 33 are conv_igemm_m32_kernel<T, 256, 256> under the default gemm_kernel = 2, conv_igemm_ws_kernel<T, wide> under gemm_kernel = 0)
  * stop synchronises on the recorded events. */
 #define RGBM_PROF_ROWS 42
 /* A/B switches for kernel benchmarking and the parity tests of the non-default kernel variants (0 = normal operation; bits OR together):
- *      4  (experiments build) register-staged implicit GEMM instead of the LDS-DMA kernels        8  no persistent ws kernels (generic tiles)
+ *      8  no persistent ws kernels (generic tiles)
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
  *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
- *   4096  halo-tile conv0 instead of the plane-sweep kernels             8192  256 x 256 two-group kernel (experimental) for Cout % 256 == 0
- *  65536  128 x 256 ws tile even where the 256 x 128 tile applies       131072  row-halo variant of the 256 x 128 tile (experimental)
+ *   4096  halo-tile conv0 instead of the plane-sweep kernels             65536  128 x 256 ws tile even where the 256-channel tiles apply
+ *          (4 / 8192 / 131072 selected the register-staged kernel, the 256 x 256 two-group kernel and the row-halo wide tile of rounds
+ *          1-2: measured slower, removed in round 6; the bits are ignored)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner
  *                                                                                  (default since round 3: channel block outer, taps inner)
  * 2097152  plane sweep of a bf16 feature map (option sweep_f16 = 0): blend on fp32 FMAs from inline asm; fp16 nets: the packed-f16 blend
@@ -392,7 +393,9 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  * 33554432 post-processing: generic fp64 radix selection of the median only (the fall-back of the default selection on fp32
  *          approximations; same result bit for bit)                    67108864  post-processing: guard band in every even-count pose
  * 134217728 implicit-GEMM request waves: 64-bit global addresses + zero page instead of buffer descriptors (the form before round 5)
- * 268435456 plane sweep of an f16 feature map (bf16 nets, sweep_f16 = 1): one workgroup per tile instead of the persistent kernel */
+ * 268435456 plane sweep of an f16 feature map (bf16 nets, sweep_f16 = 1; fp16 nets since round 6): one workgroup per tile instead of the
+ *          persistent kernel            536870912  sparse tail: the round-3..5 point kernel instead of prob_sparse2_kernel
+ * 1073741824 256-channel GEMM: tail and small launches on 256-channel x 128-pixel tiles / the 64 x 256 ws tile as in round 5 */
 int rgbm_debug_flags(int flags);
 /* Kernel choice - tile shape, and with it the order of the fp32 sums - depends on a launch's GEMM rows, i.e. on the batch size: the
  * same pose in batches of different sizes agrees to the storage type's rounding (1e-6 .. 1e-5 relative in fp32 / bf16x3), not bit for
@@ -408,9 +411,6 @@ int rgbm_debug_flags(int flags);
  * residual sums per million.  Debug flag 134217728: the persistent kernels' request waves use 64-bit global addresses and a zero page
  * instead of buffer descriptors (A/B). */
 int rgbm_set_tuning(const char* key, long long value);
-/* 1 if the library was built with RGBM_EXPERIMENTS (the experiment kernels behind flags 4, 8192 and 131072 exist), else 0: those
- * flags are then ignored */
-int rgbm_has_experiments(void);
 /* Achievable-peak probes (the peaks the box reaches, next to the datasheet ones; no reference counterpart).  Asynchronous:
  * the caller times them with events on `stream`.  rgbm_microbench_mfma: a bare v_mfma_f32_16x16x32_bf16 stream, 8 waves per CU on
  * every CU, `iters` x 32 MFMAs per wave on constant (random_operands = 0) or pseudo-random operands; `scratch` holds

@@ -41,17 +41,17 @@ PROF_KERNELS = [
     ("conv3d_tile_kernel<unsigned short, 16, 16, 4, 8, 8, 1, true, false> (conv11)", "bf16"),
 ] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
      ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false> (128 channels x 256 pixels)", "bf16x3"),
-     ("conv_igemm_w256_kernel<unsigned short> (experimental, debug flag 8192)", "bf16"),
+     ("unused (conv_igemm_w256_kernel of rounds 2-5)", "bf16"),
      ("conv_igemm_m32_kernel<unsigned short, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<unsigned short, true, false>, 256 x 128)", "bf16"),
-     ("conv_igemm_ws_kernel<unsigned short, true, true> (256 x 128, one pixel slot per kernel row)", "bf16"),
+     ("unused (row-halo ws tile of rounds 2-5)", "bf16"),
      ("conv_igemm_m32_kernel<rgbm::bx3_t, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<rgbm::bx3_t, true, false>, 256 x 128)", "bf16x3"),
      ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"),
      ("conv_igemm_ws_kernel<unsigned short, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16"),
      ("conv_igemm_ws_kernel<float, false, false, true> (64 channels x 256 pixels, four multiply waves)", "fp32"),
      ("upconv_combine_kernel<16-bit> (PSPUpsample tap combination)", "bf16"), ("upconv_combine_kernel<4-byte> (PSPUpsample tap combination)", "bf16x3"),
      ("upconv_final_kernel (up_3 + final in one kernel; either storage width)", "bf16"),
-     ("conv_igemm_m32_kernel<unsigned short, 128> (256 channels x 128 pixels: the tail launches of the 256 x 256 kernel)", "bf16"),
-     ("conv_igemm_m32_kernel<rgbm::bx3_t, 128> (256 channels x 128 pixels: the tail launches of the 256 x 256 kernel)", "bf16x3")]
+     ("conv_igemm_m32_kernel<unsigned short, 128, 64 / 128 / 256> (128-pixel tiles: tail and small-batch launches of the 256-channel GEMM)", "bf16"),
+     ("conv_igemm_m32_kernel<rgbm::bx3_t, 128, 64 / 128 / 256> (128-pixel tiles: tail and small-batch launches of the 256-channel GEMM)", "bf16x3")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 
@@ -140,7 +140,6 @@ SIGNATURES = {
     "rgbm_debug_flags": (_i, [_i]),
     "rgbm_set_tuning": (_i, [C.c_char_p, _i64]),
     "rgbm_prof_rows": (_i, []),
-    "rgbm_has_experiments": (_i, []),
     "rgbm_microbench_mfma_scratch_floats": (_i, [C.POINTER(C.c_int)]),
     "rgbm_microbench_mfma": (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp]),
     "rgbm_microbench_copy": (_i, [_vp, _vp, C.c_size_t, _vp]),

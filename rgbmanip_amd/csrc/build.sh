@@ -14,9 +14,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 # code objects hold no v_pk_*_f32 (tests/test_cabi_symbols.py).  The packed forms buy nothing here (same-box A/B of every kernel file with
 # and without them: within 0.3 %), so they are off everywhere.
 FLAGS="$FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops"
-# RGBM_EXPERIMENTS=1 build.sh also compiles the experiment kernels (256 x 256 two-group implicit GEMM, row-halo variant of the
-# 256 x 128 tile, register-staged implicit GEMM: all measured slower than what ships; debug flags 8192 / 131072 / 4 select them)
-if [ "${RGBM_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DRGBM_EXPERIMENTS"; fi
 echo "$FLAGS" > build/.flags.new 2>/dev/null || true
 if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o build/*.asm_ok; cp build/.flags.new build/.flags; fi      # new flags: everything is rebuilt AND the sweep kernels' ISA is re-checked
 pids=()
@@ -25,7 +22,7 @@ for f in conv_igemm.hip conv_igemm_glds.hip conv3d_tile.hip conv0_sweep.hip conv
   EXTRA=""
   # files that must round like numpy / torch elementwise ops: no mul+add -> fma contraction
   case "$f" in postproc.hip|ppo_kernels.hip|prepare.hip|control.hip|synth_env.hip|align.hip|pnp.hip|misc_kernels.hip|bn_kernels.hip) EXTRA="-ffp-contract=off";; esac
-  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ] || [ conv_igemm_experiments.inc -nt build/${f%.hip}.o ] || [ conv_igemm_m32.inc -nt build/${f%.hip}.o ] || [ conv3d_tile_table.h -nt build/${f%.hip}.o ] || [ control.h -nt build/${f%.hip}.o ] || [ bbox_emit.h -nt build/${f%.hip}.o ] || [ build.sh -nt build/${f%.hip}.o ]; then
+  if [ ! -f build/${f%.hip}.o ] || [ "$f" -nt build/${f%.hip}.o ] || [ common.h -nt build/${f%.hip}.o ] || [ kernels.h -nt build/${f%.hip}.o ] || [ conv_igemm_m32.inc -nt build/${f%.hip}.o ] || [ conv3d_tile_table.h -nt build/${f%.hip}.o ] || [ control.h -nt build/${f%.hip}.o ] || [ bbox_emit.h -nt build/${f%.hip}.o ] || [ build.sh -nt build/${f%.hip}.o ]; then
     hipcc $FLAGS $EXTRA -c "$f" -o build/${f%.hip}.o &
     pids+=($!)
   fi

@@ -350,13 +350,6 @@ int rgbm_build_volume(int dtype, const void* feat_dev, const float* P_views_dev,
 #include "prof.h"
 extern "C" {
 int rgbm_prof_rows(void) { return rgbm::kProfVariants; }
-int rgbm_has_experiments(void) {
-#ifdef RGBM_EXPERIMENTS
-  return 1;
-#else
-  return 0;
-#endif
-}
 int rgbm_microbench_mfma_scratch_floats(int* n) {
   RGBM_REQUIRE(n, "microbench_mfma_scratch_floats arguments");
   return rgbm::microbench_mfma_scratch_floats(n);

@@ -1388,9 +1388,6 @@ static int launch_ws(ConvDesc d, hipStream_t s) {
 
 #include "conv_igemm_m32.inc"      // 256 x 128 tile on 32x32x16 MFMAs, one multiply wave per SIMD (tuning key gemm_kernel)
 
-#ifdef RGBM_EXPERIMENTS      // experiment kernels (slower than the shipped ones; kept with their parity tests): build with RGBM_EXPERIMENTS=1 build.sh
-#include "conv_igemm_experiments.inc"
-#endif  // RGBM_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------
 // 256 pixel x 64 channel tile, bf16, three roles (layers with 33..64 output channels and no residual: up_2, up_3).
@@ -1948,13 +1945,6 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   if (conv_ch_tile(d.Cout) == 128 && !(g_debug_flags & 8) && d.M >= ws_min_rows(sizeof(T))) {
     // role-specialised (uniform taps, 16-byte aligned output / residual rows)
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
-#ifdef RGBM_EXPERIMENTS
-    if constexpr (sizeof(T) == 2) {
-      // 256 x 256 tiles for the layers whose channel count allows them (debug flag 8192 selects the 128 x 256 kernel for A/B)
-      if (uni && (al & 15ull) == 0ull && d.Cout % 256 == 0 && d.Cin % 64 == 0 && d.KT >= 2 && (g_debug_flags & 8192) && !(g_debug_flags & 64))
-        return launch_w256<T>(d, s);
-    }
-#endif
     if (uni && !(g_debug_flags & 64) && (al & 15ull) == 0ull) {
       // Small launches (B = 1 .. 8): the 256 x 128 / 128 x 256 tiles leave most CUs idle (layer3 at B = 1: 13 tiles), and every tile walks
       // the whole K range.  The 64-channel x 256-pixel shape of the same kernel makes 2-4x as many tiles of a quarter / half of the work;
@@ -1976,13 +1966,6 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
         if (slim_tiles <= n_cu) return launch_ws<T, false, false, true>(d, s);
       }
       if (d.Cout % 256 == 0 && !(g_debug_flags & 65536)) {
-#ifdef RGBM_EXPERIMENTS
-        if constexpr (sizeof(T) == 2) {
-          // row-halo variant: measured 18 % SLOWER than the plain wide tile on a box where the kernel is issue-bound (the shifted B
-          // rows cost ~70 VALU per step in the multiply waves); kept behind a switch for boxes where the L2 -> LDS path is the limit
-          if ((g_debug_flags & 131072) && conv_rowhalo_ok(d) && d.Kpad == 9 * d.Cin && d.KT == 9 * (d.Cin >> 6)) return launch_ws<T, true, true>(d, s);
-        }
-#endif
         if constexpr (sizeof(T) == 2 || std::is_same<T, bx3_t>::value) {
           if (conv_buffer_offsets_ok(d, 256, sizeof(T))) {      // its request waves address both operands through 32-bit buffer offsets
             if (g_gemm_kernel >= 1) return launch_m32<T>(d, s, g_gemm_kernel);

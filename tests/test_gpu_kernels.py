@@ -102,16 +102,15 @@ def test_conv2d(case, dtype):
     assert rel_err(y, ref) < TOL[dtype], name
 
 
-@pytest.mark.parametrize("flags", [131072, 8192, 65536, 1048576], ids=["wide_rowhalo", "w256_pingpong", "narrow_tile", "taps_outer_k_walk"])
+@pytest.mark.parametrize("flags", [65536, 1048576], ids=["narrow_tile", "taps_outer_k_walk"])
 @pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16], ids=["bf16", "fp16"])
 def test_conv2d_switchable_igemm_variants(flags, dtype):
-    """The implicit-GEMM variants behind rgbm_debug_flags (the row-halo wide tile and the 256 x 256 two-group kernel are opt-in
-    experiments, the 128 x 256 tile is the fallback of the wide one, 1048576 = the request waves walk K taps outer / channels inner
-    as before round 3) stay correct: same case, same tolerance as the default."""
+    """The implicit-GEMM variants behind rgbm_debug_flags (65536: the 128 x 256 tile, the fallback of the wide ones; 1048576: the request
+    waves walk K taps outer / channels inner as before round 3) stay correct: same case, same tolerance as the default.  (The row-halo
+    wide tile, the 256 x 256 two-group kernel and the register-staged kernel of rounds 1-2 - measured slower, DESIGN 5b - left the tree in
+    round 6 with their RGBM_EXPERIMENTS build.)"""
     from gpu_util import conv_nd, rel_err
     lib = _lib.load()
-    if flags in (131072, 8192) and not lib.rgbm_has_experiments():
-        pytest.skip("experiment kernels are not in this build (RGBM_EXPERIMENTS=1 rgbmanip_amd/csrc/build.sh)")
     g = torch.Generator().manual_seed(11)
     N, Cin, H, W, Cout, dil = 2, 128, 182, 181, 256, 2
     x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)

@@ -8,7 +8,7 @@ import numpy as np, torch
 from rgbmanip_amd import _lib
 lib = _lib.load()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-kernels = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2").split(",")]      # 10 + k: kernel k with debug flag 134217728 (64-bit global addresses in the ws request waves); 20 / 30: the 256 x 256 ping-pong experiment kernel (debug flag 8192; RGBM_EXPERIMENTS build) with buffer / global requests
+kernels = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2").split(",")]      # 10 + k: kernel k with debug flag 134217728 (64-bit global addresses in the ws request waves)
 dt_name = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "bf16x3": _lib.BF16X3}[dt_name]
 N = int(os.environ.get("AB_VIEWS", "512"))
@@ -39,14 +39,14 @@ for name, H, W, Cin, Cout, k, dil, res in shapes:
     ref = None
     diffs = {}
     for kk in kernels:
-        _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kk % 10), "tuning"); lib.rgbm_debug_flags(8192 if kk == 20 else (8192 | (1 << 27)) if kk == 30 else (1 << 27) if kk >= 10 else 0)
+        _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kk % 10), "tuning"); lib.rgbm_debug_flags((1 << 27) if kk >= 10 else 0)
         out.zero_(); run(); torch.cuda.synchronize()
         o = out.view(torch.int32 if x.dtype in (torch.float32, torch.int32) else torch.int16).clone()
         if ref is None: ref = o
         else: diffs[kk] = int((o != ref).sum())
     for rd in range(rounds):
         for kk in kernels:
-            _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kk % 10), "tuning"); lib.rgbm_debug_flags(8192 if kk == 20 else (8192 | (1 << 27)) if kk == 30 else (1 << 27) if kk >= 10 else 0)
+            _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kk % 10), "tuning"); lib.rgbm_debug_flags((1 << 27) if kk >= 10 else 0)
             lib.rgbm_prof_start()
             for _ in range(4): run()
             torch.cuda.synchronize()
