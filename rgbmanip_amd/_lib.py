@@ -42,9 +42,9 @@ PROF_KERNELS = [
 ] + [("conv_igemm_glds_kernel<bx3_t, ...> (all channel tiles)", "bf16x3"), ("conv3d_tile_kernel<bx3_t, ...> (conv1..conv11)", "bf16x3"),
      ("conv0 + fused plane sweep <bx3_t>", "bf16x3"), ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false> (128 channels x 256 pixels)", "bf16x3"),
      ("unused (conv_igemm_w256_kernel of rounds 2-5)", "bf16"),
-     ("conv_igemm_m32_kernel<unsigned short, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<unsigned short, true, false>, 256 x 128)", "bf16"),
+     ("conv_igemm_m32_kernel<unsigned short, 256, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<unsigned short, true, false>, 256 x 128)", "bf16"),
      ("unused (row-halo ws tile of rounds 2-5)", "bf16"),
-     ("conv_igemm_m32_kernel<rgbm::bx3_t, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<rgbm::bx3_t, true, false>, 256 x 128)", "bf16x3"),
+     ("conv_igemm_m32_kernel<rgbm::bx3_t, 256, 256> (256 channels x 256 pixels, 32x32x16 MFMAs; gemm_kernel = 0: conv_igemm_ws_kernel<rgbm::bx3_t, true, false>, 256 x 128)", "bf16x3"),
      ("conv_igemm_ws_kernel<rgbm::bx3_t, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16x3"),
      ("conv_igemm_ws_kernel<unsigned short, false, false, true> (64 channels x 256 pixels, four multiply waves)", "bf16"),
      ("conv_igemm_ws_kernel<float, false, false, true> (64 channels x 256 pixels, four multiply waves)", "fp32"),
