@@ -11,7 +11,7 @@ FLAGS="--cuda-host-only -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-poi
 pids=()
 for f in *.hip *.cpp "$R/tests/asan/hip_stub.cpp"; do
   o=$B/$(basename $f).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ common.h -nt $o ] || [ kernels.h -nt $o ] || [ layers.h -nt $o ] || [ adapose.h -nt $o ] || [ prof.h -nt $o ] || [ conv_igemm_m32.inc -nt $o ] || [ conv_igemm_experiments.inc -nt $o ]; then
+  if [ ! -f $o ] || [ $f -nt $o ] || [ common.h -nt $o ] || [ kernels.h -nt $o ] || [ layers.h -nt $o ] || [ adapose.h -nt $o ] || [ prof.h -nt $o ] || [ conv_igemm_m32.inc -nt $o ]; then
     hipcc $FLAGS -c $f -o $o &
     pids+=($!)
     if [ ${#pids[@]} -ge 6 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
