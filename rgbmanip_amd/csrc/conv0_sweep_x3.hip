@@ -21,21 +21,8 @@
 #include "kernels.h"
 #include "prof.h"
 
-#ifndef X3_COOP
-#define X3_COOP 1     // 1: eight neighbouring producer lanes fetch the eight 16-byte chunks of ONE pixel (8 cache lines per gather
-                      // instruction instead of 64); 0: the first version, one lane = one voxel = all its chunks (kept for A/B)
-#endif
 #ifndef X3_DEPTH
-#define X3_DEPTH 4    // cooperative producers: rounds of gathers in flight (4 = half a plane ahead, 8 = a whole plane)
-#endif
-#ifndef X3_T
-#define X3_T 0        // bisection switches of the cooperative producers: 1 no reference loads, 2 no plane stores, 4 all gathers at offset 0
-#endif
-#ifndef X3_DTAP
-#define X3_DTAP 4     // X3_DBG & 4: which in-plane tap's operand is dumped
-#endif
-#ifndef X3_DBG
-#define X3_DBG 0      // experiment builds only (tools/abl_build.sh): 1 = every blend waits for ALL gathers, 2 = two barriers per plane
+#define X3_DEPTH 4    // cooperative producers: rounds of gathers in flight (half a plane ahead)
 #endif
 
 namespace rgbm {
@@ -50,13 +37,12 @@ constexpr int X3_SLOT = X3_NV * X3_VS;           // 40320
 constexpr int X3_NSLOT = 3;                      // plane p is written during step p, read during step p + 1, rewritten during step p + 3
 constexpr int X3_RING = X3_NSLOT * X3_SLOT;      // 120960
 constexpr int X3_WLDS = 9 * 64 * 16;             // lo operands of the kd=2 taps, lane-linear per tap (the consumers' register budget)
-constexpr int X3_REC = X3_COOP ? 4 * 2 * 64 * 32 : 0;   // cooperative producers: per wave [plane parity][lane] {4 corner offsets, 4 weights}
+constexpr int X3_REC = 4 * 2 * 64 * 32;   // cooperative producers: per wave [plane parity][lane] {4 corner offsets, 4 weights}
 constexpr int X3_LDS = X3_RING + X3_WLDS + X3_REC;
 constexpr int X3_NPW = 4, X3_NCW = 4;            // producer waves and consumer waves, one of each per SIMD (round 6; rounds 2-5: three consumer waves of 4 rows)
 constexpr int X3_CR = X3_TH / X3_NCW;            // rows of 16 voxels (= fragments) per consumer wave: 3
 static_assert(X3_CR == 3, "the consumers' unit schedule below is written for three fragments per wave");
 constexpr int X3_THREADS = (X3_NPW + X3_NCW) * 64;
-constexpr int X3_NCH = 8;                        // 16-byte chunks (4 fp32 channels) per voxel of the feature map
 static_assert(X3_NV <= X3_NPW * 64, "one producer thread per voxel");
 
 struct Sweep3Desc {
@@ -135,16 +121,27 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
   __syncthreads();
 
   if (wave < X3_NPW) {
-#if X3_COOP
-    // ------------------------------------------------------------------ producers, cooperative gathers
-    // Thread pv still OWNS voxel pv of the 14 x 18 plane for the projection (corner offsets + bilinear weights), but the gathers, the
+    // ------------------------------------------------------------------ producers, cooperative gathers, streaming across tiles
+    // Thread pv OWNS voxel pv of the 14 x 18 plane for the projection (corner offsets + bilinear weights), but the gathers, the
     // blend and the LDS store are done per (voxel, 16-byte chunk): in round r lane (j = lane >> 3, c = lane & 7) works on chunk c
     // (4 fp32 channels) of voxel wave*64 + r*8 + j, so the eight lanes of a group read the eight chunks of one pixel — one 128-byte
-    // line — and a gather instruction touches 8 lines instead of 64.  Measured on the first version: the vector L1 looks up ~1.3
-    // lines per clock and CU under these gathers, and 32 instructions x 64 lines x 4 waves per plane were the kernel's longest
-    // pole (41.5 ms; 33.9 ms when groups of 8 lanes were pointed at the same pixel).  The owner publishes its record
-    // {off[4], w[4]} per plane in LDS (wave-private, two parities); LDS executes a wave's instructions in order, so the readers
-    // of the same wave need no barrier.  Arithmetic and summation order are those of the first version: bit-identical output.
+    // line — and a gather instruction touches 8 lines instead of 64.  Measured on the first version (one lane = one voxel = all its
+    // chunks; removed in round 6): the vector L1 looks up ~1.3 lines per clock and CU under these gathers, and 32 instructions x 64
+    // lines x 4 waves per plane were the kernel's longest pole (41.5 ms; 33.9 ms when groups of 8 lanes were pointed at the same
+    // pixel).  The owner publishes its record {off[4], w[4]} per plane in LDS (wave-private, two parities); LDS executes a wave's
+    // instructions in order, so the readers of the same wave need no barrier.
+    //
+    // Round 6: the plane stream runs on ACROSS tiles.  Rounds 1-5 drained the gathers at a tile's end, sat at a "step D" barrier while
+    // the consumers multiplied the tile's last plane, and only then loaded the next tile's reference features and homography,
+    // projected its first plane and requested its gathers.  Worth -1 % (17.72 -> 17.50 ms on the survey masks, 29.55 -> 29.25 dense,
+    // same box): the D-independent 8 % of a launch that tools/sweep_depth_fit.py measures is still there afterwards, i.e. it is not
+    // the hand-over (a tile's first touches of its partner's feature rows are the likelier cost).  Kept for what it removes — the drain,
+    // a barrier per tile, two producer variants.  A tile's setup loads are requested a whole tile ahead (tile_request), the LAST plane of a tile requests plane 0 of
+    // the next one where the planes before it request their successor (from the partner view of the next tile: the gathers' base is a
+    // macro argument), and there is no barrier but the one per plane: global plane q is produced during step q into ring slot q % 3 and
+    // multiplied during step q + 1.  The last plane is peeled out of the plane loop, so the loop with the counted waits keeps a single
+    // back edge (tools/check_asm_gathers.py follows the rolling gather registers to the end of the kernel).
+    static_assert(X3_DEPTH == 4, "four rounds of gathers in flight (half a plane ahead)");
     const int pv = tid;
     const bool act = pv < X3_NV;
     const int hh = pv / X3_HW, hw = pv - hh * X3_HW;
@@ -164,283 +161,170 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
     // voxel of round r for this lane: wave*64 + r*8 + j; byte position of chunk c's hi part inside a plane slot (lo part 64 bytes on)
     const int vdst0 = (wave * 64 + j) * X3_VS + c * 8;
     const bool vact7 = wave * 64 + 56 + j < X3_NV;      // only round 7 of the last producer wave runs past the 252 voxels
-#define X3_GATHER(R, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(g[R][Q]) : "v"(OFF), "s"(srcb) : "memory")
-#define X3_GATHER4(R, O) do { X3_GATHER(R, 0, (O).x); X3_GATHER(R, 1, (O).y); X3_GATHER(R, 2, (O).z); X3_GATHER(R, 3, (O).w); } while (0)
-#define X3_WAIT(R, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(g[R][0]), "+v"(g[R][1]), "+v"(g[R][2]), "+v"(g[R][3]) :: "memory")
-#if X3_DEPTH == 8
-#define X3_WAITB(R) X3_WAIT(R, 28)
-#else
-#define X3_WAITB(R) X3_WAIT(R, 12)
-#endif
-    int pg = 0;                                          // planes produced so far (ring slot = pg % 3)
-    for (int k = 0; k < n_my; ++k) {
+#define X3_GATHER(R, Q, OFF, BASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(g[R][Q]) : "v"(OFF), "s"(BASE) : "memory")
+#define X3_GATHER4(R, O, BASE) do { X3_GATHER(R, 0, (O).x, BASE); X3_GATHER(R, 1, (O).y, BASE); X3_GATHER(R, 2, (O).z, BASE); X3_GATHER(R, 3, (O).w, BASE); } while (0)
+#define X3_WAITB(R) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[R][0]), "+v"(g[R][1]), "+v"(g[R][2]), "+v"(g[R][3]) :: "memory")
+    // what the projection of a tile's planes needs, per lane = per owned voxel
+    struct TileP { float rx, ry, rz, t0, t1, t2; int dbits; int inb; };      // (inb an int: a bool member made hipcc copy the struct's tail through scratch)
+    // a tile's setup loads in flight (nothing derived yet): lane e < 12 holds word e of the view's homography, lane z < D depth z
+    struct TileRaw { float hmv; int dbits; int gh, gw; };
+    auto tile_request = [&](int k, TileRaw& R, f4v (&rf)[8], const unsigned char*& base) {
       int n, h0, w0;
       tile_of(k, n, h0, w0);
       const int vv = d.v0 + n;
-      const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-      const bool inb = act && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
       const int partner = (vv + d.B) % d.V, bb = vv % d.B;
-      const float* __restrict__ hm = d.homog + (long long)vv * 12;
-      const unsigned char* __restrict__ srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
-      // the previous tile's trailing re-request must have landed before its registers are requested again
-      X3_WAIT(0, 0); X3_WAIT(1, 0); X3_WAIT(2, 0); X3_WAIT(3, 0);
-#if X3_DEPTH == 8
-      X3_WAIT(4, 0); X3_WAIT(5, 0); X3_WAIT(6, 0); X3_WAIT(7, 0);
-#endif
+      R.gh = h0 - 1 + hh; R.gw = w0 - 1 + hw;
+      R.hmv = lane < 12 ? d.homog[(long long)vv * 12 + lane] : 0.f;
+      R.dbits = __float_as_int(lane < D ? d.depths[(long long)bb * D + lane] : 1.f);      // lane z holds depth z
+      base = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
       // reference-view features of this lane's eight (voxel, chunk) pairs; outside the image: conv zero padding
-      f4v ref[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int pvx = wave * 64 + r * 8 + j;
         const int hr = pvx / X3_HW, wr = pvx - hr * X3_HW;
         const int ghr = h0 - 1 + hr, gwr = w0 - 1 + wr;
-        ref[r] = f4v{0.f, 0.f, 0.f, 0.f};
-#if defined(X3_T) && (X3_T & 1)
-        if (false)
-#else
+        rf[r] = f4v{0.f, 0.f, 0.f, 0.f};
         if (pvx < X3_NV && (unsigned)ghr < (unsigned)H && (unsigned)gwr < (unsigned)W)
-#endif
-          ref[r] = *reinterpret_cast<const f4v*>(d.feat + (((long long)vv * H + ghr) * W + gwr) * 32 + c * 4);
+          rf[r] = *reinterpret_cast<const f4v*>(d.feat + (((long long)vv * H + ghr) * W + gwr) * 32 + c * 4);
       }
+    };
+    auto tile_finish = [&](const TileRaw& R, TileP& P) {
+      float hm[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) hm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R.hmv), e));
       // projection of the OWNED pixel (network_v5.py:378-430 folded as in conv0_sweep.hip): p = rot*(x,y,1)*depth + t
-      const float x = (float)gw, y = (float)gh;
-      const float rx = hm[0] * x + hm[1] * y + hm[2];
-      const float ry = hm[3] * x + hm[4] * y + hm[5];
-      const float rz = hm[6] * x + hm[7] * y + hm[8];
-      const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
-      const int dbits = __float_as_int(lane < D ? d.depths[(long long)bb * D + lane] : 1.f);      // lane z holds depth z
-      // corner record of the owned voxel at depth plane z -> LDS record [parity][lane]
-      auto publish = [&](int z, int par) {
-        const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
-        const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
-        const float ix = (px / pz) * sx - 0.5f, iy = (py / pz) * sy - 0.5f;       // true divisions: the fp32 path's accuracy
-        const bool fin = isfinite(ix) && isfinite(iy);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
-        const float tx = ix - fx, ty = iy - fy;
-        const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-        const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
-        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
-        const float ux = 1.f - tx, uy = 1.f - ty;
-        f4v w;
-        w.x = (inb && xin0 && yin0) ? ux * uy : 0.f;
-        w.y = (inb && xin1 && yin0) ? tx * uy : 0.f;
-        w.z = (inb && xin0 && yin1) ? ux * ty : 0.f;
-        w.w = (inb && xin1 && yin1) ? tx * ty : 0.f;
-        if (inb && !fin) w.x = __builtin_nanf("");             // the voxel becomes NaN like the reference's
-        const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
-        u4v off;
-        off.x = (r0 + (unsigned)xc0) * 128u;
-        off.y = (r0 + (unsigned)xc1) * 128u;
-        off.z = (r1 + (unsigned)xc0) * 128u;
-        off.w = (r1 + (unsigned)xc1) * 128u;
-        unsigned char* p = rec + par * 2048 + lane * 32;
-        *reinterpret_cast<u4v*>(p) = off;
-        *reinterpret_cast<f4v*>(p + 16) = w;
-      };
-      auto rec_off = [&](int par, int r) {       // corner offsets of round r's voxel, already at this lane's chunk
-        u4v o = *reinterpret_cast<const u4v*>(rec + par * 2048 + (r * 8 + j) * 32);
-        const unsigned cc = (unsigned)c * 16u;
-        o.x += cc; o.y += cc; o.z += cc; o.w += cc;
-#if defined(X3_T) && (X3_T & 4)
-        o.x = o.y = o.z = o.w = 0u;
-#endif
-        return o;
-      };
-      auto rec_w = [&](int par, int r) { return *reinterpret_cast<const f4v*>(rec + par * 2048 + (r * 8 + j) * 32 + 16); };
-      publish(0, 0);
+      const float x = (float)R.gw, y = (float)R.gh;
+      P.rx = hm[0] * x + hm[1] * y + hm[2];
+      P.ry = hm[3] * x + hm[4] * y + hm[5];
+      P.rz = hm[6] * x + hm[7] * y + hm[8];
+      P.t0 = hm[9]; P.t1 = hm[10]; P.t2 = hm[11];
+      P.dbits = R.dbits;
+      P.inb = (act && (unsigned)R.gh < (unsigned)H && (unsigned)R.gw < (unsigned)W) ? 1 : 0;
+    };
+    // corner record of the owned voxel at depth plane z of the tile described by P -> LDS record [parity][lane]
+    auto publish = [&](int z, int par, const TileP& P) {
+      const float depth = __int_as_float(__builtin_amdgcn_readlane(P.dbits, z));
+      const float px = P.rx * depth + P.t0, py = P.ry * depth + P.t1, pz = P.rz * depth + P.t2;
+      const float ix = (px / pz) * sx - 0.5f, iy = (py / pz) * sy - 0.5f;       // true divisions: the fp32 path's accuracy
+      const bool fin = isfinite(ix) && isfinite(iy);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
+      const float ux = 1.f - tx, uy = 1.f - ty;
+      f4v w;
+      w.x = (P.inb && xin0 && yin0) ? ux * uy : 0.f;
+      w.y = (P.inb && xin1 && yin0) ? tx * uy : 0.f;
+      w.z = (P.inb && xin0 && yin1) ? ux * ty : 0.f;
+      w.w = (P.inb && xin1 && yin1) ? tx * ty : 0.f;
+      if (P.inb && !fin) w.x = __builtin_nanf("");           // the voxel becomes NaN like the reference's
+      const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
+      u4v off;
+      off.x = (r0 + (unsigned)xc0) * 128u;
+      off.y = (r0 + (unsigned)xc1) * 128u;
+      off.z = (r1 + (unsigned)xc0) * 128u;
+      off.w = (r1 + (unsigned)xc1) * 128u;
+      unsigned char* p = rec + par * 2048 + lane * 32;
+      *reinterpret_cast<u4v*>(p) = off;
+      *reinterpret_cast<f4v*>(p + 16) = w;
+    };
+    auto rec_off = [&](int par, int r) {       // corner offsets of round r's voxel, already at this lane's chunk
+      u4v o = *reinterpret_cast<const u4v*>(rec + par * 2048 + (r * 8 + j) * 32);
+      const unsigned cc = (unsigned)c * 16u;
+      o.x += cc; o.y += cc; o.z += cc; o.w += cc;
+      return o;
+    };
+    auto rec_w = [&](int par, int r) { return *reinterpret_cast<const f4v*>(rec + par * 2048 + (r * 8 + j) * 32 + 16); };
+    // round R of the plane whose gathers are in flight: wait for its 4 gathers (the oldest), blend chunk c of its voxel, request the
+    // data of the round four rounds on — this plane's round R + 4 (R < 4: from BASE, this tile's partner view), or round R - 4 of the
+    // plane that follows in the stream (R >= 4: from the partner view of THAT plane's tile) — into the same registers, split into bf16
+    // hi / lo and store 8 + 8 bytes.  The records of the next round are read under the split.
+#define X3_ROUND(R, BASE)                                                                                        \
+    {                                                                                                            \
+      X3_WAITB((R) % X3_DEPTH);                                                                                  \
+      const float wq[4] = {wc.x, wc.y, wc.z, wc.w};                                                              \
+      f4v t = blend4(ref[R], g[(R) % X3_DEPTH][0], g[(R) % X3_DEPTH][1], g[(R) % X3_DEPTH][2], g[(R) % X3_DEPTH][3], wq); \
+      /* the blend must be DONE before the registers are requested again: without this tie hipcc sank round 7's blend into \
+         the `vact7` branch below the gathers and kept "the old values" in copies made before the wait, i.e. stale ones */ \
+      asm volatile("" : "+v"(t));                                                                                \
+      X3_GATHER4((R) % X3_DEPTH, oc, BASE);                                                                      \
+      if (R < 7) { wc = rec_w(pc, R + 1);                                                                        \
+                   oc = (R + 1 < 4) ? rec_off(pc, R + 5) : rec_off(pn, R - 3); }                                 \
+      const unsigned h0_ = pack2_bf16(t.x, t.y), h1_ = pack2_bf16(t.z, t.w);                                     \
+      const unsigned l0_ = pack2_bf16(t.x - __uint_as_float(h0_ << 16), t.y - __uint_as_float(h0_ & 0xffff0000u)); \
+      const unsigned l1_ = pack2_bf16(t.z - __uint_as_float(h1_ << 16), t.w - __uint_as_float(h1_ & 0xffff0000u)); \
+      if (R < 7 || vact7) {                                                                                      \
+        *reinterpret_cast<uint2*>(dst + vdst0 + R * 8 * X3_VS) = make_uint2(h0_, h1_);                           \
+        *reinterpret_cast<uint2*>(dst + vdst0 + R * 8 * X3_VS + 64) = make_uint2(l0_, l1_);                      \
+      }                                                                                                          \
+    }
+    // one plane: publish the record of the plane that follows it in the stream (depth ZREQ of the tile PREQ), blend and store this one,
+    // request that one (rounds 0-3 of it from BASEN), meet the consumers
+#define X3_PLANE(PREQ, ZREQ, BASEC, BASEN)                                                                       \
+    {                                                                                                            \
+      const int pc = par, pn = par ^ 1;                                                                          \
+      publish((ZREQ), pn, (PREQ));                                                                               \
+      unsigned char* dst = planes + (pg % X3_NSLOT) * X3_SLOT;                                                   \
+      f4v wc = rec_w(pc, 0);                                                                                     \
+      u4v oc = rec_off(pc, 4);                                                                                   \
+      X3_ROUND(0, BASEC) X3_ROUND(1, BASEC) X3_ROUND(2, BASEC) X3_ROUND(3, BASEC)                                \
+      X3_ROUND(4, BASEN) X3_ROUND(5, BASEN) X3_ROUND(6, BASEN) X3_ROUND(7, BASEN)                                \
+      ++pg;                                                                                                      \
+      par ^= 1;                                                                                                  \
+      /* the plane just written must be visible before the consumers are released; prefetched gathers stay in flight */ \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+      __builtin_amdgcn_s_barrier();                                                                              \
+      asm volatile("" ::: "memory");          /* no LDS store of the next plane may be scheduled above the barrier */ \
+    }
+    int pg = 0, par = 0;                                 // planes produced so far (ring slot = pg % 3), parity of the plane's record
+    if (n_my > 0) {
+      TileRaw raw;
+      TileP cur, nxt;
+      f4v ref[8], nref[8];
+      const unsigned char *srcb, *nsrcb;
+      tile_request(0, raw, ref, srcb);
+      tile_finish(raw, cur);
+      publish(0, 0, cur);
       {
         u4v o;
-        o = rec_off(0, 0); X3_GATHER4(0, o);
-        o = rec_off(0, 1); X3_GATHER4(1, o);
-        o = rec_off(0, 2); X3_GATHER4(2, o);
-        o = rec_off(0, 3); X3_GATHER4(3, o);
-#if X3_DEPTH == 8
-        o = rec_off(0, 4); X3_GATHER4(4, o);
-        o = rec_off(0, 5); X3_GATHER4(5, o);
-        o = rec_off(0, 6); X3_GATHER4(6, o);
-        o = rec_off(0, 7); X3_GATHER4(7, o);
-#endif
+        o = rec_off(0, 0); X3_GATHER4(0, o, srcb);
+        o = rec_off(0, 1); X3_GATHER4(1, o, srcb);
+        o = rec_off(0, 2); X3_GATHER4(2, o, srcb);
+        o = rec_off(0, 3); X3_GATHER4(3, o, srcb);
       }
-      for (int z = 0; z < D; ++z) {
-        {
-          const int pc = z & 1, pn = pc ^ 1;
-          publish(min(z + 1, D - 1), pn);                  // last plane: a harmless re-request keeps the wait counts static
-          unsigned char* dst = planes + (pg % X3_NSLOT) * X3_SLOT;
-          // round R: wait for its 4 gathers (the oldest in flight), blend chunk c of its voxel, request the data of the round four
-          // rounds on — this plane's round R + 4, or the next plane's round R - 4 — into the same registers, split into bf16
-          // hi / lo and store 8 + 8 bytes.  The records of the next round are read under the split.
-          f4v wc = rec_w(pc, 0);
-          u4v oc = X3_DEPTH == 8 ? rec_off(pn, 0) : rec_off(pc, 4);
-#define X3_ROUND(R)                                                                                              \
-          {                                                                                                      \
-            X3_WAITB((R) % X3_DEPTH);                                                                            \
-            const float wq[4] = {wc.x, wc.y, wc.z, wc.w};                                                        \
-            f4v t = blend4(ref[R], g[(R) % X3_DEPTH][0], g[(R) % X3_DEPTH][1], g[(R) % X3_DEPTH][2], g[(R) % X3_DEPTH][3], wq); \
-            /* the blend must be DONE before the registers are requested again: without this tie hipcc sank round 7's blend into \
-               the `vact7` branch below the gathers and kept "the old values" in copies made before the wait, i.e. stale ones */ \
-            asm volatile("" : "+v"(t));                                                                          \
-            X3_GATHER4((R) % X3_DEPTH, oc);                                                                      \
-            if (R < 7) { wc = rec_w(pc, R + 1);                                                                  \
-                         oc = X3_DEPTH == 8 ? rec_off(pn, R + 1) : (R + 1 < 4) ? rec_off(pc, R + 5) : rec_off(pn, R - 3); } \
-            const unsigned h0_ = pack2_bf16(t.x, t.y), h1_ = pack2_bf16(t.z, t.w);                               \
-            const unsigned l0_ = pack2_bf16(t.x - __uint_as_float(h0_ << 16), t.y - __uint_as_float(h0_ & 0xffff0000u)); \
-            const unsigned l1_ = pack2_bf16(t.z - __uint_as_float(h1_ << 16), t.w - __uint_as_float(h1_ & 0xffff0000u)); \
-            if ((R < 7 || vact7) && !(X3_T & 2)) {                                                               \
-              *reinterpret_cast<uint2*>(dst + vdst0 + R * 8 * X3_VS) = make_uint2(h0_, h1_);                     \
-              *reinterpret_cast<uint2*>(dst + vdst0 + R * 8 * X3_VS + 64) = make_uint2(l0_, l1_);                \
-            }                                                                                                    \
-          }
-          X3_ROUND(0) X3_ROUND(1) X3_ROUND(2) X3_ROUND(3) X3_ROUND(4) X3_ROUND(5) X3_ROUND(6) X3_ROUND(7)
-#undef X3_ROUND
+      nsrcb = srcb;
+      for (int k = 0; k < n_my; ++k) {
+        const bool has_next = k + 1 < n_my;
+        // the next tile's setup loads travel while this tile's planes are produced; their first use is behind the plane loop (they are
+        // OLDER than every gather issued after them, so the counted waits below can only wait longer, never shorter)
+        if (has_next) tile_request(k + 1, raw, nref, nsrcb);
+        for (int z = 0; z + 1 < D; ++z) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(ref[r]));      // (pinned per plane: nothing of the reference features is hoisted around the counted gathers)
+          X3_PLANE(cur, z + 1, srcb, srcb)
         }
-        ++pg;
-        // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
+        // last plane of the tile: what is requested behind it is plane 0 of the next tile (none left: a harmless re-request of this
+        // plane keeps the counted waits valid)
+        if (has_next) tile_finish(raw, nxt); else nxt = cur;
+        X3_PLANE(nxt, has_next ? 0 : D - 1, srcb, nsrcb)
+        if (has_next) {
+          cur = nxt;
+          srcb = nsrcb;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ref[r] = nref[r];
+        }
       }
-      __builtin_amdgcn_s_barrier();                        // step D of the tile: the consumers multiply the last plane
+      __builtin_amdgcn_s_barrier();                        // the consumers multiply the stream's last plane
       asm volatile("" ::: "memory");
     }
 #undef X3_GATHER
 #undef X3_GATHER4
-#undef X3_WAIT
 #undef X3_WAITB
-#else
-    // ------------------------------------------------------------------ producers: one thread per voxel of the 14 x 18 plane
-    const int pv = tid;
-    const bool act = pv < X3_NV;
-    const int hh = pv / X3_HW, hw = pv - hh * X3_HW;
-    unsigned char* dst0 = planes + pv * X3_VS;
-    const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
-    f4v g[X3_NCH][4];                                    // [chunk][corner]: one whole voxel of corner data in flight
-#pragma unroll
-    for (int k = 0; k < X3_NCH; ++k)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) g[k][q] = f4v{0.f, 0.f, 0.f, 0.f};
-    // Gathers are issued from inline asm and counted by hand (see conv0_sweep.hip): chunk k of plane z + 1 is requested right
-    // after chunk k of plane z has been blended out of the same registers; each blend waits for exactly its 4 oldest loads
-    // (28 stay in flight).  The asm results must not be touched before X3_WAIT(k), which names them as in/out.
-#define X3_GATHER(K, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
-#if defined(X3_ABL) && (X3_ABL & 1)      // timing experiment: every lane gathers the same 16 bytes (no address divergence, no cache traffic)
-#define X3_GATHER4(K, C) do { X3_GATHER(K, 0, zoff); X3_GATHER(K, 1, zoff); X3_GATHER(K, 2, zoff); X3_GATHER(K, 3, zoff); } while (0)
-#elif defined(X3_ABL) && (X3_ABL & 2)    // timing experiment: no gathers at all
-#define X3_GATHER4(K, C) do { } while (0)
-#else
-#define X3_GATHER4(K, C) do { X3_GATHER(K, 0, (C).off[0]); X3_GATHER(K, 1, (C).off[1]); X3_GATHER(K, 2, (C).off[2]); X3_GATHER(K, 3, (C).off[3]); } while (0)
-#endif
-#if X3_DBG & 1
-#define X3_WAITB(K) X3_WAIT(K, 0)
-#else
-#define X3_WAITB(K) X3_WAIT(K, 28)
-#endif
-#define X3_WAIT(K, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
-    const unsigned zoff = 0u; (void)zoff;
-    int pg = 0;                                          // planes produced so far (ring slot = pg % 3)
-    for (int k = 0; k < n_my; ++k) {
-      int n, h0, w0;
-      tile_of(k, n, h0, w0);
-      const int vv = d.v0 + n;
-      const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-      const bool inb = act && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-      const int partner = (vv + d.B) % d.V, bb = vv % d.B;
-      const float* __restrict__ hm = d.homog + (long long)vv * 12;
-      const unsigned char* __restrict__ srcb = reinterpret_cast<const unsigned char*>(d.feat + (long long)partner * H * W * 32);
-      // the previous tile's trailing re-request must have landed before its registers are requested again
-      X3_WAIT(0, 0); X3_WAIT(1, 0); X3_WAIT(2, 0); X3_WAIT(3, 0); X3_WAIT(4, 0); X3_WAIT(5, 0); X3_WAIT(6, 0); X3_WAIT(7, 0);
-      f4v ref[X3_NCH];
-#pragma unroll
-      for (int c = 0; c < X3_NCH; ++c) ref[c] = f4v{0.f, 0.f, 0.f, 0.f};     // outside the image: conv zero padding
-      if (inb) {
-        const f4v* pr = reinterpret_cast<const f4v*>(d.feat + (((long long)vv * H + gh) * W + gw) * 32);
-#pragma unroll
-        for (int c = 0; c < X3_NCH; ++c) ref[c] = pr[c];
-      }
-      // projection of this pixel (network_v5.py:378-430 folded as in conv0_sweep.hip): p = rot*(x,y,1)*depth + t
-      const float x = (float)gw, y = (float)gh;
-      const float rx = hm[0] * x + hm[1] * y + hm[2];
-      const float ry = hm[3] * x + hm[4] * y + hm[5];
-      const float rz = hm[6] * x + hm[7] * y + hm[8];
-      const float t0 = hm[9], t1 = hm[10], t2 = hm[11];
-      const int dbits = __float_as_int(lane < D ? d.depths[(long long)bb * D + lane] : 1.f);      // lane z holds depth z
-      auto corners = [&](int z, Corner3& c) {
-        const float depth = __int_as_float(__builtin_amdgcn_readlane(dbits, z));
-        const float px = rx * depth + t0, py = ry * depth + t1, pz = rz * depth + t2;
-        const float ix = (px / pz) * sx - 0.5f, iy = (py / pz) * sy - 0.5f;       // true divisions: the fp32 path's accuracy
-        const bool fin = isfinite(ix) && isfinite(iy);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x0 = (int)fx, y0 = (int)fy;                  // v_cvt_i32_f32 saturates: far-away projections stay "outside"
-        const float tx = ix - fx, ty = iy - fy;
-        const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-        const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0, -1) + 1, W - 1);
-        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0, -1) + 1, H - 1);
-        const float ux = 1.f - tx, uy = 1.f - ty;
-        c.w[0] = (inb && xin0 && yin0) ? ux * uy : 0.f;
-        c.w[1] = (inb && xin1 && yin0) ? tx * uy : 0.f;
-        c.w[2] = (inb && xin0 && yin1) ? ux * ty : 0.f;
-        c.w[3] = (inb && xin1 && yin1) ? tx * ty : 0.f;
-        if (inb && !fin) c.w[0] = __builtin_nanf("");          // the voxel becomes NaN like the reference's
-        const unsigned r0 = (unsigned)(yc0 * W), r1 = (unsigned)(yc1 * W);
-        c.off[0] = (r0 + (unsigned)xc0) * 128u;
-        c.off[1] = (r0 + (unsigned)xc1) * 128u;
-        c.off[2] = (r1 + (unsigned)xc0) * 128u;
-        c.off[3] = (r1 + (unsigned)xc1) * 128u;
-#if defined(X3_ABL) && (X3_ABL & 4)      // timing experiment: groups of 8 lanes gather the same pixel (8 instead of 64 lines per instruction)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c.off[q] = (unsigned)__builtin_amdgcn_ds_bpermute((lane & ~7) * 4, (int)c.off[q]);
-#endif
-      };
-      Corner3 cur, nxt;
-      if (act) {
-        corners(0, cur);
-        X3_GATHER4(0, cur); X3_GATHER4(1, cur); X3_GATHER4(2, cur); X3_GATHER4(3, cur);
-        X3_GATHER4(4, cur); X3_GATHER4(5, cur); X3_GATHER4(6, cur); X3_GATHER4(7, cur);
-      }
-      for (int z = 0; z <= D; ++z) {
-        if (act && z < D) {
-          corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
-          unsigned char* dst = dst0 + (pg % X3_NSLOT) * X3_SLOT;
-          float o[8];
-          uint4 hi, lo;
-          // blend of chunk K (4 channels): ref + w0*a + w1*b + w2*c + w3*e as one fma chain; two chunks make an 8-channel hi / lo pair
-#define X3_BLEND(K, OB)                                                                                         \
-          X3_WAITB(K);                                                                                           \
-          { const f4v t = blend4(ref[K], g[K][0], g[K][1], g[K][2], g[K][3], cur.w);                              \
-            o[OB] = t.x; o[OB + 1] = t.y; o[OB + 2] = t.z; o[OB + 3] = t.w; }                                    \
-          X3_GATHER4(K, nxt);
-          X3_BLEND(0, 0) X3_BLEND(1, 4)
-          split8(o, hi, lo);
-          *reinterpret_cast<uint4*>(dst) = hi; *reinterpret_cast<uint4*>(dst + 64) = lo;
-          X3_BLEND(2, 0) X3_BLEND(3, 4)
-          split8(o, hi, lo);
-          *reinterpret_cast<uint4*>(dst + 16) = hi; *reinterpret_cast<uint4*>(dst + 80) = lo;
-          X3_BLEND(4, 0) X3_BLEND(5, 4)
-          split8(o, hi, lo);
-          *reinterpret_cast<uint4*>(dst + 32) = hi; *reinterpret_cast<uint4*>(dst + 96) = lo;
-          X3_BLEND(6, 0) X3_BLEND(7, 4)
-          split8(o, hi, lo);
-          *reinterpret_cast<uint4*>(dst + 48) = hi; *reinterpret_cast<uint4*>(dst + 112) = lo;
-#undef X3_BLEND
-          cur = nxt;
-        }
-        if (z < D) ++pg;
-        // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
-#if X3_DBG & 2
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#endif
-      }
-    }
-#undef X3_GATHER
-#undef X3_GATHER4
-#undef X3_WAIT
-#endif
+#undef X3_ROUND
+#undef X3_PLANE
   } else {
     // ------------------------------------------------------------------ consumers: 3 rows x 16 voxels per wave
     const int cw = wave - X3_NPW;
@@ -552,7 +436,8 @@ __global__ __launch_bounds__(X3_THREADS, 2) void conv0_sweep_x3_kernel(const Swe
           Lp[pr] = lo;
         }
       };
-      for (int z = 0; z <= D; ++z) {
+      // (k > 0: plane 0 of this tile was produced, and its barrier passed, while the previous tile's last plane was multiplied)
+      for (int z = k == 0 ? 0 : 1; z <= D; ++z) {
         if (z >= 1) {
           const int p = z - 1;
           const unsigned sa = lds_base + (unsigned)(((pg0 + p) % X3_NSLOT) * X3_SLOT + boff);      // LDS address of (fragment 0, tap (0,0), hi)
