@@ -30,11 +30,8 @@
 #include "kernels.h"
 #include "prof.h"
 
-#ifndef SW_ABL
-#define SW_ABL 0      // ablation builds only (tools/abl_sweep_flags.sh): 1 no blend, 2 no MFMA, 4 no gathers, 8 four lanes share a gathered pixel,
-                      // 16 no output stores, 32 no per-plane projection (the first plane's corners are reused), 64 gathers from one address,
-                      // 256 s_memtime phase timers, printed by a few workgroups, 512 no operand reads in the consumers
-#endif
+// (Rounds 1-5 carried timing-build switches here - `SW_ABL`: no blend / no MFMA / no gathers / phase timers ... - whose measurements are in
+// DESIGN.md sections 5, 5d and 5e; they left the source in round 6 together with the two-plane-lag variants `SW_PRE` / `SWP_PRE`.)
 
 namespace rgbm {
 
@@ -52,17 +49,12 @@ constexpr int SW_NV = SW_HH * SW_HW;             // 252 voxels per input plane
                       // touches 16 pixels' 64-byte runs instead of 64 lanes' 16-byte pieces of 64 pixels).  Same box, dense, ms per step:
                       // lane per voxel 14.05, quads with a DPP exchange 13.2 (and 15.4 with 16 consecutive voxels per round + ds_bpermute_b32)
 #endif
-#ifndef SW_PRE
-#define SW_PRE 0      // > 0 (3, 6, 9): the consumers run TWO planes behind the producers (four ring slots) and read the first SW_PRE operand fragments
-                      // of the next plane while the current plane's output epilogue runs.  Round 5, timers in the kernel (-DSW_ABL=256): since
-                      // the packed-f16 blend the consumers are the critical path - 1160-1200 cycles from the barrier to the last MFMA issue for
-                      // 864 cycles of MFMAs - but taking the first reads' LDS round trip out of that phase only moves the time (the phase
-                      // shrinks by 100 cycles, the epilogue with the reads in it grows by as much): 13.2 ms dense with 0, 13.3 with 6, and
-                      // 9 does not fit the 168-register budget.  Off; kept because the two-plane lag is what a persistent version would need.
-#endif
-constexpr int SW_LAG = SW_PRE > 0 ? 2 : 1;
+// (Round 5 measured the consumers TWO planes behind the producers, reading the first operand fragments of the next plane during the current plane's
+// output epilogue: it only moves the time - the MFMA phase shrinks by 100 cycles, the epilogue with the reads in it grows by as much: 13.2 ms dense
+// without, 13.3 with six fragments.)
+constexpr int SW_LAG = 1;                        // the consumers run one plane behind the producers
 #ifndef SW_NSLOT_N
-#define SW_NSLOT_N (SW_PRE > 0 ? 4 : 3)
+#define SW_NSLOT_N 3
 #endif
 #ifndef SW_VS_BYTES
 #define SW_VS_BYTES 80
@@ -107,7 +99,7 @@ constexpr int SW_THREADS = (SW_NPW + SW_NCW) * 64;
 constexpr int SW_NSLOT = SW_NSLOT_N;
 constexpr int SW_LDS = SW_NSLOT * SW_SLOT;
 static_assert(SW_TH % SW_CR_ == 0, "a consumer wave owns SW_CR rows");
-static_assert((SW_PRE == 0 || SW_PRE == 3 || SW_PRE == 6 || SW_PRE == 9) && SW_PRE <= 3 * SW_CR_ && SW_NSLOT_N > SW_LAG, "the prefetched fragments are those of the first in-plane tap row; the ring holds the plane being written and the SW_LAG behind it");
+static_assert(SW_NSLOT_N > SW_LAG, "the ring holds the plane being written and the SW_LAG behind it");
 constexpr int SW_NPAIR = (SW_CR_ + 1) / 2;       // fragment pairs of the output epilogue; with an odd SW_CR the last fragment pairs with itself
 
 struct SweepDesc {
@@ -311,10 +303,6 @@ template <typename T, typename TO, int BL>
 __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const SweepDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if SW_ABL & 256
-  unsigned long long t_entry;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
-#endif
 
   // XCD-aware tile order: every XCD walks a contiguous run of tiles (whole views) so the partner feature maps its CUs
   // gather from stay in that XCD's L2
@@ -335,12 +323,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
   if (wave < SW_NPW) {
     // ------------------------------------------------------------------ producers
     if (std::is_same<T, f16_t>::value) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);      // MODE.FP16_OVFL = 1 (see blend_chunk<f16_t>)
-#if SW_ABL & 256
-    unsigned long long tm[3] = {0, 0, 0}, tq[3];
-#define SW_TP(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SW_TP(I) do {} while (0)
-#endif
     if constexpr (BL == 3 && SW_COOP != 0) {
     // ---- cooperative form (packed-f16 blend).  The projection stays one lane per voxel (lane l of producer wave w owns voxel 64 w + l and
     // computes its four corner offsets and weights); the gathers, the blend and the LDS store run per (voxel, 16-byte chunk): in round r
@@ -398,10 +380,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
     unsigned wco[4][4];                                  // [round][corner]: weights of the gathers in flight
 #define SW_CGATHER(R, Q, OFF) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(g[R][Q]) : "v"(OFF), "s"(srcb) : "memory")
-#if SW_ABL & 4
-#undef SW_CGATHER
-#define SW_CGATHER(R, Q, OFF) do { (void)(OFF); } while (0)
-#endif
 #define SW_CWAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     // request round R of the plane whose per-voxel values are (off, wp): every lane fetches its voxel's four offsets and weights
 #define SW_CREQ(R, OFFV, WPV)                                                                                         \
@@ -433,17 +411,14 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
     };
     // (two loops, not `if (z < D)` inside one: the plane loop that holds the counted waits has no branch but its back edge - check_asm_gathers.py)
     for (int z = 0; z < D; ++z) {
-      SW_TP(0);
-#if !(SW_ABL & 32)
       corners(min(z + 1, D - 1), noff, nwp);             // last plane: a harmless re-request keeps the wait counts static
-#endif
 #pragma unroll
       for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ref[k].x), "+v"(ref[k].y), "+v"(ref[k].z), "+v"(ref[k].w));
       unsigned char* dst = planes + (z % SW_NSLOT) * SW_SLOT;
 #define SW_CROUND(R)                                                                                                  \
       do {                                                                                                            \
         SW_CWAIT12(R);                                                                                                \
-        if (!(SW_ABL & 1)) {                                                                                          \
+        {                                                                                                             \
           const uint4 o4 = blend4(ref[R], g[R][0], g[R][1], g[R][2], g[R][3], wco[R]);                                \
           if (actr[R]) *reinterpret_cast<uint4*>(dst + dsto[R]) = o4;                                                 \
         }                                                                                                             \
@@ -453,22 +428,13 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
 #undef SW_CROUND
       // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      SW_TP(1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
-#if SW_ABL & 256
-      SW_TP(2);
-      if (z >= 1) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += 1; }
-#endif
     }
     for (int z = D; z < D + SW_LAG; ++z) {               // the consumers run SW_LAG planes behind
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-#if SW_ABL & 256
-    if (lane == 0 && (blockIdx.x % 4099) == 17)
-      printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
-#endif
 #undef SW_CGATHER
 #undef SW_CWAIT12
 #undef SW_CREQ
@@ -530,10 +496,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       } else {
         c.skip = false;
       }
-#if SW_ABL & 8        // timing experiment: groups of 4 lanes gather the same pixel (16 instead of 64 lines per instruction)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c.off[q] = (unsigned)__builtin_amdgcn_ds_bpermute((lane & ~3) * 4, (int)c.off[q]);
-#endif
     };
 
     // One register set of 16 x 16 B: chunk k (its 4 corners) of plane z+1 is requested right after chunk k of plane z
@@ -555,10 +517,6 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       for (int q = 0; q < 4; ++q) g[k][q] = u32x4{0u, 0u, 0u, 0u};
 #define SW_GATHER(K, Q, OFF)                                                                                       \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #K "*16" : "+v"(g[K][Q]) : "v"(OFF), "s"(srcb) : "memory")
-#if SW_ABL & 4
-#undef SW_GATHER
-#define SW_GATHER(K, Q, OFF) do { (void)(OFF); } while (0)
-#endif
 #define SW_GATHER4(K, C) do { SW_GATHER(K, 0, (C).off[0]); SW_GATHER(K, 1, (C).off[1]); SW_GATHER(K, 2, (C).off[2]); SW_GATHER(K, 3, (C).off[3]); } while (0)
 #define SW_WAIT12(K) asm volatile("s_waitcnt vmcnt(12)" : "+v"(g[K][0]), "+v"(g[K][1]), "+v"(g[K][2]), "+v"(g[K][3]) :: "memory")
     if (act) {
@@ -566,16 +524,8 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
       SW_GATHER4(0, cur); SW_GATHER4(1, cur); SW_GATHER4(2, cur); SW_GATHER4(3, cur);
     }
     for (int z = 0; z < D + SW_LAG; ++z) {
-      SW_TP(0);
       if (act && z < D) {
-#if SW_ABL & 32
-        nxt = cur;
-#else
         corners(min(z + 1, D - 1), nxt);                 // last plane: a harmless re-request keeps the wait counts static
-#endif
-#if SW_ABL & 64
-        nxt.off[0] = nxt.off[1] = nxt.off[2] = nxt.off[3] = 0u;
-#endif
         if (sizeof(T) == 2 && !std::is_same<T, unsigned short>::value) {
           // f16_t: keep the reference feature packed (hipcc otherwise hoists its 32 conversions out of the plane loop:
           // 170 VGPRs instead of 164)
@@ -584,41 +534,24 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         }
         unsigned char* dst = dst0 + (z % SW_NSLOT) * SW_SLOT;
         SW_WAIT12(0);
-#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst) = blend(ref[0], g[0][0], g[0][1], g[0][2], g[0][3], cur);
         SW_GATHER4(0, nxt);
         SW_WAIT12(1);
-#endif
-#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 16) = blend(ref[1], g[1][0], g[1][1], g[1][2], g[1][3], cur);
-#endif
         SW_GATHER4(1, nxt);
         SW_WAIT12(2);
-#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 32) = blend(ref[2], g[2][0], g[2][1], g[2][2], g[2][3], cur);
-#endif
         SW_GATHER4(2, nxt);
         SW_WAIT12(3);
-#if !(SW_ABL & 1)
         *reinterpret_cast<uint4*>(dst + 48) = blend(ref[3], g[3][0], g[3][1], g[3][2], g[3][3], cur);
-#endif
         SW_GATHER4(3, nxt);
         cur = nxt;
       }
       // the plane just written must be visible before the consumers are released; prefetched gathers stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      SW_TP(1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");                     // no LDS store of the next plane may be scheduled above the barrier
-#if SW_ABL & 256
-      SW_TP(2);
-      if (z >= 1 && z < D) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += 1; }
-#endif
     }
-#if SW_ABL & 256
-    if (lane == 0 && (blockIdx.x % 4099) == 17)
-      printf("producer %d of block %d: per plane: work %llu, barrier %llu cycles\n", wave, (int)blockIdx.x, tm[0] / tm[2], tm[1] / tm[2]);
-#endif
     }
 #undef SW_GATHER
 #undef SW_GATHER4
@@ -679,40 +612,14 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
             v[r] = hi[r] + Lp[pr][r];
             v[r] = v[r] < 0.f ? 0.f : v[r];                        // conv0 always has its ReLU (the launcher checks); NaN propagates, like torch.relu
           }
-          if (!(SW_ABL & 16) || v[0] == 12345.678f) store4(dst, v);
+          store4(dst, v);
         }
         Lp[pr] = lo;
       }
     };
 
-#if SW_ABL & 256
-    unsigned long long t_loop;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop) :: "memory");
-    unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq[5];
-#define SW_T(I) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SW_T(I) do {} while (0)
-#endif
     // operand fragments of a plane: b[r][c] = voxels (row cw * SW_CR + r, columns c .. c + 15) of the 14 x 18 input plane, r < SW_CR + 2
-    sw_u4v pre[SW_PRE > 0 ? SW_PRE : 1];      // fragment k = b[k % SW_CR][k / SW_CR] of the NEXT plane (the first in-plane taps' operands)
-#pragma unroll
-    for (int k = 0; k < (SW_PRE > 0 ? SW_PRE : 1); ++k) pre[k] = sw_u4v{0u, 0u, 0u, 0u};
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
-    auto prefetch = [&](int q) {       // plane q is complete (its barrier lies one iteration back) and stays untouched for SW_NSLOT - 1 more
-      const unsigned sa = lds_base + (unsigned)((q % SW_NSLOT) * SW_SLOT + boff);
-#pragma unroll
-      for (int k = 0; k < SW_PRE; ++k)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[k]) : "v"(sa), "n"(((k % SW_CR_) * SW_HW + k / SW_CR_) * SW_VS) : "memory");
-    };
-#if SW_ABL & 512
-    uint4 bfix[SW_CR_ + 2][3];       // timing experiment: operands read once per tile (no LDS reads in the plane loop)
-#pragma unroll
-    for (int r = 0; r < SW_CR_ + 2; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) bfix[r][c] = *reinterpret_cast<const uint4*>(planes + boff + (r * SW_HW + c) * SW_VS);
-#endif
     for (int z = 0; z < D + SW_LAG; ++z) {
-      SW_T(0);
       if (z >= SW_LAG) {
         const int p = z - SW_LAG;
         const unsigned char* slot = planes + (p % SW_NSLOT) * SW_SLOT + boff;
@@ -724,68 +631,31 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
         for (int r = 0; r < SW_CR_ + 2; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            if (r < SW_CR_ && c * SW_CR_ + r < SW_PRE) b[r][c] = __builtin_bit_cast(uint4, pre[c * SW_CR_ + r]);      // read during the previous iteration
-#if SW_ABL & 512
-            else { b[r][c] = bfix[r][c]; asm volatile("" : "+v"(b[r][c].x), "+v"(b[r][c].y), "+v"(b[r][c].z), "+v"(b[r][c].w)); }
-#else
-            else b[r][c] = *reinterpret_cast<const uint4*>(slot + (r * SW_HW + c) * SW_VS);
-#endif
+            b[r][c] = *reinterpret_cast<const uint4*>(slot + (r * SW_HW + c) * SW_VS);
           }
 #pragma unroll
-        for (int tp = 0; tp < ((SW_ABL & 2) ? 0 : 9); ++tp) {
+        for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
           for (int f = 0; f < SW_CR_; ++f) {
             Xn[f] = Sw16<T>::mma(A01[tp], b[f + tp / 3][tp % 3], Xn[f]);
             Xp[f] = Sw16<T>::mma(A2[tp], b[f + tp / 3][tp % 3], Xp[f]);
           }
         }
-#if SW_ABL & 256
-        asm volatile("s_nop 0" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[2]));      // all MFMAs issued
-#endif
-        if (SW_PRE > 0 && p + 1 < D) {
-          // the next plane's first operands travel while the epilogue below runs; tied to the accumulators so that hipcc keeps the reads
-          // behind this plane's MFMAs (their registers are this plane's operands until then)
-          asm volatile("" : "+v"(Xp[0]), "+v"(Xn[SW_CR_ - 1]) :: "memory");
-          prefetch(p + 1);
-        }
-        SW_T(1);
-#if SW_ABL & 256
-        asm volatile("v_mov_b32 %0, %0" : "+v"(Xp[SW_CR_ - 1][0]));      // the last MFMA's result has landed
-#endif
-        SW_T(2);
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
         for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
       }
-      else if (SW_PRE > 0 && z == SW_LAG - 1) prefetch(0);      // plane 0 is complete since the barrier of iteration 0
-      SW_T(3);
       // The barrier builtin alone does not stop hipcc from hoisting the next plane's first ds_reads above it (seen in the
       // ISA: "ds_read, ds_read, s_barrier"): those reads raced with the producers still writing that slot.  The empty asm
       // with a memory clobber pins every LDS access to its side of the barrier.  The lgkmcnt(0) covers the other direction:
       // MFMAs are not memory operations, so hipcc may sink a plane's last ds_read/MFMA pairs below the barrier (seen in
       // the peeled first iteration of an experimental build) — the read would then still be queued when the producers
       // start to overwrite the slot.
-      if constexpr (SW_PRE == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]) :: "memory");
-      else if constexpr (SW_PRE == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]) :: "memory");
-      else if constexpr (SW_PRE == 9) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]), "+v"(pre[7]), "+v"(pre[8]) :: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#if SW_ABL & 256
-      SW_T(4);
-      if (z >= SW_LAG + 1) { tm[0] += tq[1] - tq[0]; tm[1] += tq[2] - tq[1]; tm[2] += tq[3] - tq[2]; tm[3] += tq[4] - tq[3]; tm[4] += 1; }
-#endif
     }
-#if SW_ABL & 256
     emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
-    unsigned long long t_exit;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit) :: "memory");
-    if (lane == 0 && (blockIdx.x % 4099) == 17)
-      printf("consumer %d of block %d: per plane: reads + MFMA issue %llu, last MFMA lands %llu, epilogue %llu, barrier %llu cycles; entry -> loop %llu, loop %llu (%d iterations), wave total %llu\n", cw, (int)blockIdx.x,
-             tm[0] / tm[4], tm[1] / tm[4], tm[2] / tm[4], tm[3] / tm[4], t_loop - t_entry, tq[4] - t_loop, D + SW_LAG, t_exit - t_entry);
-#else
-    emit(D - 1);                       // plane D is zero padding: X[D-1] is already complete
-#endif
   }
 }
 
@@ -797,14 +667,11 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void conv0_sweep_kernel(const S
 // from plane D - 1 of a tile straight to plane 0 of the next (whose reference features, depths and homography were requested a whole tile
 // earlier), the consumers follow one plane behind, keep their weights, and spend one extra output epilogue per tile instead of one
 // iteration.  f16 feature maps + packed-f16 blend + cooperative quad gathers only (what the bf16 nets run); TO = storage type of c0.
-#ifndef SWP_PRE
-#define SWP_PRE 0     // 1: the consumers run TWO planes behind and read ALL operand fragments of the next plane (15 x 16 bytes per lane: the 256-register
-                      // budget of one workgroup per CU has room) while the current plane's epilogue runs - no LDS round trip between the barrier and
-                      // the first MFMA, no read between the MFMAs.  Measured 12.9-13.0 ms dense against 12.5: a denser MFMA phase takes from the
-                      // producer on the same SIMD what it gives the consumer (fp32 arithmetic of another wave does not issue under MFMAs:
-                      // tools/micro/mfma_valu_coissue.hip).  Off.
-#endif
-constexpr int SWP_LAG = SWP_PRE ? 2 : 1;
+// (Round 5 also measured the consumers TWO planes behind, reading all 15 operand fragments of the next plane during the current plane's epilogue -
+// no LDS round trip between the barrier and the first MFMA: 12.9-13.0 ms dense against 12.5.  A denser MFMA phase takes from the producer on the
+// same SIMD what it gives the consumer (fp32 arithmetic of another wave does not issue under MFMAs: tools/micro/mfma_valu_coissue.hip).  The
+// `SWP_PRE` switch left the source in round 6.)
+constexpr int SWP_LAG = 1;                         // the consumers run one plane behind the producers
 constexpr int SWP_NSLOT = 4;                       // 80.6 KB: also keeps a second workgroup off the CU (one workgroup per CU by construction)
 constexpr int SWP_LDS = SWP_NSLOT * SW_SLOT;
 
@@ -1016,29 +883,9 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
 #pragma unroll
     for (int r = 0; r < 4; ++r) binit[r] = lg >= 2 ? d.bias[(lg & 1) * 4 + r] : 0.f;
     const int boff = ((cw * SW_CR_) * SW_HW + lr) * SW_VS + lg * 16;     // fragment 0, tap (0,0)
-    constexpr int NF = 3 * (SW_CR_ + 2);                   // operand fragments of a plane: b[r][c] = fragment 3 r + c
-    sw_u4v pre[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) pre[k] = sw_u4v{0u, 0u, 0u, 0u};
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)planes;
-    auto prefetch = [&](int sl) {      // the plane in ring slot sl is complete (its barrier lies behind) and stays untouched for two more iterations
-      const unsigned sa = lds_base + (unsigned)(sl * SW_SLOT + boff);
-#pragma unroll
-      for (int k = 0; k < NF; ++k)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[k]) : "v"(sa), "n"(((k / 3) * SW_HW + k % 3) * SW_VS) : "memory");
-    };
-#define SWP_TIE_PRE(STR) asm volatile(STR : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]), "+v"(pre[7]), \
-                                       "+v"(pre[8]), "+v"(pre[9]), "+v"(pre[10]), "+v"(pre[11]), "+v"(pre[12]), "+v"(pre[13]), "+v"(pre[14]) :: "memory")
-    static_assert(NF == 15 || !SWP_PRE, "SWP_TIE_PRE names 15 fragments");
     __builtin_amdgcn_s_barrier();      // plane 0 of the first tile is complete
     asm volatile("" ::: "memory");
-    if (SWP_PRE) {
-      prefetch(0);
-      SWP_TIE_PRE("s_waitcnt lgkmcnt(0)");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    int slot = 0, rslot = 1, left = nt * D;                // ring slot of the plane to multiply / to read next; planes left in the stream
+    int slot = 0;                                          // ring slot of the plane to multiply
     int t1 = nt > 1 ? tile_index(1) : 0;
     int tcur = tile_index(0);
     for (int ti = 0; ti < nt; ++ti) {
@@ -1094,26 +941,15 @@ __global__ __launch_bounds__(SW_THREADS, 2) void conv0_sweep_persistent_kernel(c
         for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
           for (int f = 0; f < SW_CR_; ++f) {
-            uint4 b;
-            if constexpr (SWP_PRE != 0) b = __builtin_bit_cast(uint4, pre[(f + tp / 3) * 3 + tp % 3]);
-            else b = *reinterpret_cast<const uint4*>(sl + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
+            const uint4 b = *reinterpret_cast<const uint4*>(sl + ((f + tp / 3) * SW_HW + tp % 3) * SW_VS);
             Xn[f] = Sw16<T>::mma(A01[tp], b, Xn[f]);
             Xp[f] = Sw16<T>::mma(A2[tp], b, Xp[f]);
           }
         }
-        --left;
-        if (SWP_PRE != 0 && left > 0) {
-          // every MFMA of this plane has read its operands (the nops cover the last one's passes: a ds_read result landing in a register an
-          // MFMA still reads is the hazard tools/micro/mfma_lds_war.hip demonstrates) - the next plane's operands travel during the epilogue
-          asm volatile("s_nop 15\n\ts_nop 3" : "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[SW_CR_ - 1]), "+v"(Xn[0]), "+v"(Xn[1]), "+v"(Xn[SW_CR_ - 1]) :: "memory");
-          prefetch(rslot);
-        }
-        rslot = (rslot + 1) & (SWP_NSLOT - 1);
         emit(p - 1);                   // X[p-1] is complete once plane p has contributed its kd=2 taps
 #pragma unroll
         for (int f = 0; f < SW_CR_; ++f) Xp[f] = Xn[f];
-        if (SWP_PRE != 0) SWP_TIE_PRE("s_waitcnt lgkmcnt(0)");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (both directions: see conv0_sweep_kernel)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (both directions: see conv0_sweep_kernel)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
