@@ -56,11 +56,6 @@ struct Sweep3Desc {
   const int* tile_list; const int* tile_count;      // sparse cost regularisation: only these tiles (ascending), else null
 };
 
-struct Corner3 {
-  unsigned off[4];          // byte offsets of the 4 (clamped) corner pixels inside the partner feature map
-  float w[4];               // bilinear weights: 0 outside the image, NaN for a non-finite projection
-};
-
 typedef __attribute__((ext_vector_type(4))) float f4v;        // native vectors: usable as tied inline-asm operands
 typedef __attribute__((ext_vector_type(4))) unsigned u4v;
 __device__ __forceinline__ u4v ld_u4v(const uint4* p) { const uint4 t = *p; return u4v{t.x, t.y, t.z, t.w}; }

@@ -11,18 +11,8 @@
 #include "common.h"
 #include "prof.h"
 
-#ifndef W256_DIST
-#define W256_DIST 422     // LDS-DMA pieces per phase of the 256 x 256 kernel (4 digits, phases 1-4)
-#endif
-#ifndef W256_ABL
-#define W256_ABL 0    // experiment builds of the 256 x 256 kernel: 1 = no MFMA, 2 = no LDS-DMA, 4 = no fragment reads, 8 = no setprio
-#endif
 #ifndef WS_BUF
 #define WS_BUF 1      // request waves of the persistent kernels: LDS-DMA through buffer descriptors (blds16) where the operands fit 32-bit offsets
-#endif
-#ifndef IG_ABL
-#define IG_ABL 0      // ablation builds only (tools/abl_build.sh): 1 = pixel gathers read the zero page, 2 = no MFMA, 4 = weights too,
-                      // 8 = no DMA; ws kernel: 16 = no epilogue, 32 = generic epilogue only, 64 = no output stores, 128 = no residual reads
 #endif
 
 namespace rgbm {
@@ -44,10 +34,6 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // lds_off: wave-uniform LDS byte address of this wave's 1 KiB slot (hardware adds lane*16).  M0 is left modified: nothing
 // else in these kernels reads it (gfx9+ DS instructions do not), and saving/restoring it cost 2 SALU per piece.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
-#if IG_ABL & 8
-  asm volatile("" :: "v"(gsrc), "s"(lds_off) : "memory");
-  return;
-#endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_off) : "memory");
 }
 // one LDS-DMA piece through a buffer descriptor: lane address = base + voff + soff (soff is not part of the range check: a lane whose
@@ -241,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 32 + wave * 8) * 8)));
       }
       tc += BK;
@@ -274,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvDesc 
     if (wload) {
 #pragma unroll
       for (int i = 0; i < WL; ++i)
-        glds16((IG_ABL & 4) ? reinterpret_cast<const char*>(zero) : wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
+        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 32 + wave * 8) * 8)));
     }
   };
 
@@ -467,7 +453,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
+        const char* src = ok ? rowp[i] + soff : reinterpret_cast<const char*>(zero);
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(X + (i * 64 + wave * 8) * 8)));
       }
       tc += BK;
@@ -500,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
     if (true) {
 #pragma unroll
       for (int i = 0; i < WL; ++i)
-        glds16((IG_ABL & 4) ? reinterpret_cast<const char*>(zero) : wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
+        glds16(wrow[i] + wk, __builtin_amdgcn_readfirstlane(lds_addr(W + (i * 64 + wave * 8) * 8)));
     }
   };
 
@@ -553,8 +539,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(const ConvDesc d)
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
-          if (!(IG_ABL & 2)) MmaG<T>::run(af[a], bf[b], acc[a][b]);
-          else acc[a][b][0] += __uint_as_float(af[a].x ^ bf[b].x);
+          MmaG<T>::run(af[a], bf[b], acc[a][b]);
         }
     }
   };
@@ -896,8 +881,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 
     int ikt = 0, itile = 0;                  // K tile / tile index of the next request
     auto issue = [&](int stage) {
-      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile();
-      if ((IG_ABL & 256) && ikt == 0) { tkd = tkh = tkw = tc = 0; wko = 0; }
+      if (ikt == 0) enter_tile();
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
       const long long soff =
@@ -915,11 +899,11 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         const bool ok = cok && (rmask[i] & sel) == sel;
-        const char* src = (ok && !(IG_ABL & 1)) ? rowp[i] + soff : zero;
+        const char* src = ok ? rowp[i] + soff : zero;
         glds16(src, sbase + (BCH * 8 + i * 256) * 16);               // X rows 32*i + 8*pw .. +7
       }
 #pragma unroll
-      for (int i = 0; i < WL; ++i) glds16((IG_ABL & 4) ? zero : wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
+      for (int i = 0; i < WL; ++i) glds16(wrow[i] + wko, sbase + (i * 256) * 16);   // W rows 32*i + 8*pw .. +7; wko = byte offset of K index tap * Cin + channel
       }
       if (d.korder && d.lcin >= 0) {
         // channel block outer, taps inner: the taps of one channel block read the same pixel rows shifted by a few rows / columns,
@@ -1024,7 +1008,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
   int xs = 0, kw = 0;                        // RH: X slot and kernel column of the current step
   auto tile_interior = [&](int pix_tile, int ch_tile) {
     return (d.bias == nullptr || bias_lds) && (long long)(pix_tile + 1) * BPIX <= d.M && (ch_tile + 1) * BCH <= d.Cout &&
-           d.act != ACT_TANH && !(IG_ABL & 32);
+           d.act != ACT_TANH;
   };
   for (int k = 0; k < n_my; ++k) {
     {
@@ -1190,17 +1174,6 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
     // All 16 residual reads of a lane are requested before the first one is used: written as load-use-store per
     // fragment they were 16 dependent HBM round trips, 15-17 us per tile with the matrix pipe idle (measured as the
     // K-independent part of the launch time).
-#if IG_ABL & 16
-    {
-      float sum = 0.f;
-#pragma unroll
-      for (int a = 0; a < FM; ++a)
-#pragma unroll
-        for (int b = 0; b < FN; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-      if (sum == 12345.678f) reinterpret_cast<unsigned short*>(out)[tid] = 1;
-      continue;
-    }
-#endif
     int pix_tile, ch_tile;
     tile_of(k, pix_tile, ch_tile);
     const bool interior = tile_interior(pix_tile, ch_tile);
@@ -1257,7 +1230,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
             for (int bb = 0; bb < GRP; ++bb)
 #pragma unroll
               for (int q = 0; q < NQ; ++q)
-                rr[q][bb] = (IG_ABL & 128) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(res + obase[bh + bb] + chL + q * CHK);
+                rr[q][bb] = *reinterpret_cast<const uint4*>(res + obase[bh + bb] + chL + q * CHK);
           }
 #pragma unroll
           for (int bb = 0; bb < GRP; ++bb) {
@@ -1279,7 +1252,7 @@ __global__ __launch_bounds__(SLIM ? 512 : 768) void conv_igemm_ws_kernel(const C
                 for (int e = 0; e < CHK; ++e) v[e] += rv[e];
               }
               const uint4 pk = pack_chunk(v, T());
-              if (!(IG_ABL & 64) || pk.x == 0x12345678u) *reinterpret_cast<uint4*>(out + obase[b] + chL + q * CHK) = pk;
+              *reinterpret_cast<uint4*>(out + obase[b] + chL + q * CHK) = pk;
             }
           }
         }
@@ -1660,8 +1633,7 @@ __global__ __launch_bounds__(768) void conv_igemm_ws64_kernel(const ConvDesc d) 
 
     int ikt = 0, itile = 0;
     auto issue = [&](int stage) {
-      if (ikt == 0 && (itile == 0 || !(IG_ABL & 256))) enter_tile();
-      if ((IG_ABL & 256) && ikt == 0) tkd = tkh = tkw = tc = 0;
+      if (ikt == 0) enter_tile();
       const unsigned sbase = lds0 + (unsigned)stage * (STAGE * 16);
       const unsigned sel = (1u << tkd) | (256u << tkh) | (65536u << tkw);
       const long long soff =

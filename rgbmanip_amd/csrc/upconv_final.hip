@@ -25,10 +25,6 @@
 #include "kernels.h"
 #include "prof.h"
 
-#ifndef UF_ABL
-#define UF_ABL 0      // timing experiments only (tools/abl_build.sh): 1 no combine, 2 no z stores, 4 no per-tap products, 8 no barriers in the tap loop
-#endif
-
 namespace rgbm {
 
 namespace {
@@ -254,9 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OUTK == 2 ?
   {                                                                                                           \
     f32x4 zacc[kNT];                                                                                          \
     _Pragma("unroll") for (int n = 0; n < kNT; ++n) zacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};                     \
-    if constexpr ((UF_ABL & 4) != 0) {                                                                        \
-      _Pragma("unroll") for (int n = 0; n < kNT; ++n) zacc[n][0] = __uint_as_float(af[0].x + n);              \
-    } else if constexpr (X3) {                                                                                \
+    if constexpr (X3) {                                                                                       \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                      \
         uint4 ah, al, bh[kNT], bl[kNT];                                                                       \
         bx3_pair(af[2 * ks], af[2 * ks + 1], ah, al);                                                         \
@@ -279,18 +273,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OUTK == 2 ?
           zacc[n] = Mma16<typename std::conditional<X3, unsigned short, T>::type>::run(af[ks], xf[n][ks], zacc[n]); \
     }                                                                                                         \
     if (KH * 3 + KW < 8) load_a(KH * 3 + KW + 1);                                                             \
-    if constexpr (!(UF_ABL & 8)) __syncthreads(); /* the previous tap's z has been read */                    \
-    if constexpr (!(UF_ABL & 2) && HF) {                                                                      \
+    __syncthreads(); /* the previous tap's z has been read */                                                 \
+    if constexpr (HF) {                                                                                       \
       _Pragma("unroll") for (int n = 0; n < kNT; ++n)                                                         \
         *reinterpret_cast<uint2*>(zw + n * 16 * ZROW) = make_uint2(pair16(zacc[n][0], zacc[n][1]), pair16(zacc[n][2], zacc[n][3])); \
-    } else if constexpr (!(UF_ABL & 2)) {                                                                     \
-      _Pragma("unroll") for (int n = 0; n < kNT; ++n) *reinterpret_cast<f32x4*>(zw + n * 16 * kZRow) = zacc[n]; \
     } else {                                                                                                  \
-      _Pragma("unroll") for (int n = 0; n < kNT; ++n) asm volatile("" :: "v"(zacc[n]));                       \
+      _Pragma("unroll") for (int n = 0; n < kNT; ++n) *reinterpret_cast<f32x4*>(zw + n * 16 * kZRow) = zacc[n]; \
     }                                                                                                         \
-    if constexpr (!(UF_ABL & 8)) __syncthreads();                                                             \
-    if constexpr (!(UF_ABL & 1) && HF) combine_tap_h<KH, KW>(zl, wyh, wxh, acch);                             \
-    else if constexpr (!(UF_ABL & 1)) combine_tap<KH, KW>(zl, wy, wx, acc);                                   \
+    __syncthreads();                                                                                          \
+    if constexpr (HF) combine_tap_h<KH, KW>(zl, wyh, wxh, acch);                                              \
+    else combine_tap<KH, KW>(zl, wy, wx, acc);                                                                \
   }
   UF_TAP(0, 0) UF_TAP(0, 1) UF_TAP(0, 2)
   UF_TAP(1, 0) UF_TAP(1, 1) UF_TAP(1, 2)

@@ -54,12 +54,6 @@ for name, H, W, Cin, Cout, k, dil, res in shapes:
             st = np.array(list(st)).reshape(_lib.PROF_ROWS, 4)
             tot = sum(st[v, 1] for v in range(_lib.PROF_ROWS))
             ms[kk].append(tot / 4)      # per call: a layer may be two launches (whole rounds of 256 x 256 tiles + a tail)
-    if os.environ.get("AB_DEBUG"):      # M32_ABL & 256 builds: request-wave cycle counters at the head of the output
-        _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kernels[-1]), "tuning"); out.zero_(); run(); torch.cuda.synchronize()
-        dbg = out.view(torch.int32).flatten()[:1024].cpu().numpy().astype(np.int64).reshape(256, 4)
-        dbg = np.where(dbg < 0, dbg + (1 << 32), dbg)
-        st_ = dbg[:, 3].clip(min=1)
-        print(f"   request wave 0, cycles per K step (mean over workgroups): landing wait {np.mean(dbg[:,0]/st_):.0f}  barrier {np.mean(dbg[:,1]/st_):.0f}  issue {np.mean(dbg[:,2]/st_):.0f}  steps {st_.mean():.0f}")
     line = f"{name:28s}"
     for kk in kernels:
         m = float(np.median(ms[kk])); line += f" | k{kk}: {m:.4f} ms {flops / m / 1e9:6.0f} TF (min {min(ms[kk]):.4f})"
