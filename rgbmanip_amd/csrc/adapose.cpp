@@ -16,6 +16,7 @@ static const int kLayerBlocks[4] = {3, 4, 6, 3};
 static const int kLayerStride[4] = {1, 2, 1, 1};
 static const int kLayerDil[4] = {1, 1, 2, 4};
 static const int kPspBins[4] = {1, 2, 3, 6};
+static const int kPspSmallViews = 32;      // up to this many views the PSP stage pools and multiplies its 50 cells per view in one launch (see AdaPose::pspnet)
 
 
 static const HostTensor* find(const StateDict& sd, const std::string& name) {
@@ -410,15 +411,36 @@ int AdaPose::pspnet(const Buffers& bf, int V, const float* img1, const float* im
   const void* f = bf.lb[xi];                    // [V][H][W][512], H = W = S/8
   last_f_index = xi;
   RGBM_REQUIRE(H == S / 8 && W == S / 8, "feature stride");
-  if (int rc = launch_copy_channels(dtype, f, bf.cat, (long long)V * H * W, 512, 1024, 0, s)) return rc;
-  {
-    void* outs[4] = {bf.pooled[0], bf.pooled[1], bf.pooled[2], bf.pooled[3]};
-    if (int rc = launch_adaptive_avgpool_multi(dtype, f, outs, kPspBins, 4, V, H, W, 512, s)) return rc;     // all four bin sizes, one launch
-  }
-  for (int i = 0; i < 4; ++i) {
-    const int Sb = kPspBins[i];
-    if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, Sb, Sb, 128, nullptr, 0, nullptr, 0, s)) return rc;
-    if (int rc = launch_resize_bilinear_ac(dtype, bf.stage[i], bf.cat, V, Sb, Sb, 128, H, W, 1024, 512 + 128 * i, s)) return rc;
+  if (g_debug_flags & 1024) {      // the PSP stage as rounds 1-5 ran it: copy, pooling, four GEMM launches, four resizes
+    if (int rc = launch_copy_channels(dtype, f, bf.cat, (long long)V * H * W, 512, 1024, 0, s)) return rc;
+    {
+      void* outs[4] = {bf.pooled[0], bf.pooled[1], bf.pooled[2], bf.pooled[3]};
+      if (int rc = launch_adaptive_avgpool_multi(dtype, f, outs, kPspBins, 4, V, H, W, 512, s)) return rc;     // all four bin sizes, one launch
+    }
+    for (int i = 0; i < 4; ++i) {
+      const int Sb = kPspBins[i];
+      if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, Sb, Sb, 128, nullptr, 0, nullptr, 0, s)) return rc;
+      if (int rc = launch_resize_bilinear_ac(dtype, bf.stage[i], bf.cat, V, Sb, Sb, 128, H, W, 1024, 512 + 128 * i, s)) return rc;
+    }
+  } else {
+    // Small batches (the deployment shape, B = 1 .. 8): pooling and the four 512 -> 128 convs of the 50 cells per view in one launch on the
+    // vector pipe (misc_kernels.hip; the GEMM launches it replaces had 2 .. 576 rows); larger ones keep the pooling launch and the
+    // implicit GEMMs.  The concat (backbone channels + the four resized stages) is one launch at any size.
+    bool small = V <= kPspSmallViews;
+    for (int i = 0; i < 4; ++i)
+      small = small && psp[i].packs.size() == 1 && psp[i].packs[0].Kpad == 512 && psp[i].Cout_pad == 128 && psp[i].bias == nullptr;
+    if (small) {
+      const void* w[4] = {psp[0].packs[0].w, psp[1].packs[0].w, psp[2].packs[0].w, psp[3].packs[0].w};
+      void* outs[4] = {bf.stage[0], bf.stage[1], bf.stage[2], bf.stage[3]};
+      if (int rc = launch_psp_pool_conv(dtype, f, 512, w, outs, kPspBins, V, H, W, psp[0].g.act, psp[0].g.slope, s)) return rc;
+    } else {
+      void* outs[4] = {bf.pooled[0], bf.pooled[1], bf.pooled[2], bf.pooled[3]};
+      if (int rc = launch_adaptive_avgpool_multi(dtype, f, outs, kPspBins, 4, V, H, W, 512, s)) return rc;     // all four bin sizes, one launch
+      for (int i = 0; i < 4; ++i)
+        if (int rc = psp[i].run(bf.pooled[i], bf.stage[i], V, 1, kPspBins[i], kPspBins[i], 128, nullptr, 0, nullptr, 0, s)) return rc;
+    }
+    const void* stages[4] = {bf.stage[0], bf.stage[1], bf.stage[2], bf.stage[3]};
+    if (int rc = launch_psp_resize_cat(dtype, f, stages, kPspBins, bf.cat, V, H, W, s)) return rc;
   }
   // up_1 / up_2: 1x1 GEMM at the low resolution (nine taps stacked on the output channels, z in `ups`: 9/16 of the up-sampled
   // tensor it replaces) + tap combination; or, for A/B, the x2 resize followed by the 3x3 conv on the up-sampled grid
@@ -634,15 +656,15 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
   }
   if (int rc = pm1[0].run(pf_in, bf.Q128a, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
   if (int rc = pm1[1].run(bf.Q128a, bf.Q128b, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.Q128b, bf.glob, bf.Q128a, Vh, P, 128, s)) return rc;
-  if (int rc = launch_view_linear(bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, Vh, 128, 256, 256, 128, 0, s)) return rc;
+  // the two means over a view's points are finished by their consumers (the slices' partial sums in Q128a / G256a: free at that point)
+  if (int rc = launch_mean_points_partial(pdt, bf.Q128b, (float*)bf.Q128a, Vh, P, 128, s)) return rc;
+  if (int rc = launch_view_linear_mean((const float*)bf.Q128a, P, bf.glob, pm2_0_wfull, pm2_0_bias, bf.vbias, Vh, 128, 256, 256, 128, 0, s)) return rc;
   if (int rc = pm2[0].run(bf.Q128b, bf.G256a, Vh, 1, 1, P, 256, nullptr, 0, bf.vbias, 256, s)) return rc;
   if (int rc = pm2[1].run(bf.G256a, bf.G256b, Vh, 1, 1, P, 256, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = launch_mean_points(pdt, bf.G256b, bf.pf2, bf.G256a, Vh, P, 256, s)) return rc;
+  if (int rc = launch_mean_points_partial(pdt, bf.G256b, (float*)bf.G256a, Vh, P, 256, s)) return rc;
   float* hout[3] = {bf.r6, bf.tv, bf.sv};
   const int hdim[3] = {6, 3, 3};
-  if (int rc = launch_pose_heads(bf.pf2, head_w, head_b, hout, hdim, Vh, s)) return rc;
-  if (int rc = launch_ortho6d(bf.r6, bf.R, Vh, s)) return rc;
+  if (int rc = launch_pose_heads_mean((const float*)bf.G256a, P, bf.pf2, bf.R, head_w, head_b, hout, hdim, Vh, s)) return rc;      // + Ortho6d -> R
 
   // ---- outputs (fp32, reference shapes); view2_heads = 0: the view-2 outputs are filled with NaN, so that a consumer of one fails
   // loudly instead of reading stale numbers ----

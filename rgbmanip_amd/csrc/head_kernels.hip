@@ -299,14 +299,36 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const TI* __restrict__
   }
 }
 
+// the mean of channel c of view v from the slices' partial sums: the slices in ascending order, then one division — the one expression
+// of mean_points_finish_kernel and of the consumers that finish the mean themselves (view_linear_kernel, pose_heads_kernel)
+__device__ __forceinline__ float mean_from_partials(const float* __restrict__ partial, long long v, int c, int C, int P) {
+  float sum = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < kMeanSplit; ++sl) sum += partial[(v * kMeanSplit + sl) * C + c];
+  return sum / (float)P;
+}
+
 __global__ __launch_bounds__(256) void mean_points_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int C) {
   const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sum = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < kMeanSplit; ++sl) sum += partial[((long long)v * kMeanSplit + sl) * C + c];
-    out[(long long)v * C + c] = sum / (float)P;
-  }
+  for (int c = threadIdx.x; c < C; c += 256) out[(long long)v * C + c] = mean_from_partials(partial, v, c, C, P);
+}
+
+// the slices' partial sums only (scratch: V * 8 * C floats): for a consumer that finishes the mean itself (launch_view_linear_mean,
+// launch_pose_heads_mean: one launch less per mean, which is what a small-batch forward consists of)
+int launch_mean_points_partial(int dtype, const void* in, float* scratch, int V, int P, int C, hipStream_t s) {
+  RGBM_REQUIRE(dtype == F32 || dtype == F16 || dtype == BF16X3, "mean_points: fp32, fp16 or split-pair input");
+  RGBM_REQUIRE(scratch != nullptr && (const void*)scratch != in, "mean_points: scratch");
+  const int E = dtype == F16 ? 8 : 4;
+  RGBM_REQUIRE(C % E == 0 && C / E <= 256 && 256 % (C / E) == 0, "mean_points: channel count");
+  const dim3 g((unsigned)V * kMeanSplit);
+  if (dtype == F16)
+    hipLaunchKernelGGL(mean_points_kernel<f16_t>, g, dim3(256), 0, s, (const f16_t*)in, scratch, P, C);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(mean_points_kernel<bx3_t>, g, dim3(256), 0, s, (const bx3_t*)in, scratch, P, C);
+  else
+    hipLaunchKernelGGL(mean_points_kernel<float>, g, dim3(256), 0, s, (const float*)in, scratch, P, C);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 // scratch: V * 8 * C floats (any buffer that is free between the producer of `in` and the consumer of `out`)
@@ -329,12 +351,23 @@ int launch_mean_points(int dtype, const void* in, float* out, float* scratch, in
 
 // ---------------------------------------------------------------- small dense layer on per-view vectors
 // out[v][o] = act(bias[o] + sum_i W[o][i0 + i] * x[v][i]),  W row-major [O][ldw].  One block per view.
+// partial != null: x is not read — the input vector is the mean of launch_mean_points_partial's slices over P points, finished here
+// and also written to mean_out [V][I] (the tensor launch_mean_points would have produced)
 __global__ __launch_bounds__(256) void view_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                           const float* __restrict__ bias, float* __restrict__ out, int I,
-                                                          int O, int ldw, int i0, int relu) {
+                                                          int O, int ldw, int i0, int relu, const float* __restrict__ partial, int P,
+                                                          float* __restrict__ mean_out) {
   extern __shared__ float xs[];
   const int v = blockIdx.x;
-  for (int i = threadIdx.x; i < I; i += blockDim.x) xs[i] = x[(long long)v * I + i];
+  if (partial) {
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+      const float m = mean_from_partials(partial, v, i, I, P);
+      xs[i] = m;
+      mean_out[(long long)v * I + i] = m;
+    }
+  } else {
+    for (int i = threadIdx.x; i < I; i += blockDim.x) xs[i] = x[(long long)v * I + i];
+  }
   __syncthreads();
   for (int o = threadIdx.x; o < O; o += blockDim.x) {
     float acc = bias ? bias[o] : 0.f;
@@ -347,7 +380,17 @@ __global__ __launch_bounds__(256) void view_linear_kernel(const float* __restric
 
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s) {
-  hipLaunchKernelGGL(view_linear_kernel, dim3(V), dim3(256), I * sizeof(float), s, x, W, bias, out, I, O, ldw, i0, relu);
+  hipLaunchKernelGGL(view_linear_kernel, dim3(V), dim3(256), I * sizeof(float), s, x, W, bias, out, I, O, ldw, i0, relu, (const float*)nullptr, 0,
+                     (float*)nullptr);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_view_linear_mean(const float* partial, int P, float* mean_out, const float* W, const float* bias, float* out, int V, int I, int O,
+                            int ldw, int i0, int relu, hipStream_t s) {
+  RGBM_REQUIRE(partial && mean_out && P > 0, "view_linear_mean arguments");
+  hipLaunchKernelGGL(view_linear_kernel, dim3(V), dim3(256), I * sizeof(float), s, (const float*)nullptr, W, bias, out, I, O, ldw, i0, relu, partial, P,
+                     mean_out);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -362,12 +405,22 @@ struct PoseHeadsDesc {
   const float* b[3][3];
   float* out[3];
   int odim[3];
+  const float* partial; int P; float* mean_out;      // partial != null: pf2 = the mean of mean_points' slices, finished here (head 0's workgroup writes it to mean_out)
+  float* R;                                          // != null: head 0's six outputs also as a rotation matrix (ortho6d_rotation)
 };
 
+__device__ __forceinline__ void ortho6d_rotation(const float* a, float* o);
+
 __global__ __launch_bounds__(256) void pose_heads_kernel(const float* __restrict__ pf2, const PoseHeadsDesc d) {
-  __shared__ float x0[256], x1[256], x2[128];
+  __shared__ float x0[256], x1[256], x2[128], y6[8];
   const int v = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
-  x0[t] = pf2[(long long)v * 256 + t];
+  if (d.partial) {
+    const float m = mean_from_partials(d.partial, v, t, 256, d.P);
+    x0[t] = m;
+    if (h == 0) d.mean_out[(long long)v * 256 + t] = m;
+  } else {
+    x0[t] = pf2[(long long)v * 256 + t];
+  }
   __syncthreads();
   {
     float acc = d.b[h][0][t];
@@ -388,20 +441,41 @@ __global__ __launch_bounds__(256) void pose_heads_kernel(const float* __restrict
     const float* wr = d.w[h][2] + (long long)t * 128;
     for (int i = 0; i < 128; ++i) acc = fmaf(wr[i], x2[i], acc);
     d.out[h][(long long)v * d.odim[h] + t] = acc;
+    if (t < 8) y6[t] = acc;
+  }
+  if (h == 0 && d.R != nullptr) {      // block-uniform
+    __syncthreads();
+    if (t == 0) ortho6d_rotation(y6, d.R + (long long)v * 9);
   }
 }
 
-int launch_pose_heads(const float* pf2, float* const w[3][3], float* const b[3][3], float* const out[3], const int odim[3], int V,
-                      hipStream_t s) {
+static int pose_heads_launch(const float* pf2, const float* partial, int P, float* mean_out, float* R, float* const w[3][3],
+                             float* const b[3][3], float* const out[3], const int odim[3], int V, hipStream_t s) {
   PoseHeadsDesc d;
   for (int h = 0; h < 3; ++h) {
     for (int l = 0; l < 3; ++l) { d.w[h][l] = w[h][l]; d.b[h][l] = b[h][l]; }
     d.out[h] = out[h];
     d.odim[h] = odim[h];
+    RGBM_REQUIRE(odim[h] <= 8, "pose heads: at most 8 outputs per head");
   }
+  RGBM_REQUIRE(R == nullptr || odim[0] == 6, "pose heads: the rotation matrix needs head 0's six outputs");
+  d.partial = partial; d.P = P; d.mean_out = mean_out; d.R = R;
   hipLaunchKernelGGL(pose_heads_kernel, dim3(V, 3), dim3(256), 0, s, pf2, d);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_pose_heads(const float* pf2, float* const w[3][3], float* const b[3][3], float* const out[3], const int odim[3], int V,
+                      hipStream_t s) {
+  return pose_heads_launch(pf2, nullptr, 0, nullptr, nullptr, w, b, out, odim, V, s);
+}
+
+// the heads on the mean of launch_mean_points_partial's slices (finished here, written to mean_out [V][256]); R != null: head 0's
+// six outputs also as rotation matrices [V][9] (launch_ortho6d's arithmetic) — three launches of a small-batch forward in one
+int launch_pose_heads_mean(const float* partial, int P, float* mean_out, float* R, float* const w[3][3], float* const b[3][3],
+                           float* const out[3], const int odim[3], int V, hipStream_t s) {
+  RGBM_REQUIRE(partial && mean_out && P > 0, "pose_heads_mean arguments");
+  return pose_heads_launch(nullptr, partial, P, mean_out, R, w, b, out, odim, V, s);
 }
 
 // ---------------------------------------------------------------- input / output staging of a forward in one launch each
@@ -469,10 +543,7 @@ int launch_stage_out(const float* nocs4, const float* depth, const float* R, con
 }
 
 // ---------------------------------------------------------------- Ortho6d -> rotation matrix (rotation_utils.py:18-27)
-__global__ void ortho6d_kernel(const float* __restrict__ r6, float* __restrict__ R, int V) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  const float* a = r6 + (long long)v * 6;        // [x_raw(3), y_raw(3)]
+__device__ __forceinline__ void ortho6d_rotation(const float* a, float* o) {      // a: [x_raw(3), y_raw(3)]; o: 3 x 3, columns [x y z]
   float xr[3] = {a[0], a[1], a[2]}, y[3] = {a[3], a[4], a[5]}, z[3], x[3];
   float n = fmaxf(sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]), 1e-8f);
   for (int i = 0; i < 3; ++i) y[i] /= n;
@@ -484,8 +555,13 @@ __global__ void ortho6d_kernel(const float* __restrict__ r6, float* __restrict__
   x[0] = y[1] * z[2] - y[2] * z[1];
   x[1] = y[2] * z[0] - y[0] * z[2];
   x[2] = y[0] * z[1] - y[1] * z[0];
-  float* o = R + (long long)v * 9;               // columns [x y z]
   for (int i = 0; i < 3; ++i) { o[i * 3 + 0] = x[i]; o[i * 3 + 1] = y[i]; o[i * 3 + 2] = z[i]; }
+}
+
+__global__ void ortho6d_kernel(const float* __restrict__ r6, float* __restrict__ R, int V) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  ortho6d_rotation(r6 + (long long)v * 6, R + (long long)v * 9);
 }
 
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s) {

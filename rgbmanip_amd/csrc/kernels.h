@@ -15,6 +15,10 @@ int launch_copy_channels(int dtype, const void* in, void* out, long long npix, i
 int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, int W, int C, int S, hipStream_t s);
 int launch_adaptive_avgpool_multi(int dtype, const void* in, void* const* outs, const int* bins, int nb, int V, int H, int W, int C,
                                   hipStream_t s);
+// PSP stage of small batches (misc_kernels.hip): pooling + the four 512 -> 128 1x1 convs in one launch (small batches); the whole concat (copy + four resizes) in one
+int launch_psp_pool_conv(int dtype, const void* in, int ldi, const void* const* w, void* const* outs, const int* bins, int V, int H, int W,
+                         int act, float slope, hipStream_t s);
+int launch_psp_resize_cat(int dtype, const void* f, const void* const* stages, const int* bins, void* out, int V, int Ho, int Wo, hipStream_t s);
 int launch_homography(const float* P_views, float* out, int V, int B, hipStream_t s);
 int launch_build_volume(int dtype, const void* feat, const float* homog, const float* depths, void* vol, int v0, int Vc, int V,
                         int B, int D, int H, int W, hipStream_t s);
@@ -51,6 +55,12 @@ int launch_f32_to_bx3(const float* in, void* out, long long n, hipStream_t s);  
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
+// consumers that finish a mean over points themselves (one launch less per mean): launch_mean_points_partial writes the slices' sums
+int launch_mean_points_partial(int dtype, const void* in, float* scratch, int V, int P, int C, hipStream_t s);
+int launch_view_linear_mean(const float* partial, int P, float* mean_out, const float* W, const float* bias, float* out, int V, int I, int O,
+                            int ldw, int i0, int relu, hipStream_t s);
+int launch_pose_heads_mean(const float* partial, int P, float* mean_out, float* R, float* const w[3][3], float* const b[3][3],
+                           float* const out[3], const int odim[3], int V, hipStream_t s);
 // the three regression heads (3 x Linear + ReLU each) of every view in one launch; out[h] is [V][odim[h]]
 int launch_pose_heads(const float* pf2, float* const w[3][3], float* const b[3][3], float* const out[3], const int odim[3], int V,
                       hipStream_t s);

@@ -405,6 +405,193 @@ int launch_adaptive_avgpool(int dtype, const void* in, void* out, int V, int H, 
   return launch_adaptive_avgpool_multi(dtype, in, outs, &S, 1, V, H, W, C, s);
 }
 
+// ---------------------------------------------------------------- PSP stage for small batches (pspnet.py:76-94)
+// The pyramid of a deployment-sized batch (B = 1 .. 8: 2 .. 16 views) is 50 cells per view, each a 512 -> 128 1x1 conv of one pooled
+// vector: four GEMM launches of 2 .. 576 rows behind the pooling launch, and four resize launches behind them — ten launches of
+// 5-25 us for a few MFLOP.  psp_pool_conv_kernel: one workgroup per (view, cell) pools its window exactly as adaptive_avgpool_kernel
+// does (same split over the pixel lanes, same order of the sums, the mean rounded to the storage type as the pooled tensor was) and
+// multiplies it with the stage's [128][512] weights on the vector pipe: a wave owns 16 output channels, a lane one 16-byte chunk of
+// K (two for the 4-byte types), fp32 FMAs, butterfly sum over the lanes — a fixed order.  psp_resize_cat_kernel: the four stages'
+// bilinear resize (align_corners, the arithmetic of resize_bilinear_ac_kernel) into their channel slices of `cat` together with the
+// copy of the backbone's 512 channels: the whole concat in one launch, at any batch size.
+struct PspStage { const void* in[4]; const void* w[4]; void* out[4]; int S[4]; int first[5]; float sy[4], sx[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(512) void psp_pool_conv_kernel(const T* __restrict__ in, const PspStage ps, int V, int H, int W, int ldi, int act,
+                                                              float slope) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr int C = 512, CO = 128, NCH = C / E;            // 64 chunks (16-bit types) or 128
+  constexpr int PL = 8;
+  __shared__ float red[PL][64][E];
+  __shared__ uint4 pooled[NCH];
+  __shared__ float res[CO];
+  const int ncell = ps.first[4];
+  const int cell_all = blockIdx.x % ncell;
+  const long long v = blockIdx.x / ncell;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (cell_all >= ps.first[i]) g = i;
+  const int S = ps.S[g], cell = cell_all - ps.first[g];
+  const int sy = cell / S, sx = cell % S;
+  const int h0 = (sy * H) / S, h1 = ((sy + 1) * H + S - 1) / S;
+  const int w0 = (sx * W) / S, w1 = ((sx + 1) * W + S - 1) / S;
+  const int ww = w1 - w0, npx = (h1 - h0) * ww;
+  const float inv = 1.0f / (float)npx;
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < NCH; c0 += 64) {
+    const int cc = c0 + cl;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll 4
+    for (int p = pl; p < npx; p += PL) {
+      const int h = h0 + p / ww, w = w0 + p % ww;
+      float x[E];
+      unpack_chunk(*reinterpret_cast<const uint4*>(in + ((v * H + h) * W + w) * ldi + cc * E), x, T());
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[pl][cl][e] = acc[e];
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float t = red[0][cl][e];
+#pragma unroll
+        for (int q = 1; q < PL; ++q) t += red[q][cl][e];
+        acc[e] = t * inv;
+      }
+      pooled[cc] = pack_chunk(acc, T());
+    }
+    __syncthreads();
+  }
+  // 1x1 conv: wave `pl` owns output channels 16 pl .. 16 pl + 15
+  const T* __restrict__ wg = reinterpret_cast<const T*>(ps.w[g]);
+  float x[NCH / 64][E];
+#pragma unroll
+  for (int q = 0; q < NCH / 64; ++q) unpack_chunk(pooled[q * 64 + cl], x[q], T());
+  float part[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH / 64; ++q) {
+      float wv[E];
+      unpack_chunk(*reinterpret_cast<const uint4*>(wg + (long long)(pl * 16 + o) * C + (q * 64 + cl) * E), wv, T());
+#pragma unroll
+      for (int e = 0; e < E; ++e) sum = fmaf(wv[e], x[q][e], sum);
+    }
+    part[o] = sum;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int o = 0; o < 16; ++o) part[o] += __shfl_xor(part[o], m, 64);
+  if (cl == 0) {
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const float r = part[o];
+      res[pl * 16 + o] = act == ACT_RELU ? (r < 0.f ? 0.f : r) : act == ACT_PRELU ? (r < 0.f ? r * slope : r) : r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CO / E) {
+    float r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = res[threadIdx.x * E + e];
+    T* __restrict__ out = reinterpret_cast<T*>(ps.out[g]);
+    *reinterpret_cast<uint4*>(out + ((long long)v * S * S + cell) * CO + threadIdx.x * E) = pack_chunk(r, T());
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void psp_resize_cat_kernel(const T* __restrict__ f, const PspStage ps, T* __restrict__ out, int V, int Ho, int Wo) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr int CF = 512, CO = 128, CPS = CO / E, CPF = CF / E, CPP = CPF + 4 * CPS;      // chunks per stage / of the backbone's channels / per pixel of `out`
+  const long long total = (long long)V * Ho * Wo * CPP;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CPP);
+    long long t = i / CPP;
+    if (cp < CPF) {                                     // channels 0 .. 511: the backbone's feature map itself (pspnet.py:93 `[feats]`)
+      reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(f + t * CF + cp * E);
+      continue;
+    }
+    const int cq = cp - CPF;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho); t /= Ho;
+    const long long v = t;
+    const int g = cq / CPS, cc = cq - g * CPS;
+    const int S = ps.S[g];
+    const Lerp ly = lerp_ac(ho, S, ps.sy[g]), lx = lerp_ac(wo, S, ps.sx[g]);
+    const T* base = reinterpret_cast<const T*>(ps.in[g]) + v * S * S * CO + cc * E;
+    float a[E], b[E], c[E], dd[E], r[E];
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * S + lx.i0) * CO), a, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i0 * S + lx.i1) * CO), b, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * S + lx.i0) * CO), c, T());
+    unpack_chunk(*reinterpret_cast<const uint4*>(base + ((long long)ly.i1 * S + lx.i1) * CO), dd, T());
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = bilerp(a[e], b[e], c[e], dd[e], lx, ly);
+    reinterpret_cast<uint4*>(out)[i] = pack_chunk(r, T());      // out is [V][Ho][Wo][1024]: chunk i of the tensor
+  }
+}
+
+static int psp_stage_desc(const int* bins, PspStage& ps) {
+  ps.first[0] = 0;
+  for (int i = 0; i < 4; ++i) {
+    RGBM_REQUIRE(bins[i] >= 1, "psp bin size");
+    ps.S[i] = bins[i];
+    ps.first[i + 1] = ps.first[i] + bins[i] * bins[i];
+  }
+  return 0;
+}
+
+// pooled cells of the four bin sizes x their 512 -> 128 1x1 convs (weights [128][512] in the storage type, no bias) -> outs[i] [V][S_i][S_i][128]
+int launch_psp_pool_conv(int dtype, const void* in, int ldi, const void* const* w, void* const* outs, const int* bins, int V, int H, int W,
+                         int act, float slope, hipStream_t s) {
+  const int E = dtype_chunk(dtype);
+  RGBM_REQUIRE(ldi % E == 0 && ldi >= 512 && V > 0, "psp stage arguments");
+  PspStage ps{};
+  if (int rc = psp_stage_desc(bins, ps)) return rc;
+  for (int i = 0; i < 4; ++i) { ps.w[i] = w[i]; ps.out[i] = outs[i]; }
+  const long long blocks = (long long)V * ps.first[4];
+  RGBM_REQUIRE(blocks < (1ll << 31), "psp stage grid");
+  if (dtype == BF16)
+    hipLaunchKernelGGL(psp_pool_conv_kernel<unsigned short>, dim3((unsigned)blocks), dim3(512), 0, s, (const unsigned short*)in, ps, V, H, W, ldi, act, slope);
+  else if (dtype == F16)
+    hipLaunchKernelGGL(psp_pool_conv_kernel<f16_t>, dim3((unsigned)blocks), dim3(512), 0, s, (const f16_t*)in, ps, V, H, W, ldi, act, slope);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(psp_pool_conv_kernel<bx3_t>, dim3((unsigned)blocks), dim3(512), 0, s, (const bx3_t*)in, ps, V, H, W, ldi, act, slope);
+  else
+    hipLaunchKernelGGL(psp_pool_conv_kernel<float>, dim3((unsigned)blocks), dim3(512), 0, s, (const float*)in, ps, V, H, W, ldi, act, slope);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// out [V][Ho][Wo][1024] = concat(f [V][Ho][Wo][512], the four stages [V][S_i][S_i][128] resized (bilinear, align_corners) to Ho x Wo)
+int launch_psp_resize_cat(int dtype, const void* f, const void* const* stages, const int* bins, void* out, int V, int Ho, int Wo, hipStream_t s) {
+  const int E = dtype_chunk(dtype);
+  RGBM_REQUIRE(V > 0 && f && out, "psp resize arguments");
+  PspStage ps{};
+  if (int rc = psp_stage_desc(bins, ps)) return rc;
+  for (int i = 0; i < 4; ++i) {
+    ps.in[i] = stages[i];
+    ps.sy[i] = Ho > 1 ? (float)(bins[i] - 1) / (float)(Ho - 1) : 0.f;
+    ps.sx[i] = Wo > 1 ? (float)(bins[i] - 1) / (float)(Wo - 1) : 0.f;
+  }
+  const long long total = (long long)V * Ho * Wo * (1024 / E);
+  if (dtype == BF16)
+    hipLaunchKernelGGL(psp_resize_cat_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s, (const unsigned short*)f, ps, (unsigned short*)out, V, Ho, Wo);
+  else if (dtype == F16)
+    hipLaunchKernelGGL(psp_resize_cat_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const f16_t*)f, ps, (f16_t*)out, V, Ho, Wo);
+  else if (dtype == BF16X3)
+    hipLaunchKernelGGL(psp_resize_cat_kernel<bx3_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bx3_t*)f, ps, (bx3_t*)out, V, Ho, Wo);
+  else
+    hipLaunchKernelGGL(psp_resize_cat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)f, ps, (float*)out, V, Ho, Wo);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- plane-sweep homography (network_v5.py:390-392)
 // proj = P_src @ inverse(P_ref).  The 4x4 inverse is done in fp64 (Gauss-Jordan, partial pivoting) and
 // rounded to fp32; the product is accumulated in fp32 like torch.matmul.  out[v] = {rot[9] row-major, trans[3]}.

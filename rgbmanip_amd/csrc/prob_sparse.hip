@@ -522,13 +522,15 @@ int sparse_mask_offset(int S, int layer) {      // layer: 0 = sweep, 1..5 = conv
                    case 5: return L.o5; case 7: return L.o7; case 8: return L.o9; default: return -1; }
 }
 
-__global__ __launch_bounds__(256) void sparse_mask_kernel(const int* __restrict__ choose, int v0, int P, int S, SparseMaskLayout L,
+__global__ __launch_bounds__(1024) void sparse_mask_kernel(const int* __restrict__ choose, int v0, int P, int S, SparseMaskLayout L,
                                                           unsigned char* __restrict__ masks, int* __restrict__ view_count) {
+  // one point per thread (1024 threads): a point marks up to a few dozen tiles byte by byte; with four points per thread the launch was
+  // 20 us of a 1.26 ms forward at B = 1
   __shared__ unsigned char m[2048];
   const int vl = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < L.total; i += 256) m[i] = 0;
+  for (int i = tid; i < L.total; i += 1024) m[i] = 0;
   __syncthreads();
-  for (int p = tid; p < P; p += 256) {
+  for (int p = tid; p < P; p += 1024) {
     const int pix = choose[(long long)(v0 + vl) * P + p];
     const int y = pix / S, x = pix - y * S;
     const Cone r = cone_of(y, S), c = cone_of(x, S);
@@ -542,15 +544,19 @@ __global__ __launch_bounds__(256) void sparse_mask_kernel(const int* __restrict_
     mark(m + L.o9, L.n3, r.u9, c.u9, 4, 0, 4, 0);
   }
   __syncthreads();
-  for (int i = tid; i < L.total; i += 256) masks[(long long)vl * L.total + i] = m[i];
+  for (int i = tid; i < L.total; i += 1024) masks[(long long)vl * L.total + i] = m[i];
   // this view's number of sweep tiles (the list kernel's offsets)
   int c = 0;
-  for (int i = tid; i < L.n0h * L.n0w; i += 256) c += m[L.o0 + i];
+  for (int i = tid; i < L.n0h * L.n0w; i += 1024) c += m[L.o0 + i];
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  __shared__ int wsum[4];
+  __shared__ int wsum[16];
   if ((tid & 63) == 0) wsum[tid >> 6] = c;
   __syncthreads();
-  if (tid == 0) view_count[1 + vl] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) {
+    int t = 0;
+    for (int q = 0; q < 16; ++q) t += wsum[q];
+    view_count[1 + vl] = t;
+  }
 }
 
 // needed tiles of the depth-sweeping conv0 in ascending order: list[i] = (view * n0h + row tile) * n0w + column tile, count[0] = how many.
@@ -594,7 +600,7 @@ int launch_sparse_masks(const int* choose, int v0, int Vc, int P, int S, unsigne
   RGBM_REQUIRE(choose && masks && sweep_list && sweep_count && S % 8 == 0 && S >= 16 && Vc > 0, "sparse masks arguments");
   const SparseMaskLayout L = sparse_mask_layout(S);
   RGBM_REQUIRE(L.total <= 2048, "sparse masks: crop too large for the mask kernel's LDS table");
-  hipLaunchKernelGGL(sparse_mask_kernel, dim3((unsigned)Vc), dim3(256), 0, s, choose, v0, P, S, L, masks, sweep_count);
+  hipLaunchKernelGGL(sparse_mask_kernel, dim3((unsigned)Vc), dim3(1024), 0, s, choose, v0, P, S, L, masks, sweep_count);
   hipLaunchKernelGGL(sparse_sweep_list_kernel, dim3((unsigned)Vc), dim3(256), 0, s, masks, Vc, L, sweep_list, sweep_count);
   RGBM_CHECK_HIP(hipGetLastError());
   return 0;

@@ -752,6 +752,37 @@ def test_device_control_queue_with_hip_estimator():
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "bf16x3", "fp32"])
+def test_psp_stage_paths_agree(dtype):
+    """PSP stage (pspnet.py:76-94).  Round 6: the concat (backbone channels + the four resized stages) is ONE launch at any batch size,
+    and up to 32 views the pooling and the four 512 -> 128 convs are one launch on the vector pipe.  Against the rounds 1-5 sequence
+    (debug flag 1024: copy, pooling, four GEMM launches, four resizes): 34 views — `cat` bit for bit (same pooling, same GEMMs, the
+    resize arithmetic is the same expression); 4 views — channels 0..511 bit for bit, the stage channels to the storage type's rounding
+    (fp32 FMAs + a lane butterfly instead of the MFMA's sums over the same rounded operands)."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    for B in (2, 17):
+        inp = synth.adapose_inputs(B, seed=6)
+        cats = {}
+        for flag in (0, 1024):
+            _lib.check(lib.rgbm_debug_flags(flag))
+            try:
+                net = _net(dtype)
+                _run(net, inp, stop_after=1)      # (the cost-volume phase reuses the PSPNet buffers: taps are read behind a forward that stops there)
+                cats[flag] = net.fetch(B, "cat", 2 * B * 28 * 28 * 1024).view(2 * B, 28, 28, 1024).cpu().numpy()
+            finally:
+                _lib.check(lib.rgbm_debug_flags(0))
+        a, b = cats[0], cats[1024]
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a[..., :512], b[..., :512])
+        if B == 17:
+            np.testing.assert_array_equal(a, b)
+        else:
+            tol = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10, "bf16x3": 2e-5, "fp32": 2e-6}[dtype]
+            scale = np.abs(b[..., 512:]).max()
+            assert scale > 0 and np.abs(a[..., 512:] - b[..., 512:]).max() <= tol * scale, (dtype, np.abs(a[..., 512:] - b[..., 512:]).max(), scale)
+
+
 def test_bf16_batch_invariance_across_kernel_selection():
     """bf16, B = 9 in two cost-volume chunks (max 10 views) against the same poses run one by one: the batched run takes the
     persistent kernels for more layers (their M >= 65536 rule) and a ragged last chunk; results may differ only by fp32
