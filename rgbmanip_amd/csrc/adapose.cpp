@@ -630,13 +630,28 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
 
   const int Vh = view2_heads ? V : B;      // views that get heads: both crops of every pose, or the view-1 crops only (option view2_heads)
   // ---- per-point NOCS branch (network_v5.py:432-444) ----
-  if (int rc = launch_gather_points(fdt, featg, bf.choose, bf.X0, Vh, P, S * S, 32, s)) return rc;
-  if (int rc = inst.run(bf.X0, bf.X1, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[0].run(bf.X1, bf.H128, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[1].run(bf.H128, bf.H64, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = nh[2].run(bf.H64, bf.nocs4, Vh, 1, 1, P, 4, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = npm[0].run(bf.nocs4, bf.N32, Vh, 1, 1, P, 32, nullptr, 0, nullptr, 0, s)) return rc;
-  if (int rc = npm[1].run(bf.N32, bf.PF96 + 32, Vh, 1, 1, P, 96, nullptr, 0, nullptr, 0, s)) return rc;
+  const ConvLayer* pl[6] = {&inst, &nh[0], &nh[1], &nh[2], &npm[0], &npm[1]};
+  bool fused = !(g_debug_flags & 2048) && ((long long)Vh * P) % 64 == 0;
+  for (int l = 0; l < 6; ++l) fused = fused && pl[l]->dtype == F32 && pl[l]->packs.size() == 1;
+  if (fused) {
+    // gather + the six layers in one launch (head_kernels.hip): a wave carries 16 points through the whole branch, weights and activations in LDS
+    PointMlpDesc pd{};
+    for (int l = 0; l < 6; ++l) {
+      pd.w[l] = (const float*)pl[l]->packs[0].w; pd.b[l] = pl[l]->bias;
+      pd.kpad[l] = pl[l]->packs[0].Kpad; pd.wrows[l] = pl[l]->Cout_pad; pd.brows[l] = pl[l]->Cout_pad;
+    }
+    pd.feat = featg; pd.choose = bf.choose; pd.nocs4 = bf.nocs4; pd.pf = bf.PF96 + 32; pd.ldpf = 96; pd.P = P; pd.HW = S * S;
+    pd.N = (long long)Vh * P;
+    if (int rc = launch_point_mlp(fdt, pd, s)) return rc;
+  } else {
+    if (int rc = launch_gather_points(fdt, featg, bf.choose, bf.X0, Vh, P, S * S, 32, s)) return rc;
+    if (int rc = inst.run(bf.X0, bf.X1, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = nh[0].run(bf.X1, bf.H128, Vh, 1, 1, P, 128, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = nh[1].run(bf.H128, bf.H64, Vh, 1, 1, P, 64, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = nh[2].run(bf.H64, bf.nocs4, Vh, 1, 1, P, 4, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = npm[0].run(bf.nocs4, bf.N32, Vh, 1, 1, P, 32, nullptr, 0, nullptr, 0, s)) return rc;
+    if (int rc = npm[1].run(bf.N32, bf.PF96 + 32, Vh, 1, 1, P, 96, nullptr, 0, nullptr, 0, s)) return rc;
+  }
 
   // ---- plane-sweep cost volume -> probability at the sampled pixels -> depth ----
   if (int rc = cost_volume(bf, V, B, depths, s)) return rc;

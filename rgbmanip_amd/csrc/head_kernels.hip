@@ -47,6 +47,155 @@ int launch_gather_points(int dtype, const void* feat, const int* choose, float* 
   return 0;
 }
 
+// ---------------------------------------------------------------- the per-point NOCS branch in one kernel (network_v5.py:432-444)
+// gather feat at choose -> instance_color (32 -> 64, ReLU) -> nocs_head (64 -> 128 ReLU -> 64 ReLU -> 3 Tanh) -> nocs_pts_mlp (3 -> 32 ReLU
+// -> 64 ReLU, written into channels 32..95 of the pose feature).  Rounds 1-5 ran it as a gather launch and six fp32 implicit-GEMM launches
+// of 32..128 channels: 65 us of a 1.2 ms forward at B = 1 and 0.55 ms of a batch-256 step at a few per cent of the fp32 matrix pipe, the
+// five intermediate tensors (1.2 GB at batch 256) written and read back.  Here a wave carries 16 points through all six layers: the
+// weights (88 KB of fp32, in MFMA-fragment order: one ds_read_b128 per lane feeds four v_mfma_f32_16x16x4_f32) and a wave's two activation
+// buffers ([channel][16 points], so that a B operand is one contiguous ds_read_b32 per K step) live in LDS; four output-channel tiles
+// accumulate side by side (independent accumulators hide the MFMA's latency behind the one wave per SIMD); bias and activation as in the
+// GEMM epilogue (fp32 sums over ascending K, bias added behind them).  One workgroup of four waves per CU walks 64-point tiles.
+// Layers 3 / 4 (64 -> 3 and 3 -> 32) run on a 16-channel tile with zero weights beyond channel 2: tanh(0) = 0 there, and 0 * 0 adds nothing.
+
+namespace pmlp {
+constexpr int NL = 6;
+constexpr int cin(int l) { return l == 0 ? 32 : l == 1 ? 64 : l == 2 ? 128 : l == 3 ? 64 : l == 4 ? 16 : 32; }      // K of a layer's MFMA chain (layer 4: 3 real + 13 zero)
+constexpr int cout(int l) { return l == 0 ? 64 : l == 1 ? 128 : l == 2 ? 64 : l == 3 ? 16 : l == 4 ? 32 : 64; }     // (layer 3: 3 real + 13 zero)
+constexpr int act(int l) { return l == 3 ? ACT_TANH : ACT_RELU; }
+constexpr int w_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += cin(i) * cout(i); return o; }
+constexpr int b_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += cout(i); return o; }
+constexpr int W_FLOATS = w_off(NL), B_FLOATS = b_off(NL);
+constexpr int ACT_A = 128 * 16, ACT_B = 64 * 16;          // floats of a wave's two activation buffers (layer inputs 0 / 2 / 4 in A, 1 / 3 / 5 in B)
+constexpr size_t LDS_BYTES = (size_t)(W_FLOATS + B_FLOATS + 4 * (ACT_A + ACT_B)) * sizeof(float);
+}  // namespace pmlp
+
+template <int L>
+__device__ __forceinline__ void pmlp_layer(const float* __restrict__ wl, const float* __restrict__ bl, const float* __restrict__ xin,
+                                           float* __restrict__ xout, int lane, float* __restrict__ gout4, float* __restrict__ gout64, int ldg) {
+  using namespace pmlp;
+  constexpr int CI = cin(L), CO = cout(L), KS4 = CI / 16, NT = CO / 16, G = NT < 4 ? NT : 4, AC = act(L);
+  const float* wf = wl + w_off(L);
+  const float* bf = bl + b_off(L);
+#pragma unroll
+  for (int t0 = 0; t0 < NT; t0 += G) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < KS4; ++k4) {
+      float bx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bx[j] = xin[(k4 * 4 + j) * 64 + lane];                      // X[k = 16 k4 + 4 j + lane / 16][point lane % 16]
+      f32x4 a[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(wf + (((t0 + g) * KS4 + k4) * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][j], bx[j], acc[g], 0, 0, 0);
+    }
+    // rows 4 (lane / 16) + i of tile t0 + g, point lane % 16
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int ch = (t0 + g) * 16 + 4 * (lane >> 4);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bf + ch);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = acc[g][i] + bv[i];
+        v[i] = AC == ACT_RELU ? (r < 0.f ? 0.f : r) : AC == ACT_TANH ? tanhf(r) : r;      // NaN propagates like torch
+      }
+      if (L == 3) {
+        if (lane < 16) *reinterpret_cast<float4*>(gout4 + (long long)lane * 4) = make_float4(v[0], v[1], v[2], v[3]);      // nocs4: channels 0..3 of the tile
+      }
+      if (L == NL - 1) {
+        *reinterpret_cast<float4*>(gout64 + (long long)(lane & 15) * ldg + ch) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xout[(ch + i) * 16 + (lane & 15)] = v[i];
+      }
+    }
+  }
+}
+
+// weights into MFMA-fragment order: slot ((t * KS4 + k4) * 64 + lane) * 4 + j = W[16 t + lane % 16][16 k4 + 4 j + lane / 16]
+template <int L>
+__device__ __forceinline__ void pmlp_load(const PointMlpDesc& d, float* __restrict__ wl, float* __restrict__ bl, int tid) {
+  using namespace pmlp;
+  constexpr int CI = cin(L), CO = cout(L), KS4 = CI / 16;
+  const float* __restrict__ w = d.w[L];
+  for (int i = tid; i < CI * CO; i += 256) {
+    const int j = i & 3, ln = (i >> 2) & 63, q = i >> 8;
+    const int k4 = q % KS4, t = q / KS4;
+    const int row = 16 * t + (ln & 15), k = 16 * k4 + 4 * j + (ln >> 4);
+    wl[w_off(L) + i] = (row < d.wrows[L] && k < d.kpad[L]) ? w[(long long)row * d.kpad[L] + k] : 0.f;
+  }
+  for (int i = tid; i < CO; i += 256) bl[b_off(L) + i] = (d.b[L] != nullptr && i < d.brows[L]) ? d.b[L][i] : 0.f;
+}
+
+template <typename TF>
+__global__ __launch_bounds__(256) void point_mlp_kernel(const PointMlpDesc d) {
+  using namespace pmlp;
+  extern __shared__ __attribute__((aligned(16))) float pm_lds[];
+  float* wl = pm_lds;
+  float* bl = wl + W_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* xa = bl + B_FLOATS + wave * (ACT_A + ACT_B);
+  float* xb = xa + ACT_A;
+  pmlp_load<0>(d, wl, bl, tid); pmlp_load<1>(d, wl, bl, tid); pmlp_load<2>(d, wl, bl, tid);
+  pmlp_load<3>(d, wl, bl, tid); pmlp_load<4>(d, wl, bl, tid); pmlp_load<5>(d, wl, bl, tid);
+  __syncthreads();
+  const TF* __restrict__ feat = reinterpret_cast<const TF*>(d.feat);
+  const long long ntile = d.N / 64;
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long long p0 = tile * 64 + wave * 16;            // this wave's 16 points
+    // gather: 16 points x 8 four-channel groups = 128 loads, two per lane
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int q = lane + 64 * r, pt = q >> 3, c4 = q & 7;
+      const long long vp = p0 + pt;
+      const long long v = vp / d.P;
+      const int pix = d.choose[vp];
+      float x[4];
+      load4(feat + (v * d.HW + pix) * 32 + c4 * 4, x);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xa[(c4 * 4 + e) * 16 + pt] = x[e];
+    }
+    // (wave-private buffers: a wave's LDS writes are seen by its own later reads in program order, no barrier)
+    pmlp_layer<0>(wl, bl, xa, xb, lane, nullptr, nullptr, 0);
+    pmlp_layer<1>(wl, bl, xb, xa, lane, nullptr, nullptr, 0);
+    pmlp_layer<2>(wl, bl, xa, xb, lane, nullptr, nullptr, 0);
+    pmlp_layer<3>(wl, bl, xb, xa, lane, d.nocs4 + p0 * 4, nullptr, 0);
+    pmlp_layer<4>(wl, bl, xa, xb, lane, nullptr, nullptr, 0);
+    pmlp_layer<5>(wl, bl, xb, xa, lane, nullptr, d.pf + p0 * d.ldpf, d.ldpf);
+  }
+}
+
+int launch_point_mlp(int feat_dtype, const PointMlpDesc& d, hipStream_t s) {
+  RGBM_REQUIRE(d.N > 0 && d.N % 64 == 0 && d.P > 0 && d.ldpf % 4 == 0, "point MLP: V * P must be a multiple of 64");
+  static_assert(pmlp::LDS_BYTES <= 160 * 1024, "point MLP: weights + four waves' activations must fit the LDS");
+  int n_cu = 0;
+  if (int rc = persistent_grid_cus(&n_cu)) return rc;
+  const long long ntile = d.N / 64;
+  const unsigned grid = (unsigned)(ntile < n_cu ? ntile : n_cu);
+  const void* fn = feat_dtype == BF16 ? reinterpret_cast<const void*>(point_mlp_kernel<unsigned short>)
+                   : feat_dtype == F16 ? reinterpret_cast<const void*>(point_mlp_kernel<f16_t>)
+                   : feat_dtype == BF16X3 ? reinterpret_cast<const void*>(point_mlp_kernel<bx3_t>)
+                                          : reinterpret_cast<const void*>(point_mlp_kernel<float>);
+  if (int rc = ensure_dynamic_lds(fn, (int)pmlp::LDS_BYTES)) return rc;
+  if (feat_dtype == BF16)
+    hipLaunchKernelGGL(point_mlp_kernel<unsigned short>, dim3(grid), dim3(256), pmlp::LDS_BYTES, s, d);
+  else if (feat_dtype == F16)
+    hipLaunchKernelGGL(point_mlp_kernel<f16_t>, dim3(grid), dim3(256), pmlp::LDS_BYTES, s, d);
+  else if (feat_dtype == BF16X3)
+    hipLaunchKernelGGL(point_mlp_kernel<bx3_t>, dim3(grid), dim3(256), pmlp::LDS_BYTES, s, d);
+  else
+    hipLaunchKernelGGL(point_mlp_kernel<float>, dim3(grid), dim3(256), pmlp::LDS_BYTES, s, d);
+  RGBM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- sparse prob conv + softmax + depth
 // prob = Conv3d(8->1, 3^3, pad 1, no bias) evaluated only at the P chosen pixels x D depths
 // (network_v5.py:280,290,449-455); softmax over depth; depth = sum p*d (network_v5.py:293-299).

@@ -54,6 +54,19 @@ int launch_stem(int dtype, const float* img1, const float* img2, const void* wpk
 int launch_f32_to_bx3(const float* in, void* out, long long n, hipStream_t s);     // plain fp32 -> split pairs (n % 4 == 0; in place allowed)
 int launch_view_linear(const float* x, const float* W, const float* bias, float* out, int V, int I, int O, int ldw, int i0,
                        int relu, hipStream_t s);
+// head_kernels.hip: gather + the six per-point layers of the NOCS branch in one launch
+struct PointMlpDesc {
+  const float* w[6];       // [rows >= Cout][kpad] fp32, K contiguous (ConvLayer::packs[0].w)
+  const float* b[6];       // [Cout_pad] or null
+  int kpad[6], wrows[6], brows[6];   // row stride / rows present of w / entries of b
+  const void* feat;        // [V][HW][32] in the feature map's storage type
+  const int* choose;       // [V * P]
+  float* nocs4;            // [V * P][4]
+  float* pf;               // channel 0 of the 64 output channels, row stride ldpf
+  int ldpf, P, HW;
+  long long N;             // V * P, a multiple of 64
+};
+int launch_point_mlp(int feat_dtype, const PointMlpDesc& d, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
 // consumers that finish a mean over points themselves (one launch less per mean): launch_mean_points_partial writes the slices' sums
 int launch_mean_points_partial(int dtype, const void* in, float* scratch, int V, int P, int C, hipStream_t s);

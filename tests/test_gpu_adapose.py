@@ -783,6 +783,36 @@ def test_psp_stage_paths_agree(dtype):
             assert scale > 0 and np.abs(a[..., 512:] - b[..., 512:]).max() <= tol * scale, (dtype, np.abs(a[..., 512:] - b[..., 512:]).max(), scale)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "bf16x3", "fp32"])
+def test_point_mlp_matches_the_per_layer_launches(dtype):
+    """Per-point NOCS branch (network_v5.py:432-444): point_mlp_kernel (gather + six fp32 layers in one launch, weights and activations in
+    LDS) against the rounds 1-5 sequence (debug flag 2048: gather + six implicit-GEMM launches of the same fp32 layers).  Same fp32
+    products; the sums may associate differently: nocs to fp32 rounding, and what is computed from the branch's 64 output channels
+    (r / t / s through the pose MLP, which bf16 / fp16 nets run in fp16 storage) to that storage's rounding.  Depth does not depend on it."""
+    from rgbmanip_amd import _lib
+    lib = _lib.load()
+    inp = synth.adapose_inputs(3, seed=8)
+    outs = {}
+    for flag in (0, 2048):
+        _lib.check(lib.rgbm_debug_flags(flag))
+        try:
+            outs[flag] = _run(_net(dtype), inp)
+        finally:
+            _lib.check(lib.rgbm_debug_flags(0))
+    a, b = outs[0], outs[2048]
+    errs = {k: _rel(a[k], b[k]) for k in OUT_KEYS}
+    print(dtype, "fused point MLP vs per-layer launches:", errs)
+    for k in OUT_KEYS:
+        assert np.isfinite(a[k]).all(), k
+        kind = k.split("_")[1]
+        if kind == "depth":
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        elif kind == "nocs":
+            assert errs[k] < 2e-6, (k, errs)
+        else:
+            assert errs[k] < (1e-5 if dtype in ("fp32", "bf16x3") else 2e-3), (k, errs)
+
+
 def test_bf16_batch_invariance_across_kernel_selection():
     """bf16, B = 9 in two cost-volume chunks (max 10 views) against the same poses run one by one: the batched run takes the
     persistent kernels for more layers (their M >= 65536 rule) and a ragged last chunk; results may differ only by fp32
