@@ -210,6 +210,20 @@ int AdaPose::create(const StateDict& sd, int dtype_, int norm_mode_) {
   if (int rc = init_linear(nh[2], sd, "nocs_head.4", 64, 3, ACT_TANH, 64, 4)) return rc;
   if (int rc = init_linear(npm[0], sd, "nocs_pts_mlp.0", 3, 32, ACT_RELU, 4, 32)) return rc;
   if (int rc = init_linear(npm[1], sd, "nocs_pts_mlp.2", 32, 64, ACT_RELU, 32, 64)) return rc;
+  {
+    // the same six layers as one LDS image for point_mlp_kernel (head_kernels.hip)
+    static const char* const names[6] = {"instance_color.0", "nocs_head.0", "nocs_head.2", "nocs_head.4", "nocs_pts_mlp.0", "nocs_pts_mlp.2"};
+    static const int cin[6] = {32, 64, 128, 64, 3, 32}, cout[6] = {64, 128, 64, 3, 32, 64};
+    const float* w[6]; const float* b[6];
+    for (int l = 0; l < 6; ++l) {
+      GET(wt, std::string(names[l]) + ".weight"); GET(bt, std::string(names[l]) + ".bias");
+      RGBM_REQUIRE(wt->numel() == (long long)cin[l] * cout[l] && bt->numel() == cout[l], std::string("point MLP shape ") + names[l]);
+      w[l] = wt->data; b[l] = bt->data;
+    }
+    std::vector<float> table((size_t)point_mlp_table_floats());
+    point_mlp_pack(w, b, table.data());
+    if (upload_f32(table.data(), table.size(), &pmlp_table)) return -2;
+  }
   if (int rc = init_linear(pm1[0], sd, "pose_mlp1.0", 96, 128, ACT_RELU, 96, 128, nullptr, pose_dtype())) return rc;
   if (int rc = init_linear(pm1[1], sd, "pose_mlp1.2", 128, 128, ACT_RELU, 128, 128, nullptr, pose_dtype())) return rc;
   {
@@ -267,6 +281,7 @@ void AdaPose::destroy() {
   w11_taps = nullptr;
   if (wprob) (void)hipFree(wprob);
   if (pm2_0_wfull) (void)hipFree(pm2_0_wfull);
+  if (pmlp_table) { (void)hipFree(pmlp_table); pmlp_table = nullptr; }
   if (pm2_0_bias) (void)hipFree(pm2_0_bias);
   for (int h = 0; h < 3; ++h) for (int l = 0; l < 3; ++l) { if (head_w[h][l]) (void)hipFree(head_w[h][l]); if (head_b[h][l]) (void)hipFree(head_b[h][l]); }
 }
@@ -630,17 +645,10 @@ int AdaPose::forward(int B, const float* img1, const float* img2, const int* cho
 
   const int Vh = view2_heads ? V : B;      // views that get heads: both crops of every pose, or the view-1 crops only (option view2_heads)
   // ---- per-point NOCS branch (network_v5.py:432-444) ----
-  const ConvLayer* pl[6] = {&inst, &nh[0], &nh[1], &nh[2], &npm[0], &npm[1]};
-  bool fused = !(g_debug_flags & 2048) && ((long long)Vh * P) % 64 == 0;
-  for (int l = 0; l < 6; ++l) fused = fused && pl[l]->dtype == F32 && pl[l]->packs.size() == 1;
-  if (fused) {
+  if (pmlp_table != nullptr && !(g_debug_flags & 2048) && ((long long)Vh * P) % 64 == 0) {
     // gather + the six layers in one launch (head_kernels.hip): a wave carries 16 points through the whole branch, weights and activations in LDS
     PointMlpDesc pd{};
-    for (int l = 0; l < 6; ++l) {
-      pd.w[l] = (const float*)pl[l]->packs[0].w; pd.b[l] = pl[l]->bias;
-      pd.kpad[l] = pl[l]->packs[0].Kpad; pd.wrows[l] = pl[l]->Cout_pad; pd.brows[l] = pl[l]->Cout_pad;
-    }
-    pd.feat = featg; pd.choose = bf.choose; pd.nocs4 = bf.nocs4; pd.pf = bf.PF96 + 32; pd.ldpf = 96; pd.P = P; pd.HW = S * S;
+    pd.table = pmlp_table; pd.feat = featg; pd.choose = bf.choose; pd.nocs4 = bf.nocs4; pd.pf = bf.PF96 + 32; pd.ldpf = 96; pd.P = P; pd.HW = S * S;
     pd.N = (long long)Vh * P;
     if (int rc = launch_point_mlp(fdt, pd, s)) return rc;
   } else {

@@ -68,6 +68,7 @@ struct AdaPose {
   float* wprob = nullptr;
   ConvLayer inst, nh[3], npm[2], pm1[2], pm2[2];
   float* pm2_0_wfull = nullptr;
+  float* pmlp_table = nullptr;    // the per-point NOCS branch's six layers as point_mlp_kernel's LDS image (kernels.h: point_mlp_pack)
   float* pm2_0_bias = nullptr;
   float* head_w[3][3] = {{nullptr}};
   float* head_b[3][3] = {{nullptr}};

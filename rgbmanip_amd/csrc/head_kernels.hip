@@ -119,21 +119,6 @@ __device__ __forceinline__ void pmlp_layer(const float* __restrict__ wl, const f
   }
 }
 
-// weights into MFMA-fragment order: slot ((t * KS4 + k4) * 64 + lane) * 4 + j = W[16 t + lane % 16][16 k4 + 4 j + lane / 16]
-template <int L>
-__device__ __forceinline__ void pmlp_load(const PointMlpDesc& d, float* __restrict__ wl, float* __restrict__ bl, int tid) {
-  using namespace pmlp;
-  constexpr int CI = cin(L), CO = cout(L), KS4 = CI / 16;
-  const float* __restrict__ w = d.w[L];
-  for (int i = tid; i < CI * CO; i += 256) {
-    const int j = i & 3, ln = (i >> 2) & 63, q = i >> 8;
-    const int k4 = q % KS4, t = q / KS4;
-    const int row = 16 * t + (ln & 15), k = 16 * k4 + 4 * j + (ln >> 4);
-    wl[w_off(L) + i] = (row < d.wrows[L] && k < d.kpad[L]) ? w[(long long)row * d.kpad[L] + k] : 0.f;
-  }
-  for (int i = tid; i < CO; i += 256) bl[b_off(L) + i] = (d.b[L] != nullptr && i < d.brows[L]) ? d.b[L][i] : 0.f;
-}
-
 template <typename TF>
 __global__ __launch_bounds__(256) void point_mlp_kernel(const PointMlpDesc d) {
   using namespace pmlp;
@@ -143,8 +128,8 @@ __global__ __launch_bounds__(256) void point_mlp_kernel(const PointMlpDesc d) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* xa = bl + B_FLOATS + wave * (ACT_A + ACT_B);
   float* xb = xa + ACT_A;
-  pmlp_load<0>(d, wl, bl, tid); pmlp_load<1>(d, wl, bl, tid); pmlp_load<2>(d, wl, bl, tid);
-  pmlp_load<3>(d, wl, bl, tid); pmlp_load<4>(d, wl, bl, tid); pmlp_load<5>(d, wl, bl, tid);
+  // the table (weights in MFMA-fragment order, then the biases: point_mlp_pack) as it lies in memory: 16-byte copies, all of a thread's in flight
+  for (int i = tid; i < (W_FLOATS + B_FLOATS) / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(d.table)[i];
   __syncthreads();
   const TF* __restrict__ feat = reinterpret_cast<const TF*>(d.feat);
   const long long ntile = d.N / 64;
@@ -172,8 +157,28 @@ __global__ __launch_bounds__(256) void point_mlp_kernel(const PointMlpDesc d) {
   }
 }
 
+int point_mlp_table_floats() { return pmlp::W_FLOATS + pmlp::B_FLOATS; }
+
+// host: the six layers' weights ([Cout][Cin] row-major, as the state dict holds them) and biases into the kernel's LDS image —
+// slot w_off(l) + ((t * KS4 + k4) * 64 + lane) * 4 + j = W_l[16 t + lane % 16][16 k4 + 4 j + lane / 16], zero outside the layer's shape
+void point_mlp_pack(const float* const w[6], const float* const b[6], float* table) {
+  using namespace pmlp;
+  const int cin_real[NL] = {32, 64, 128, 64, 3, 32}, cout_real[NL] = {64, 128, 64, 3, 32, 64};
+  for (int l = 0; l < NL; ++l) {
+    const int CI = cin(l), CO = cout(l), KS4 = CI / 16;
+    for (int i = 0; i < CI * CO; ++i) {
+      const int j = i & 3, ln = (i >> 2) & 63, q = i >> 8;
+      const int k4 = q % KS4, t = q / KS4;
+      const int row = 16 * t + (ln & 15), k = 16 * k4 + 4 * j + (ln >> 4);
+      table[w_off(l) + i] = (row < cout_real[l] && k < cin_real[l]) ? w[l][(size_t)row * cin_real[l] + k] : 0.f;
+    }
+    for (int i = 0; i < CO; ++i) table[W_FLOATS + b_off(l) + i] = (b[l] != nullptr && i < cout_real[l]) ? b[l][i] : 0.f;
+  }
+}
+
 int launch_point_mlp(int feat_dtype, const PointMlpDesc& d, hipStream_t s) {
-  RGBM_REQUIRE(d.N > 0 && d.N % 64 == 0 && d.P > 0 && d.ldpf % 4 == 0, "point MLP: V * P must be a multiple of 64");
+  RGBM_REQUIRE(d.N > 0 && d.N % 64 == 0 && d.P > 0 && d.ldpf % 4 == 0 && d.table, "point MLP: V * P must be a multiple of 64");
+  static_assert((pmlp::W_FLOATS + pmlp::B_FLOATS) % 4 == 0, "the table is copied in 16-byte pieces");
   static_assert(pmlp::LDS_BYTES <= 160 * 1024, "point MLP: weights + four waves' activations must fit the LDS");
   int n_cu = 0;
   if (int rc = persistent_grid_cus(&n_cu)) return rc;

@@ -56,9 +56,7 @@ int launch_view_linear(const float* x, const float* W, const float* bias, float*
                        int relu, hipStream_t s);
 // head_kernels.hip: gather + the six per-point layers of the NOCS branch in one launch
 struct PointMlpDesc {
-  const float* w[6];       // [rows >= Cout][kpad] fp32, K contiguous (ConvLayer::packs[0].w)
-  const float* b[6];       // [Cout_pad] or null
-  int kpad[6], wrows[6], brows[6];   // row stride / rows present of w / entries of b
+  const float* table;      // device: point_mlp_table_floats() floats from point_mlp_pack (weights in MFMA-fragment order, then biases)
   const void* feat;        // [V][HW][32] in the feature map's storage type
   const int* choose;       // [V * P]
   float* nocs4;            // [V * P][4]
@@ -66,6 +64,8 @@ struct PointMlpDesc {
   int ldpf, P, HW;
   long long N;             // V * P, a multiple of 64
 };
+int point_mlp_table_floats();
+void point_mlp_pack(const float* const w[6], const float* const b[6], float* table);      // host; w[l]: [Cout][Cin] row-major fp32 of instance_color.0, nocs_head.0/2/4, nocs_pts_mlp.0/2
 int launch_point_mlp(int feat_dtype, const PointMlpDesc& d, hipStream_t s);
 int launch_ortho6d(const float* r6, float* R, int V, hipStream_t s);
 // consumers that finish a mean over points themselves (one launch less per mean): launch_mean_points_partial writes the slices' sums
