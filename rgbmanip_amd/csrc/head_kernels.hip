@@ -1,10 +1,10 @@
 // Point-sampled head kernels of the AdaPose forward (network_v5.py:432-508), gfx950.
 // Everything here is fp32 (fp32 from the probability volume onward); feature maps /
-// cost-volume activations may be bf16 or f32 (template T).  The per-point MLPs themselves run
-// through the generic implicit-GEMM kernel as 1x1 convolutions; this file holds the glue:
-// gathers at `choose`, the sparse probability conv + softmax + depth regression, the depth-guided
-// fusion (re-warping only the 1024x24 samples that are consumed), reductions and the tiny
-// per-view regressors + Ortho6d.
+// cost-volume activations may be bf16 or f32 (template T).  The pose MLP's per-point layers run
+// through the implicit-GEMM kernels as 1x1 convolutions; the per-point NOCS branch is one kernel here
+// (point_mlp_kernel, round 6).  The rest is the glue: gathers at `choose`, the sparse probability
+// conv + softmax + depth regression, the depth-guided fusion (re-warping only the 1024x24 samples that
+// are consumed), reductions and the tiny per-view regressors + Ortho6d.
 #include "common.h"
 #include "kernels.h"
 
