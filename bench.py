@@ -823,7 +823,9 @@ def main():
         mixed_res = {"poses_per_sec": round(world * B * 3 / mdt, 1), "heads": list(HEADS), "batch_total": world * B,
                      "heads_on_rank0": sorted(set(int(h) for h in my_heads)),
                      "dtype": args.mixed_dtype,
-                     "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head"}
+                     "head_streams": bool(mnet.head_streams),
+                     "note": "BASELINE configs[4] layout: batch sorted by head, contiguous shard per rank, one AdaPoseNet per head, every head's samples on "
+                             "that head's own stream (MixedObjectNet(head_streams=True), bit-identical to one head after the other)"}
         del mnet
 
     _mark("mixed leg done")

@@ -24,7 +24,7 @@ class AdaPoseNet:
     def __init__(self, state_dict, dtype: str = "fp32", device: int = 0, max_chunk_views: int | None = None,
                  cost_impl: int | None = None, sparse_tail: int | None = None, options: dict | None = None,
                  norm_mode: int | str = 0, poison_workspace: bool = False, graph: bool = False, graph_max_batch: int = 32,
-                 split_streams: bool = False, split_min_batch: int = 128):
+                 split_streams: bool | int = False, split_min_batch: int = 128):
         self.lib = _lib.load()
         # graph: forwards of at most `graph_max_batch` poses are replayed from a hipGraph captured per batch size
         # (rgbm_adapose_forward_graph): static input / output / workspace buffers per batch size, one hipGraphLaunch instead of ~150
@@ -44,9 +44,11 @@ class AdaPoseNet:
         # filled by the other half's kernels (-0.7 % bf16, -2.6 % bf16x3 at batch 256).  Same kernels, same per-pose arithmetic:
         # outputs bit-identical to the one-stream forward (tests/test_gpu_at_batch.py) — which needs a library without packed fp32
         # instructions (build.sh).  Intermediate taps (fetch) refer to the one-stream workspace and are refused after a split forward.
+        # split_streams = n > 2 (round 6): n equal parts on n side streams.
         self.split_streams = bool(split_streams)
+        self.split_parts = 2 if split_streams is True else max(int(split_streams), 2)
         self.split_min_batch = int(split_min_batch)
-        self._split = None                           # ([two side streams], [two workspaces], batch)
+        self._split = None                           # ([side streams], [workspaces], batch)
         self._last_split = False
         if not torch.cuda.is_available():
             raise _lib.RgbmError("AdaPoseNet needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -183,7 +185,7 @@ class AdaPoseNet:
             "view1_t": torch.empty(B, 3, **f32), "view2_t": torch.empty(B, 3, **f32),
             "view1_s": torch.empty(B, 3, **f32), "view2_s": torch.empty(B, 3, **f32),
         }
-        if self.split_streams and stop_after == 0 and B >= self.split_min_batch and B % 2 == 0:
+        if self.split_streams and stop_after == 0 and B >= self.split_min_batch and B % self.split_parts == 0:
             self._forward_split(B, (img1, img2, ch1, ch2, P1, P2, dep), out, stream)
             return out
         self._last_split = False
@@ -199,17 +201,18 @@ class AdaPoseNet:
         return out
 
     def _forward_split(self, B, args, out, stream):
-        h = B // 2
+        n = self.split_parts
+        h = B // n
         if self._split is None or self._split[2] != B:
             self._split = None
             need = self.workspace_bytes(h) + 256
-            self._split = ([torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)],
-                           [torch.empty(need, dtype=torch.uint8, device=self.device) for _ in range(2)], B)
+            self._split = ([torch.cuda.Stream(device=self.device) for _ in range(n)],
+                           [torch.empty(need, dtype=torch.uint8, device=self.device) for _ in range(n)], B)
         side, wss, _ = self._split
         cur = stream if stream is not None else torch.cuda.current_stream(self.device)
         fork = torch.cuda.Event()
         fork.record(cur)
-        for i in (0, 1):
+        for i in range(n):
             si, ws = side[i], wss[i]
             si.wait_event(fork)                       # inputs (and the previous use of the outputs) are ordered on `cur`
             off = (-ws.data_ptr()) % 256

@@ -848,7 +848,7 @@ def test_mixed_object_batch_equals_per_head_runs(dtype):
     sds = {h: synth.adapose_state_dict(seed=10 + h, prefix="module.") for h in range(4)}
     inp = synth.adapose_inputs(8, seed=21)
     heads = np.array([2, 0, 3, 1, 0, 2, 1, 3])
-    mixed = MixedObjectNet(sds, dtype=dtype)
+    mixed = MixedObjectNet(sds, dtype=dtype, head_streams=False)
     keys = ("img1", "choose1", "img2", "choose2", "P1", "P2", "depths")
     got = {k: v.cpu().numpy() for k, v in mixed(heads, *[inp[k] for k in keys]).items()}
     for h in range(4):
@@ -862,6 +862,14 @@ def test_mixed_object_batch_equals_per_head_runs(dtype):
         part = MixedObjectNet(sds, dtype=dtype)(heads[idx], *[inp[k][idx] for k in keys])
         for k in OUT_KEYS:
             np.testing.assert_array_equal(part[k].cpu().numpy(), got[k][idx], err_msg=f"rank {r} {k}")
+    # every head on its own stream (head_streams, the default: the heads' kernels overlap on the device): the same numbers, three times over
+    streamed = MixedObjectNet(sds, dtype=dtype)
+    assert streamed.head_streams
+    for rep in range(3):
+        o = streamed(heads, *[inp[k] for k in keys])
+        torch.cuda.synchronize()
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(o[k].cpu().numpy(), got[k], err_msg=f"head_streams run {rep} {k}")
 
 
 def test_fp16_sweep_conv0_stable_and_matches_tile_conv0(inputs):
