@@ -246,6 +246,10 @@ struct ConvDesc {
   const void* w2; const float* bias2; void* out2; int ldo2, cout2, kpad2, act2; float slope2;
   double algo_flops, algo_bytes;          // algorithmic work of this launch (profiling only)
   int out_f32;                            // bf16x3 tensors, generic kernel only: write the result as PLAIN fp32 (same 4-byte slots) instead of split pairs
+  // conv_igemm_m32_kernel, 128-pixel tiles, launches of few tiles (small batches): the K loop of a tile is cut into `ksplit` parts, one workgroup
+  // each; a part leaves its fp32 accumulators in kscratch, the LAST of a tile's parts to arrive (kcount, per tile and multiply wave) adds the
+  // parts in ascending order and runs the epilogue (conv_igemm_m32.inc).  0 / 1 = no split.
+  int ksplit; float* kscratch; unsigned* kcount;
 };
 
 int launch_conv(const ConvDesc& d, int dtype, hipStream_t s);

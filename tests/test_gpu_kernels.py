@@ -178,6 +178,9 @@ def test_conv2d_gemm_kernel_variants(case, dtype):
         ref = ref + res
     ys = {}
     try:
+        # (debug flag 16384: no K split — a launch of few tiles cuts its K loop into parts whose number depends on the tile count, i.e. on
+        # the kernel variant; the split form is checked below)
+        lib.rgbm_debug_flags(16384)
         for kern in (0, 1, 2, 2, 2):
             _lib.check(lib.rgbm_set_tuning(b"gemm_kernel", kern), "gemm_kernel")
             y = conv_nd(dtype, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25)
@@ -187,8 +190,44 @@ def test_conv2d_gemm_kernel_variants(case, dtype):
                 assert torch.equal(y, ys[kern]), (name, kern, "run-to-run")
             ys[kern] = y
     finally:
+        lib.rgbm_debug_flags(0)
         lib.rgbm_set_tuning(b"gemm_kernel", 2)
     assert torch.equal(ys[1], ys[2]), name      # incl. the residual: both tile sizes add it on the matrix pipe (identity K steps)
+    # default dispatch (K split where the tiles fill at most half the CUs: partial sums in fp32 scratch, added in a fixed order by the last
+    # part to arrive): same products, another association of the fp32 sums, and the same bits run after run whichever part arrives last
+    ysp = [conv_nd(dtype, x, w, stride=stride, pad=pad, dil=dil, bias=b, res=res, res_mode=res_mode, act=act, slope=0.25) for _ in range(4)]
+    for y in ysp:
+        assert torch.isfinite(y).all() and rel_err(y, ref) < TOL[dtype], name
+        assert torch.equal(y, ysp[0]), (name, "K split run-to-run")
+    assert rel_err(ysp[0], ys[2]) < {_lib.BF16: 2.0 ** -7, _lib.F16: 2.0 ** -10, _lib.BF16X3: 1e-5}[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16, _lib.BF16X3], ids=["bf16", "fp16", "bf16x3"])
+def test_conv2d_k_split_is_stable_over_many_runs(dtype):
+    """The K split of launches with few tiles (conv_igemm_m32.inc: parts of a tile's K loop on different workgroups — on any XCD —, partial
+    sums through a scratch buffer with device-scope accesses, an arrival counter per tile and wave, the last part to arrive adds all parts
+    in ascending order): layer3's and layer4's shapes at one pose (52 tiles x 4 parts, 104 x 2), 150 launches each — every result equals
+    the first, and equals the unsplit launch to the storage type's rounding.  A partial sum read before it was visible, or a counter not
+    left at zero, shows up here."""
+    from gpu_util import conv_nd, rel_err
+    lib = _lib.load()
+    for name, N, Cin, H, W, Cout, k, dil in (("layer3_b1", 2, 256, 28, 28, 256, 3, 2), ("layer4_b1", 2, 512, 28, 28, 512, 3, 4)):
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+        x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+        w = _q(torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k), dtype)
+        res = _q(torch.randn(N, Cout, H, W, generator=g), dtype)
+        run = lambda: conv_nd(dtype, x, w, stride=1, pad=dil, dil=dil, bias=None, res=res, res_mode=1, act=1)      # noqa: E731
+        try:
+            lib.rgbm_debug_flags(16384)
+            y_one = run()
+        finally:
+            lib.rgbm_debug_flags(0)
+        y0 = run()
+        assert torch.isfinite(y0).all()
+        assert not torch.equal(y0, y_one) or dtype == _lib.BF16X3, (name, "the default launch of this shape is expected to split K")
+        assert rel_err(y0, y_one) < {_lib.BF16: 2.0 ** -7, _lib.F16: 2.0 ** -10, _lib.BF16X3: 1e-5}[dtype], name
+        for i in range(150):
+            assert torch.equal(run(), y0), (name, i)
 
 
 @pytest.mark.parametrize("name", ["l2_3x3_s2", "up_prelu", "ws128_res_pre", "ws128_1x1_s1", "ws64_prelu_bias", "ws64_rowhalo_dil2",
