@@ -37,6 +37,7 @@ hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t)
 // stream capture / graphs: handles are small heap blocks (so leaks and double frees of the library's graph cache are visible to the
 // sanitizer); a "captured" stream still executes nothing, like every launch of this stand-in
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = reinterpret_cast<hipGraph_t>(std::malloc(8)); return hipSuccess; }
 hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { *n = 7; return hipSuccess; }
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = reinterpret_cast<hipGraphExec_t>(std::malloc(8)); return hipSuccess; }
