@@ -381,6 +381,8 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *      8  no persistent ws kernels (generic tiles)
  *     16  treat every conv as non-uniform taps (v3 / generic kernels)                          64  v3 kernel instead of the ws kernel
  *    128  no ws64 kernel      256  ws64 without the row-halo variant      512  generic resize instead of the x2 kernel
+ *  32768  layer2's 128-channel layers at one to four poses on the 64 x 256 tile of conv_igemm_ws_kernel as before (default since round 6:
+ *          64-channel x 128-pixel tiles of conv_igemm_m32_kernel with the K split, residual added in the epilogue)
  *  16384  no K split of the 256-channel GEMM's launches of few tiles (small batches; default since round 6: the K loop of a 64 / 128-channel x
  *          128-pixel tile is cut into up to four parts, one workgroup each, when the tiles fill at most half the CUs; fixed-order fp32 sum)
  *   2048  per-point NOCS branch as in rounds 1-5: a gather launch and six fp32 1x1 GEMM launches (default since round 6: point_mlp_kernel)

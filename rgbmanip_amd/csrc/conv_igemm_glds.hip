@@ -1934,6 +1934,11 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
             const int pick = g_gemm_kernel == 1 ? 256 : m32_small_choice(d, n_cu, slim_tiles <= n_cu);
             if (pick) return launch_m32_small<T>(d, s, pick);
           }
+          // layer2's 128-channel layers at one to four poses (13-52 tiles of 64 x 256): 64-channel x 128-pixel tiles of the 32x32x16 kernel with
+          // their K loop split (conv_igemm_m32.inc) — taken only where the split applies, i.e. while twice the tiles still fit the grid
+          if (d.Cout == 128 && ((d.M + 127) / 128) * 2 * 2 <= n_cu && g_gemm_kernel == 2 && !(g_debug_flags & ((1 << 30) | 65536 | 16384 | 32768)) &&
+              d.w2 == nullptr && conv_buffer_offsets_ok(d, 64, sizeof(T)))
+            return launch_m32_small<T>(d, s, 64);
         }
         if (slim_tiles <= n_cu) return launch_ws<T, false, false, true>(d, s);
       }
