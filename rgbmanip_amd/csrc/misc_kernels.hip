@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512) void psp_pool_conv_kernel(const T* __restrict_
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-#pragma unroll 4
+#pragma unroll 8                                            // (eight loads in flight per thread: the one-bin cell walks 98 pixels per lane; same order of the sums)
     for (int p = pl; p < npx; p += PL) {
       const int h = h0 + p / ww, w = w0 + p % ww;
       float x[E];
