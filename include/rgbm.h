@@ -352,7 +352,9 @@ int rgbm_adapose_forward_ex(rgbm_adapose_t* h, int B, const float* img1, const f
  * keeps the instantiated graph (up to 8 per handle, least recently used evicted; dropped when an option changes); later calls with the
  * same arguments replay it with one hipGraphLaunch.  The caller keeps every buffer alive and at the same address.  `stream` must be
  * a created (non-null) stream.  *n_nodes (optional) = graph nodes (kernel launches + copies) of this batch size; *captured
- * (optional) = 1 when this call did the capture, 0 on a replay, -1 when it ran eagerly because rgbm_prof_start is active. */
+ * (optional) = 1 when this call did the capture, 0 on a replay, -1 when it ran eagerly because rgbm_prof_start is active.
+ * Pass the same `stream` for every call on one set of buffers: the captured launches of a small batch use the K-split scratch of the stream
+ * they were captured on (rgbm_debug_flags 16384), which other streams' forwards do not share. */
 int rgbm_adapose_forward_graph(rgbm_adapose_t* h, int B, const float* img1, const float* img2, const int32_t* choose1,
                                const int32_t* choose2, const float* P1, const float* P2, const float* depths, void* workspace,
                                size_t workspace_bytes, const rgbm_adapose_out* out, void* stream, int32_t* n_nodes, int32_t* captured);
