@@ -109,7 +109,7 @@ struct SweepDesc {
   const float* homog;             // [V][12]
   const float* depths;            // [B][D]
   unsigned short* out;            // [N][D][H][W][8] bf16
-  int N, D, H, W, v0, V, B, nth, ntw, relu, dbg;
+  int N, D, H, W, v0, V, B, nth, ntw, relu;
   const int* tile_list; const int* tile_count;      // sparse cost regularisation: only these tiles (ascending), else null
 };
 
@@ -988,7 +988,6 @@ int launch_conv0_sweep(const Conv3dTileDesc& t, int dtype, hipStream_t s) {
   d.out = reinterpret_cast<unsigned short*>(t.out);
   d.N = t.N; d.D = t.Di; d.H = t.Hi; d.W = t.Wi; d.v0 = t.v0; d.V = t.V; d.B = t.B; d.relu = t.relu;
   d.nth = (d.H + SW_TH - 1) / SW_TH; d.ntw = (d.W + SW_TW - 1) / SW_TW;
-  d.dbg = g_debug_flags;
   d.tile_list = t.tile_list; d.tile_count = t.tile_count;
   RGBM_REQUIRE(d.feat && d.wgt && d.bias && d.homog && d.depths && d.out && d.D >= 1 && d.D <= 64 && t.Cout == 8, "conv0 sweep arguments");
   RGBM_REQUIRE(t.relu == 1, "conv0 sweep: the kernel applies conv0's ReLU unconditionally");

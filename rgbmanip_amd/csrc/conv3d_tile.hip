@@ -128,9 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
   if (tid < VS / 16) reinterpret_cast<uint4*>(halo + ZERO_OFF)[tid] = make_uint4(0u, 0u, 0u, 0u);
 
   // ---- stage the input halo (all global loads of a batch are issued before the first LDS write) ----
-  if (d.dbg & 1) {
-    for (int i = tid; i < NVH * CPV; i += 256) reinterpret_cast<uint4*>(halo)[i] = make_uint4(0u, 0u, 0u, 0u);
-  } else if constexpr (!WARP) {
+  if constexpr (!WARP) {
     const T* __restrict__ in = reinterpret_cast<const T*>(d.in);
     constexpr int TOTAL = NVH * CPV;
     constexpr int ITERS = (TOTAL + 255) / 256;
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
     if constexpr (std::is_same<T, bx3_t>::value) {
       // split pairs: two consecutive steps (2 x 4 k values per lane, hi and lo) make the operands of the full-rate 16x16x32
       // instruction; an odd last step runs on the K=16 form
-      if (!(d.dbg & 2)) {
+      {
         // same schedule as the 16-bit path below, in units of step PAIRS: the operands of pair p + 1 are read from LDS before the
         // MFMAs of pair p (two register sets), the packed weights run two pairs ahead through a register ring
         constexpr int NP = (NS + 1) / 2;
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_tile_kernel(const Conv3dTileDes
         });
       }
     } else {
-    if (!(d.dbg & 2)) {
+    {
       // B operands of step s + 1 are read from LDS before the MFMAs of step s (two register sets).  Left alone hipcc emitted
       // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma for every single MFMA, re-using one register quad: the LDS round trip (~120
       // cycles) in front of each 16-cycle instruction — the tap loop ran at a quarter of the matrix rate.
@@ -495,7 +493,6 @@ static int launch_c3(Conv3dTileDesc d, hipStream_t s) {
   RGBM_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv3d grid out of range");
   auto kern = conv3d_tile_kernel<T, CIN, COUTP, TD, TH, TW, STRIDE, TR, WARP, WC>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)LDS)) return rc;
-  d.dbg = g_debug_flags;
   prof_begin_launch(s, d.prof_variant, d.algo_flops, d.algo_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, s, d);
   prof_end_launch(s);

@@ -1968,8 +1968,9 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
     if constexpr (std::is_same<T, bx3_t>::value) {
       // split pairs, layer1's 64-channel layers at a batch that fills the grid: 64-channel x 256-pixel tiles of the 32x32x16 kernel (the 16-bit
-      // types have the row-halo ws64 kernel for these layers; split pairs ran them on the 16x16x32 four-wave tile at half the matrix rate of
-      // the 256-channel layers).  Debug flag 65536: as before.
+      // types have the row-halo ws64 kernel for these layers — measured against this tile in bf16: 38.10 ms per forward with ws64, 38.39 with
+      // <bf16, 256, 64> —; split pairs ran them on the 16x16x32 four-wave tile at half the matrix rate of the 256-channel layers).
+      // Debug flag 65536: as before.
       int n_cu = 0;
       if (int rc = persistent_grid_cus(&n_cu)) return rc;
       if (d.Cout == 64 && (al & 15ull) == 0ull && d.M / 256 >= n_cu && g_gemm_kernel == 2 && !(g_debug_flags & 65536) && conv_buffer_offsets_ok(d, 64, sizeof(T)))

@@ -94,7 +94,6 @@ struct Conv3dTileDesc {
   const void* feat; const float* homog; const float* depths; int v0, V, B;   // fused-warp mode only
   int prof_variant; double algo_flops, algo_bytes;
   int out_classmajor;           // transposed only: write each sub-pixel class as its own dense [N][Dq][Hq][Wq][C] volume
-  int dbg;                      // ablation bits (benchmark only): 1 = skip halo staging work, 2 = skip the MFMA phase
   int feat_f16;      // depth-sweeping conv0 of a bf16 net: `feat` and `wgt` are f16 (AdaPose::feat_f16()), the output stays bf16
   const int* tile_list; const int* tile_count;      // depth-sweeping conv0 only: walk tile_list[0 .. tile_count[0]) instead of all tiles
   int tile_mask_stride;             // bytes between consecutive views' masks (0: nth * ntw)
