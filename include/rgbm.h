@@ -375,8 +375,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *  30     (unused since round 6)                     31 / 32  ws 256 x 128 tile 16-bit / (32: unused since round 6)
  *  33     ws 256 x 128 tile bf16x3                   34 / 35 / 36  ws 64 x 256 four-multiply-wave tile bf16x3 / 16-bit / f32
  *  37 / 38 upconv_combine_kernel 16-bit / 4-byte storage                39  upconv_final_kernel
- *  40 / 41 conv_igemm_m32_kernel<T, 128, 64 / 128 / 256>: the 128-pixel tail and small-batch launches of rows 31 / 33 (16-bit / bf16x3; row 41 also
- *          conv_igemm_m32_kernel<bx3_t, 256, 64>: layer1's 64-channel layers in split pairs, round 6;
+ *  40 / 41 conv_igemm_m32_kernel<T, 128, 64 / 128 / 256>: the 128-pixel tail and small-batch launches of rows 31 / 33 (16-bit / bf16x3;
  *          rows 31 / 33 are conv_igemm_m32_kernel<T, 256, 256> under the default gemm_kernel = 2, conv_igemm_ws_kernel<T, wide> under gemm_kernel = 0)
  * stop synchronises on the recorded events. */
 #define RGBM_PROF_ROWS 42
@@ -391,7 +390,7 @@ int rgbm_adapose_fetch(rgbm_adapose_t* h, int B, void* workspace, const char* na
  *   2048  per-point NOCS branch as in rounds 1-5: a gather launch and six fp32 1x1 GEMM launches (default since round 6: point_mlp_kernel)
  *   1024  PSP stage as in rounds 1-5: copy, pooling, four 1x1 GEMM launches, four resize launches (default since round 6: one concat launch;
  *          up to 32 views also pooling + the four 1x1 convs in one launch on the vector pipe)
- *   4096  halo-tile conv0 instead of the plane-sweep kernels             65536  128 x 256 ws tile even where the 256-channel tiles apply (and the 64 x 256 ws tile for split-pair 64-channel layers)
+ *   4096  halo-tile conv0 instead of the plane-sweep kernels             65536  128 x 256 ws tile even where the 256-channel tiles apply
  *          (4 / 8192 / 131072 selected the register-staged kernel, the 256 x 256 two-group kernel and the row-halo wide tile of rounds
  *          1-2: measured slower, removed in round 6; the bits are ignored)
  * 262144  generic tile instead of the 64 x 256 four-wave ws tile         1048576  ws request waves walk K taps outer, channel blocks inner

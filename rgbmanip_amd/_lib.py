@@ -51,7 +51,7 @@ PROF_KERNELS = [
      ("upconv_combine_kernel<16-bit> (PSPUpsample tap combination)", "bf16"), ("upconv_combine_kernel<4-byte> (PSPUpsample tap combination)", "bf16x3"),
      ("upconv_final_kernel (up_3 + final in one kernel; either storage width)", "bf16"),
      ("conv_igemm_m32_kernel<unsigned short, 128, 64 / 128 / 256> (128-pixel tiles: tail and small-batch launches of the 256-channel GEMM)", "bf16"),
-     ("conv_igemm_m32_kernel<rgbm::bx3_t, 128, 64 / 128 / 256> (128-pixel tiles: tail and small-batch launches of the 256-channel GEMM) and <rgbm::bx3_t, 256, 64> (layer1 in split pairs)", "bf16x3")]
+     ("conv_igemm_m32_kernel<rgbm::bx3_t, 128, 64 / 128 / 256> (128-pixel tiles: tail and small-batch launches of the 256-channel GEMM)", "bf16x3")]
 assert len(PROF_KERNELS) == PROF_ROWS
 
 

@@ -1966,16 +1966,8 @@ static int launch_dtype_g(const ConvDesc& d, hipStream_t s) {
   // role-specialised kernel with a 64 x 256 tile and four multiply waves
   if (conv_ch_tile(d.Cout) == 64 && uni && d.M >= ws_min_rows(sizeof(T)) && d.M < (1ll << 31) && !(g_debug_flags & (8 | 64 | 262144))) {
     const unsigned long long al = (unsigned long long)d.out | ((unsigned long long)d.ldo * sizeof(T)) | (d.res ? (unsigned long long)d.res : 0ull);
-    if constexpr (std::is_same<T, bx3_t>::value) {
-      // split pairs, layer1's 64-channel layers at a batch that fills the grid: 64-channel x 256-pixel tiles of the 32x32x16 kernel (the 16-bit
-      // types have the row-halo ws64 kernel for these layers — measured against this tile in bf16: 38.10 ms per forward with ws64, 38.39 with
-      // <bf16, 256, 64> —; split pairs ran them on the 16x16x32 four-wave tile at half the matrix rate of the 256-channel layers).
-      // Debug flag 65536: as before.
-      int n_cu = 0;
-      if (int rc = persistent_grid_cus(&n_cu)) return rc;
-      if (d.Cout == 64 && (al & 15ull) == 0ull && d.M / 256 >= n_cu && g_gemm_kernel == 2 && !(g_debug_flags & 65536) && conv_buffer_offsets_ok(d, 64, sizeof(T)))
-        return launch_m32_64<T>(d, s);
-    }
+    // (round 6 measured 64-channel x 256-pixel tiles of the 32x32x16 kernel for layer1's 64-channel layers at batch 256: split pairs 0.542 ms
+    // per launch against 0.475 on this tile, bf16 38.39 ms per forward against 38.10 with the row-halo ws64 kernel — not dispatched)
     if ((al & 15ull) == 0ull) return launch_ws<T, false, false, true>(d, s);
   }
   return uni ? launch_t_g<T, true>(d, s) : launch_t_g<T, false>(d, s);

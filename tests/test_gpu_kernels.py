@@ -202,38 +202,6 @@ def test_conv2d_gemm_kernel_variants(case, dtype):
     assert rel_err(ysp[0], ys[2]) < {_lib.BF16: 2.0 ** -7, _lib.F16: 2.0 ** -10, _lib.BF16X3: 1e-5}[dtype], name
 
 
-@pytest.mark.parametrize("res_mode", [0, 1], ids=["plain", "res_pre"])
-def test_conv2d_split_pair_64_channel_layers_on_the_32x32x16_tiles(res_mode):
-    """layer1's 64-channel 3x3 layers in split pairs at a batch that fills the grid (round 6: 64-channel x 256-pixel tiles of
-    conv_igemm_m32_kernel + a 128-pixel rest, residual on the matrix pipe) against F.conv2d on the same rounded operands and against the
-    16x16x32 four-wave tile they ran on before (debug flag 65536): same products, other MFMA shape — fp32 rounding apart; three runs bit
-    for bit.  M = 26 x 56 x 56 = 81536 rows: one round of 256 tiles + 62.5 tiles left for the 128-pixel launch."""
-    from gpu_util import conv_nd, rel_err
-    lib = _lib.load()
-    dtype = _lib.BF16X3
-    g = torch.Generator().manual_seed(31 + res_mode)
-    x = _q(torch.randn(26, 64, 56, 56, generator=g), dtype)
-    w = _q(torch.randn(64, 64, 3, 3, generator=g) / np.sqrt(64 * 9), dtype)
-    b = torch.randn(64, generator=g) * 0.1
-    ref = F.conv2d(x, w, b, 1, 1, 1)
-    res = _q(torch.randn(ref.shape, generator=g), dtype) if res_mode else None
-    if res_mode:
-        ref = ref + res
-    ref = F.relu(ref)
-    run = lambda: conv_nd(dtype, x, w, stride=1, pad=1, dil=1, bias=b, res=res, res_mode=res_mode, act=1)      # noqa: E731
-    try:
-        lib.rgbm_debug_flags(65536)
-        y_old = run()
-    finally:
-        lib.rgbm_debug_flags(0)
-    ys = [run() for _ in range(3)]
-    for y in ys:
-        assert torch.isfinite(y).all() and rel_err(y, ref) < TOL[dtype]
-        assert torch.equal(y, ys[0])
-    assert rel_err(ys[0], y_old) < 3e-5      # (two split-pair evaluations of the same products: each within ~1e-5 of the exact sums)
-    assert not torch.equal(ys[0], y_old), "the default launch of this shape is expected to take the 32x32x16 tiles"
-
-
 @pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F16, _lib.BF16X3], ids=["bf16", "fp16", "bf16x3"])
 def test_conv2d_k_split_is_stable_over_many_runs(dtype):
     """The K split of launches with few tiles (conv_igemm_m32.inc: parts of a tile's K loop on different workgroups — on any XCD —, partial
